@@ -1,0 +1,161 @@
+/*
+ * spacecarve.h -- C ABI of the MI355X (gfx950) voxel back-projection engine.
+ *
+ * This is the drop-in boundary for the reference's device layer: everything
+ * plant3dvision/cl.py::Backprojection does with PyOpenCL (cl.py:118-311) maps onto
+ * the entry points below, and nothing else of plant-3d-vision is replaced.  Plain
+ * pointers and sizes only; no torch / HIP types in any signature.  The host-side
+ * mirror (plant-3d-vision_amd/cl.py) binds these with cffi (ABI mode) or ctypes;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (all from the reference):
+ *   - grid state is C-order [nx][ny][nz], z fastest   (kernels/common.h:1-12)
+ *   - carve state int32 in {-1 carved, 0 unseen, 1 kept} (kernels/backprojection.c:67-83)
+ *   - average state float32 running sum in view order    (kernels/backprojection.c:54)
+ *   - K = [fx, fy, cx, cy], R row-major 3x3, t: float32   (cl.py:293-296)
+ *   - masks are row-major [H][W]; u = column, v = row     (cl.py:217)
+ *   - arithmetic: IEEE binary32, no contraction, correctly rounded divide,
+ *     (int) cast rejecting NaN/inf/out-of-range
+ *
+ * Threading: one engine per host thread; engines are not shared.  Every call
+ * returns SC_OK (0) or a negative code; sc_last_error() gives the thread-local
+ * message of the most recent failure.
+ */
+#ifndef SPACECARVE_H
+#define SPACECARVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+
+/* error codes */
+#define SC_OK 0
+#define SC_ERR_INVALID (-1)   /* bad argument                        */
+#define SC_ERR_DEVICE (-2)    /* HIP runtime error / no gfx950 device */
+#define SC_ERR_NOMEM (-3)     /* host or device allocation failed     */
+#define SC_ERR_STATE (-4)     /* call not valid in the engine's state */
+
+/* sc_create mode -- replaces the kernel choice at cl.py:145-152 */
+#define SC_MODE_CARVE 0   /* `carve`,   int32 state   (backprojection.c:57-84) */
+#define SC_MODE_AVERAGE 1 /* `average`, float32 state (backprojection.c:36-55) */
+
+/* mask element types accepted by sc_process_view* */
+#define SC_MASK_U8 0  /* carve: foreground = (value != 0), the test at backprojection.c:79 */
+#define SC_MASK_I32 1 /* carve: what cl.py:215 casts to                                    */
+#define SC_MASK_F32 2 /* average: the value added at backprojection.c:54                   */
+
+/* sc_set_option keys */
+#define SC_OPT_VIEWS_PER_LAUNCH 1 /* 0 (default): defer views, fuse all pending views into one
+                                     launch at flush; n>0: launch every n views (1 = one launch
+                                     per view, the reference's schedule cl.py:223-226)        */
+#define SC_OPT_VIEW_ORDER 2       /* carve only. 0: as given; 1 (default): stride-interleaved
+                                     order inside a fused launch (legal: the carve state is
+                                     order-independent). average always keeps
+                                     the given order (float sum).                             */
+#define SC_OPT_TIME_KERNELS 3     /* 1: bracket every kernel launch with HIP events on the
+                                     engine's stream; read with sc_kernel_stats              */
+#define SC_OPT_MAX_PENDING 4      /* deferred views that force a flush (default 256)          */
+
+/* kernel ids for sc_kernel_stats */
+#define SC_KERNEL_CARVE 0
+#define SC_KERNEL_AVERAGE 1
+#define SC_KERNEL_PACK 2
+#define SC_KERNEL_FILL 3
+
+typedef struct sc_engine sc_engine;
+
+int sc_abi_version(void);
+const char *sc_last_error(void);
+/* number of visible HIP devices whose architecture is gfx950 */
+int sc_device_count(int *count);
+
+/*
+ * Create an engine owning the whole grid.  Replaces Backprojection.__init__ +
+ * init_buffers (cl.py:118-188): state = default_value everywhere (cl.py:173-175),
+ * volinfo = {origin, voxel_size} as float32 (cl.py:181-183), shape (cl.py:185-187).
+ * device: HIP device ordinal.
+ */
+int sc_create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],
+              float voxel_size, int mode, float default_value, int device);
+
+/*
+ * Same, but the engine owns only the X-slab i in [i0, i1) of the global grid
+ * (multi-GPU sharding).  Voxel coordinates are still computed from
+ * the GLOBAL index (origin_x + (float)i * voxel_size), never from a shifted origin.
+ * State / sc_get_values cover (i1-i0)*ny*nz elements.
+ */
+int sc_create_slab(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t i1,
+                   const float origin[3], float voxel_size, int mode, float default_value,
+                   int device);
+
+void sc_destroy(sc_engine *e);
+
+/* Backprojection.clear (cl.py:307-311): reset state to default_value, drop pending views. */
+int sc_clear(sc_engine *e);
+
+int sc_set_option(sc_engine *e, int key, int64_t value);
+
+/* Run the engine's work on an existing hipStream_t (e.g. torch's current stream);
+ * NULL restores the engine's own stream. */
+int sc_set_stream(sc_engine *e, void *hip_stream);
+
+/*
+ * Backprojection.process_view (cl.py:190-227): one view from a HOST mask.
+ * The mask is consumed before the call returns (the caller may free it); the kernel
+ * launch itself may be deferred (SC_OPT_VIEWS_PER_LAUNCH).  row_stride_bytes = 0 means
+ * tightly packed rows.  mask_dtype must fit the mode (U8/I32 carve, F32 average).
+ */
+int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
+                    const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes);
+
+/* V views at once: K[V*4], R[V*9], t[V*3], masks[V] host pointers, common H, W, dtype. */
+int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                     const void *const *masks, int H, int W, int mask_dtype,
+                     int64_t row_stride_bytes);
+
+/*
+ * V views whose masks are already resident in device memory on the engine's device,
+ * contiguous [V][H][W] (the Masks2D / bench path: no host round trip).  The buffer must
+ * stay valid until the next sc_flush / sc_get_values / sc_synchronize returns.
+ */
+int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                            const void *masks_dev, int H, int W, int mask_dtype);
+
+/* Launch everything still deferred (asynchronous on the engine's stream). */
+int sc_flush(sc_engine *e);
+/* sc_flush + wait for the stream: the role of queue.finish() (cl.py:226). */
+int sc_synchronize(sc_engine *e);
+
+/*
+ * Backprojection.get_values (cl.py:229-232): flush, wait, copy the state to `out`
+ * (int32 or float32, C-order, (i1-i0)*ny*nz elements).
+ */
+int sc_get_values(sc_engine *e, void *out);
+
+/* Flush and return the device pointer of the state slab (valid until sc_destroy);
+ * work may still be running on the engine's stream. */
+int sc_values_device_ptr(sc_engine *e, void **ptr);
+
+/* number of voxels this engine owns */
+int64_t sc_num_voxels(const sc_engine *e);
+
+/* With SC_OPT_TIME_KERNELS: launches and summed HIP-event milliseconds per kernel id
+ * since the last sc_reset_kernel_stats (waits for the stream). */
+int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *total_ms);
+int sc_reset_kernel_stats(sc_engine *e);
+
+/* Device-memory helpers so that hosts without a HIP binding can stage inputs in HBM
+ * (bench.py, tests): plain hipMalloc / hipMemcpy / hipFree on the engine's device. */
+int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr);
+int sc_dev_free(sc_engine *e, void *ptr);
+int sc_dev_upload(sc_engine *e, void *dst_dev, const void *src_host, int64_t bytes);
+int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPACECARVE_H */

@@ -1,0 +1,302 @@
+"""Loader and thin binding of ``libspacecarve.so`` (the C ABI in ``include/spacecarve.h``).
+
+The north star asks for cffi; cffi (ABI mode, ``ffi.dlopen``) is used when it is importable
+and stdlib ``ctypes`` otherwise (``SPACECARVE_FFI=cffi|ctypes`` forces one).  Both paths
+pass every pointer as a plain address, so the rest of the package never sees a backend
+type.  There is no CPU fallback: if the library is missing or no gfx950 device is
+visible, calls raise.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libspacecarve.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "spacecarve.h")
+
+# constants of include/spacecarve.h
+SC_OK = 0
+SC_ERR_INVALID, SC_ERR_DEVICE, SC_ERR_NOMEM, SC_ERR_STATE = -1, -2, -3, -4
+SC_MODE_CARVE, SC_MODE_AVERAGE = 0, 1
+SC_MASK_U8, SC_MASK_I32, SC_MASK_F32 = 0, 1, 2
+SC_OPT_VIEWS_PER_LAUNCH, SC_OPT_VIEW_ORDER, SC_OPT_TIME_KERNELS, SC_OPT_MAX_PENDING = 1, 2, 3, 4
+SC_KERNEL_CARVE, SC_KERNEL_AVERAGE, SC_KERNEL_PACK, SC_KERNEL_FILL = 0, 1, 2, 3
+
+# name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
+_SIGNATURES = {
+    "sc_abi_version": ("i", []),
+    "sc_last_error": ("s", []),
+    "sc_device_count": ("i", ["p"]),
+    "sc_create": ("i", ["p", "q", "q", "q", "p", "f", "i", "f", "i"]),
+    "sc_create_slab": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
+    "sc_destroy": ("v", ["p"]),
+    "sc_clear": ("i", ["p"]),
+    "sc_set_option": ("i", ["p", "i", "q"]),
+    "sc_set_stream": ("i", ["p", "p"]),
+    "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
+    "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
+    "sc_process_views_device": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i"]),
+    "sc_flush": ("i", ["p"]),
+    "sc_synchronize": ("i", ["p"]),
+    "sc_get_values": ("i", ["p", "p"]),
+    "sc_values_device_ptr": ("i", ["p", "p"]),
+    "sc_num_voxels": ("q", ["p"]),
+    "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
+    "sc_reset_kernel_stats": ("i", ["p"]),
+    "sc_dev_alloc": ("i", ["p", "q", "p"]),
+    "sc_dev_free": ("i", ["p", "p"]),
+    "sc_dev_upload": ("i", ["p", "p", "p", "q"]),
+    "sc_dev_download": ("i", ["p", "p", "p", "q"]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float,
+       "s": ctypes.c_char_p, "v": None}
+_CDEF = {"p": "void *", "i": "int", "q": "int64_t", "f": "float", "s": "const char *",
+         "v": "void"}
+
+
+class SpaceCarveError(RuntimeError):
+    """A C-ABI call failed (device / memory / state)."""
+
+
+def build(force=False):
+    """Compile ``csrc/spacecarve.hip`` for gfx950 into ``libspacecarve.so`` (in-tree)."""
+    src = os.path.join(_PKG_DIR, "csrc", "spacecarve.hip")
+    deps = [src, HEADER_PATH, os.path.join(_PKG_DIR, "csrc", "Makefile")]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", os.path.join(_PKG_DIR, "csrc"), "-s", "-B", "all"])
+    return LIB_PATH
+
+
+class _CtypesBackend:
+    name = "ctypes"
+
+    def __init__(self, path):
+        self.lib = ctypes.CDLL(path)
+        self.fn = {}
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(self.lib, name)
+            f.restype = _CT[res]
+            f.argtypes = [_CT[a] for a in args]
+            self.fn[name] = f
+
+    def call(self, name, *args):
+        return self.fn[name](*args)
+
+    @staticmethod
+    def string(ret):
+        return (ret or b"").decode("utf-8", "replace")
+
+
+class _CffiBackend:
+    name = "cffi"
+
+    def __init__(self, path):
+        import cffi  # noqa: F401  (ImportError -> caller falls back to ctypes)
+
+        self.ffi = cffi.FFI()
+        decls = []
+        for name, (res, args) in _SIGNATURES.items():
+            decls.append(f"{_CDEF[res]} {name}({', '.join(_CDEF[a] for a in args) or 'void'});")
+        self.ffi.cdef("\n".join(decls))
+        self.lib = self.ffi.dlopen(path)
+        self.sig = _SIGNATURES
+
+    def call(self, name, *args):
+        kinds = self.sig[name][1]
+        conv = [self.ffi.cast("void *", int(a or 0)) if k == "p" else a for k, a in zip(kinds, args)]
+        return getattr(self.lib, name)(*conv)
+
+    def string(self, ret):
+        return self.ffi.string(ret).decode("utf-8", "replace") if ret else ""
+
+
+_backend = None
+
+
+def backend():
+    """Load the library once.  Raises ``SpaceCarveError`` if it is not built."""
+    global _backend
+    if _backend is not None:
+        return _backend
+    if not os.path.exists(LIB_PATH):
+        raise SpaceCarveError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C plant-3d-vision_amd/csrc` (needs hipcc, gfx950)")
+    want = os.environ.get("SPACECARVE_FFI", "").lower()
+    if want not in ("", "cffi", "ctypes"):
+        raise ValueError("SPACECARVE_FFI must be 'cffi' or 'ctypes'")
+    if want != "ctypes":
+        try:
+            _backend = _CffiBackend(LIB_PATH)
+            return _backend
+        except ImportError:
+            if want == "cffi":
+                raise
+    _backend = _CtypesBackend(LIB_PATH)
+    return _backend
+
+
+def last_error():
+    b = backend()
+    return b.string(b.call("sc_last_error"))
+
+
+def check(rc, what):
+    if rc == SC_OK:
+        return
+    msg = f"{what}: {last_error()} (code {rc})"
+    if rc == SC_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == SC_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise SpaceCarveError(msg)
+
+
+def addr(a):
+    """Address of a C-contiguous ndarray's data."""
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def device_count():
+    out = np.zeros(1, dtype=np.int32)
+    check(backend().call("sc_device_count", addr(out)), "sc_device_count")
+    return int(out[0])
+
+
+class Engine:
+    """Owning handle of one ``sc_engine`` (whole grid or an X-slab of it)."""
+
+    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None):
+        self._b = backend()
+        self._h = 0
+        nx, ny, nz = (int(s) for s in shape)
+        origin32 = np.ascontiguousarray(np.asarray(origin, dtype=np.float32).reshape(3))
+        out = np.zeros(1, dtype=np.uintp)
+        if slab is None:
+            rc = self._b.call("sc_create", addr(out), nx, ny, nz, addr(origin32),
+                              float(np.float32(voxel_size)), int(mode), float(default_value),
+                              int(device))
+            self.slab = (0, nx)
+        else:
+            i0, i1 = int(slab[0]), int(slab[1])
+            rc = self._b.call("sc_create_slab", addr(out), nx, ny, nz, i0, i1, addr(origin32),
+                              float(np.float32(voxel_size)), int(mode), float(default_value),
+                              int(device))
+            self.slab = (i0, i1)
+        check(rc, "sc_create")
+        self._h = int(out[0])
+        self.mode = int(mode)
+        self.shape = (nx, ny, nz)
+        self.slab_shape = (self.slab[1] - self.slab[0], ny, nz)
+        self.dtype = np.int32 if mode == SC_MODE_CARVE else np.float32
+        self.device = int(device)
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._b.call("sc_destroy", self._h)
+            self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        if not self._h:
+            raise SpaceCarveError("engine is closed")
+        check(self._b.call(name, self._h, *args), name)
+
+    # -- options ----------------------------------------------------------------------
+    def set_option(self, key, value):
+        self._call("sc_set_option", int(key), int(value))
+
+    def set_stream(self, stream_ptr):
+        self._call("sc_set_stream", int(stream_ptr or 0))
+
+    # -- work -------------------------------------------------------------------------
+    def clear(self):
+        self._call("sc_clear")
+
+    @staticmethod
+    def _pose(K, R, t):
+        K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(-1))
+        R = np.ascontiguousarray(np.asarray(R, dtype=np.float32).reshape(-1))
+        t = np.ascontiguousarray(np.asarray(t, dtype=np.float32).reshape(-1))
+        return K, R, t
+
+    def process_view(self, K, R, t, mask, mask_dtype):
+        K, R, t = self._pose(K, R, t)
+        if K.size != 4 or R.size != 9 or t.size != 3:
+            raise ValueError("need intrinsics[4], rot[9], tvec[3]")
+        if mask.ndim != 2:
+            raise ValueError("mask must be 2-D (H, W)")
+        mask = np.ascontiguousarray(mask)
+        H, W = mask.shape
+        self._call("sc_process_view", addr(K), addr(R), addr(t), addr(mask), H, W,
+                   int(mask_dtype), 0)
+
+    def process_views_device(self, K, R, t, masks_dev, n_views, H, W, mask_dtype):
+        K, R, t = self._pose(K, R, t)
+        if K.size != 4 * n_views or R.size != 9 * n_views or t.size != 3 * n_views:
+            raise ValueError("pose arrays do not match the view count")
+        self._call("sc_process_views_device", int(n_views), addr(K), addr(R), addr(t),
+                   int(masks_dev), int(H), int(W), int(mask_dtype))
+
+    def flush(self):
+        self._call("sc_flush")
+
+    def synchronize(self):
+        self._call("sc_synchronize")
+
+    def get_values(self, out=None):
+        if out is None:
+            out = np.empty(self.slab_shape, dtype=self.dtype)
+        if out.dtype != self.dtype or out.size != int(np.prod(self.slab_shape)) \
+                or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("output buffer has the wrong dtype/size/layout")
+        self._call("sc_get_values", addr(out))
+        return out
+
+    def values_device_ptr(self):
+        out = np.zeros(1, dtype=np.uintp)
+        self._call("sc_values_device_ptr", addr(out))
+        return int(out[0])
+
+    def num_voxels(self):
+        return int(self._b.call("sc_num_voxels", self._h))
+
+    # -- timing -----------------------------------------------------------------------
+    def kernel_stats(self, kernel_id):
+        n = np.zeros(1, dtype=np.int64)
+        ms = np.zeros(1, dtype=np.float64)
+        self._call("sc_kernel_stats", int(kernel_id), addr(n), addr(ms))
+        return int(n[0]), float(ms[0])
+
+    def reset_kernel_stats(self):
+        self._call("sc_reset_kernel_stats")
+
+    # -- device memory helpers --------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        out = np.zeros(1, dtype=np.uintp)
+        self._call("sc_dev_alloc", int(nbytes), addr(out))
+        return int(out[0])
+
+    def dev_free(self, ptr):
+        self._call("sc_dev_free", int(ptr))
+
+    def dev_upload(self, dst_dev, src):
+        src = np.ascontiguousarray(src)
+        self._call("sc_dev_upload", int(dst_dev), addr(src), int(src.nbytes))
+
+    def dev_download(self, dst, src_dev):
+        assert dst.flags["C_CONTIGUOUS"]
+        self._call("sc_dev_download", addr(dst), int(src_dev), int(dst.nbytes))

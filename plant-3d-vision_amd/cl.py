@@ -1,0 +1,243 @@
+"""Host-side mirror of ``plant3dvision.cl.Backprojection`` over the MI355X engine.
+
+Same class name, constructor, attributes, methods and error behaviour as the reference
+(``plant3dvision/cl.py:47-311``); the PyOpenCL context/queue/kernels are replaced by the
+HIP engine behind ``include/spacecarve.h``.  Differences a caller can observe:
+
+* ``process_view`` only *enqueues* the view (the mask is consumed before it returns);
+  the carve itself runs when values are requested, when ``flush()`` is called, or every
+  ``views_per_launch`` views.  The reference's per-view ``queue.finish()`` (cl.py:226) is
+  ``synchronize()``.  Results are identical because nothing is observable in between.
+* ``values_d`` & co. are not OpenCL buffers (``values_d`` is the device address, the
+  small pose buffers do not exist).
+* There is no CPU path: constructing an instance without the built library or without a
+  gfx950 GPU raises.
+"""
+import logging
+
+import numpy as np
+
+from . import _native as nat
+
+logger = logging.getLogger(__name__)
+
+EPS = 1e-10  # cl.py:35
+
+
+def img_as_float32(image):
+    """What ``skimage.util.img_as_float32`` (scikit-image, unpinned in the reference's
+    requirements.txt:19; call site cl.py:206) does for the mask dtypes that occur:
+    unsigned ints are MULTIPLIED by float32(1/max) (skimage.util.dtype._convert), bool
+    becomes {0, 1}, floats are cast.  Parity of this third-party step is unpinned."""
+    image = np.asarray(image)
+    if image.dtype == np.float32:
+        return image
+    if image.dtype == np.bool_:
+        return image.astype(np.float32)
+    if image.dtype.kind == "u":
+        imax = np.iinfo(image.dtype).max
+        comp = np.float32 if image.dtype.itemsize <= 2 else np.float64
+        return np.multiply(image, 1.0 / imax, dtype=comp).astype(np.float32, copy=False)
+    if image.dtype.kind == "i":
+        info = np.iinfo(image.dtype)
+        comp = np.float32 if image.dtype.itemsize <= 2 else np.float64
+        out = np.add(image, 0.5, dtype=comp)
+        out *= 2 / (float(info.max) - float(info.min))
+        return out.astype(np.float32, copy=False)
+    if image.dtype.kind == "f":
+        return image.astype(np.float32)
+    raise ValueError(f"cannot convert mask of dtype {image.dtype} to float32")
+
+
+def read_image(fi):
+    """``plantdb.io.read_image`` (cl.py:298; plantdb is an unvendored submodule) when it is
+    importable; otherwise files that carry their pixels (``read_image()`` / ``array``)."""
+    try:
+        from plantdb import io  # type: ignore
+    except ImportError:
+        io = None
+    if io is not None and not hasattr(fi, "array") and not hasattr(fi, "read_image"):
+        return io.read_image(fi)
+    if hasattr(fi, "read_image"):
+        return fi.read_image()
+    if hasattr(fi, "array"):
+        return fi.array
+    raise TypeError(f"cannot read an image from {fi!r}: plantdb is not installed and the "
+                    f"object has neither read_image() nor .array")
+
+
+def auto_format_bytes(size_bytes, unit="octets"):
+    """plant3dvision/utils.py, used for the log line at cl.py:157."""
+    if unit.lower() in ("octets", "o"):
+        base, names = 1024, ["o", "Ko", "Mo", "Go", "To"]
+    else:
+        base, names = 1024, ["B", "KB", "MB", "GB", "TB"]
+    v = float(size_bytes)
+    for nm in names:
+        if v < base or nm == names[-1]:
+            return f"{v:.1f} {nm}"
+        v /= base
+
+
+class Backprojection(object):
+    """Back-projection onto a voxel volume (drop-in for ``plant3dvision.cl.Backprojection``).
+
+    Parameters are the reference's (cl.py:118); ``device`` and ``views_per_launch`` are
+    additions with neutral defaults.
+
+    Attributes
+    ----------
+    shape, origin, voxel_size, default_value, log, labels : as given
+    dtype : numpy.int32 ("carving") or numpy.float32 ("averaging")   (cl.py:145-150)
+    kernel : str, "carve" or "average" -- the HIP kernel that will run
+    values_h : numpy.ndarray, host copy of the volume (refreshed by ``get_values``)
+    values_d : int, device address of the volume (None until first needed)
+    """
+
+    def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, labels=None,
+                 log=False, device=0, views_per_launch=0):
+        self.shape = shape
+        self.origin = origin
+        self.voxel_size = voxel_size
+        self.default_value = default_value
+        self.log = log
+        self.labels = labels
+        if type == "carving":
+            self.dtype = np.int32
+            self.kernel = "carve"
+            self._mode = nat.SC_MODE_CARVE
+        elif type == "averaging":
+            self.dtype = np.float32
+            self.kernel = "average"
+            self._mode = nat.SC_MODE_AVERAGE
+        else:
+            raise ValueError(f"Unknown kernel type {type}, valid values are 'averaging' or 'carving'!")
+
+        buff_size = int(np.prod([int(s) for s in self.shape])) * np.dtype(self.dtype).itemsize
+        logger.info(f"Buffer shape is {self.shape}")
+        logger.info(f"Required memory for buffer is {auto_format_bytes(buff_size)}!")
+
+        self.device = device
+        self.views_per_launch = views_per_launch
+        self.values_h = None
+        self.values_d = None
+        self.intrinsics_d = None
+        self.rot_d = None
+        self.tvec_d = None
+        self.volinfo_d = None
+        self.shape_d = None
+        self._engine = None
+        self.init_buffers()
+
+    # ---------------------------------------------------------------------------------
+    def init_buffers(self):
+        """cl.py:171-188.  The host array is built lazily in ``get_values``/``values_h``
+        consumers; the device state starts as ``default_value`` everywhere."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
+                                  default_value=float(self.default_value), device=self.device)
+        if self.views_per_launch:
+            self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(self.views_per_launch))
+        self.values_h = np.ascontiguousarray(
+            self.default_value * np.ones(self.shape, dtype=self.dtype), dtype=self.dtype)
+        self.volinfo_d = np.array([*self.origin, self.voxel_size], dtype=np.float32)  # cl.py:182
+        self.shape_d = np.array(self.shape, dtype=np.int32)  # cl.py:186
+        return
+
+    def process_view(self, intrinsics, rot, tvec, mask):
+        """Process a new view (cl.py:190-227).
+
+        intrinsics: [f_x, f_y, c_x, c_y]; rot: rotation matrix (flattened row-major or 3x3);
+        tvec: translation; mask: 2-D array (uint8/bool/int for carving, anything
+        ``img_as_float32`` accepts for averaging).
+        """
+        mask = np.asarray(mask)
+        if self.dtype == np.float32 and mask.dtype != np.float32:
+            mask = img_as_float32(mask)  # cl.py:205-206
+        if self.log and self.dtype == np.float32:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mask = np.log(EPS + mask)  # cl.py:207-208
+
+        if self.dtype == np.int32:
+            # cl.py:215 casts to int32 and the kernel tests == 0 (backprojection.c:79);
+            # for 1-byte masks that test is done on the bytes themselves
+            if mask.dtype == np.bool_:
+                mask_h, code = np.ascontiguousarray(mask).view(np.uint8), nat.SC_MASK_U8
+            elif mask.dtype == np.uint8:
+                mask_h, code = np.ascontiguousarray(mask), nat.SC_MASK_U8
+            else:
+                mask_h, code = np.ascontiguousarray(mask, dtype=np.int32), nat.SC_MASK_I32
+        else:
+            mask_h, code = np.ascontiguousarray(mask, dtype=np.float32), nat.SC_MASK_F32
+        self._engine.process_view(intrinsics, rot, tvec, mask_h, code)
+        return
+
+    def flush(self):
+        """Launch every view enqueued so far (asynchronous)."""
+        self._engine.flush()
+
+    def synchronize(self):
+        """Flush and wait: the reference's ``queue.finish()`` (cl.py:226)."""
+        self._engine.synchronize()
+
+    def get_values(self):
+        """Gets computed values from the device (cl.py:229-232); the returned array
+        aliases ``values_h`` like the reference's."""
+        if self.values_h is None or self.values_h.dtype != self.dtype:
+            self.values_h = np.empty(self.shape, dtype=self.dtype)
+        flat = self.values_h.reshape(tuple(int(s) for s in self.shape))
+        self._engine.get_values(flat)
+        self.values_d = self._engine.values_device_ptr()
+        return self.values_h.reshape(self.shape)
+
+    def process_fileset(self, fs, camera_metadata, invert=False):
+        """Processes a whole fileset (cl.py:234-257): one volume, or with ``labels`` a
+        float64 array ``[len(labels), *shape]``; the first label is not cleared."""
+        if self.labels is not None:
+            result = np.zeros((len(self.labels), *self.shape))
+            for i, label in enumerate(self.labels):
+                logger.info(f"Processing label '{label}'...")
+                if i != 0:
+                    self.clear()
+                result[i, :] = self.process_label(fs, camera_metadata, label, invert)
+            return result
+        else:
+            return self.process_label(fs, camera_metadata, None, invert=invert)
+
+    def process_label(self, fs, camera_metadata, label=None, invert=False):
+        """Processes a whole fileset for a given label (cl.py:259-305)."""
+        if hasattr(fs, "get_files") and not isinstance(fs, (list, tuple)):
+            fs = fs.get_files()  # cl.py:279-280
+
+        for fi in fs:
+            if label is not None and fi.get_metadata("channel") != label:  # cl.py:284
+                continue
+            logger.debug("processing file %s" % fi.id)
+            cam = fi.get_metadata(camera_metadata, default=None)
+            if cam is None:
+                logger.warning(
+                    f"Could not get camera params from '{camera_metadata}' for {fi.id}, skipping...")
+                continue
+            intrinsics = np.array(cam["camera_model"]['params'][0:4], dtype=np.float32)  # :293
+            rot = np.array(sum(cam['rotmat'], []), dtype=np.float32)  # :295
+            tvec = np.array(cam['tvec'], dtype=np.float32)  # :296
+            mask = read_image(fi)  # :298
+            if invert:
+                mask = np.invert(mask)  # :300-301
+            self.process_view(intrinsics, rot, tvec, mask)
+
+        return self.get_values()
+
+    def clear(self):
+        """Clear computed values (cl.py:307-311)."""
+        self.values_h = np.ascontiguousarray(
+            self.default_value * np.ones(self.shape).astype(self.dtype), dtype=self.dtype)
+        self._engine.clear()
+        return
+
+    def close(self):
+        """Release device memory now (otherwise at garbage collection)."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None

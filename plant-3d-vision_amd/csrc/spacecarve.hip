@@ -1,0 +1,1025 @@
+// spacecarve.hip -- MI355X (gfx950 / CDNA4) voxel back-projection engine + its C ABI.
+//
+// Replaces, behind include/spacecarve.h, the device layer of the reference:
+//   plant3dvision/kernels/backprojection.c  carve :57-84, average :36-55,
+//                                           backproject_point :3-34
+//   plant3dvision/kernels/common.h          unravel_index :1-12
+//   plant3dvision/cl.py                     Backprojection buffer lifecycle :118-311
+//
+// Design:
+//   * State stays in the reference's layout: C-order [nx][ny][nz], int32 / float32.
+//   * One lane owns 4 consecutive z-voxels of one (i,j) column: one 16-byte load and one
+//     16-byte store per lane, 1 KiB per wavefront instruction; one owner per voxel, so
+//     there are no atomics and no races (as in the reference, one work-item per voxel).
+//   * A launch applies a CHUNK of views to the state it holds in registers (1 view per
+//     launch = the reference's schedule).  The carve update is order-independent, so
+//     dead lanes drop out and a wavefront leaves the view loop as soon as a ballot says
+//     every one of its voxels is carved.
+//   * Carve masks live in HBM as 1 bit per pixel in 32x32-pixel tiles (one 128-byte line
+//     per tile): the 64..256 z-neighbours a wavefront projects land on a short image
+//     segment of arbitrary orientation, i.e. on a handful of lines, whatever the camera roll.
+//   * The x/y partial sums of every dot product are hoisted per column WITHOUT changing
+//     the reference's left-to-right rounding: ((R0*x + R1*y) + R2*z) + t0.
+//   * Arithmetic contract: IEEE binary32, no FMA contraction (built with
+//     -ffp-contract=off), correctly rounded division, and the (int) cast guarded so
+//     that NaN / inf / out-of-range are rejected exactly like x86 cvttss2si -> INT_MIN.
+//
+// gfx950 only.  No fallback path: every entry point fails with SC_ERR_DEVICE when HIP
+// cannot run the kernels.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "spacecarve.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------
+
+struct ViewDesc {   // 96 bytes, read with scalar loads (the view index is wave-uniform)
+    float K[4];     // fx fy cx cy
+    float R[9];     // row-major
+    float t[3];
+    const void *mask;  // carve: tiled bit words; average: float32 [H][W]
+    int32_t W, H;
+    int32_t tiles_x;
+    int32_t pad;
+    float Wf, Hf;
+};
+static_assert(sizeof(ViewDesc) == 96, "ViewDesc layout");
+
+struct GridDesc {
+    float ox, oy, oz, vs;
+    uint32_t ny, nz;
+    uint32_t i0;        // first global x index of the slab
+    uint32_t gpc;       // 4-voxel groups per column = ceil(nz / 4)
+    uint64_t ngroups;   // columns in slab * gpc
+};
+
+constexpr int kBlock = 256;
+constexpr int kTile = 32;  // mask tile edge in pixels (32 rows x 32 bits = 128 B)
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD one contiguous eighth of the grid: neighbouring bricks then share mask lines
+// in the same L2.  Speed only; any placement gives the same result.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblocks) {
+    uint32_t full = nblocks & ~7u;
+    if (bid >= full) return bid;
+    uint32_t cpx = full >> 3;
+    return (bid & 7u) * cpx + (bid >> 3);
+}
+
+// backproject_point (backprojection.c:3-34) with the x/y partial sums hoisted.
+// a{x,y,z} = R[0]*x + R[1]*y etc. (rounded as the reference rounds them).
+__device__ __forceinline__ bool project(float ax, float ay, float az, float z,
+                                        const ViewDesc &d, int &u, int &v) {
+    float pz = (az + d.R[8] * z) + d.t[2];  // :11
+    float px = (ax + d.R[2] * z) + d.t[0];  // :17
+    float py = (ay + d.R[5] * z) + d.t[1];  // :18
+    float uf = (px / pz) * d.K[0] + d.K[2];  // :20
+    float vf = (py / pz) * d.K[1] + d.K[3];  // :21
+    // :13 rejects pz < 0 (not NaN, not -0); :23-31 reject (int)uf outside [0, W-1].
+    // Truncation toward zero accepts uf in (-1, 0); NaN/inf/huge fail the comparisons,
+    // which is what the cvttss2si INT_MIN result does in the canonical restatement.
+    // (bitwise &: one straight-line predicate, no short-circuit branches)
+    bool ok = !(pz < 0.0f) & (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);
+    u = (int)uf;
+    v = (int)vf;
+    return ok;
+}
+
+struct Lane {
+    uint64_t elem;   // offset of the lane's first voxel in the slab state
+    uint32_t k0;     // z index of that voxel
+    uint32_t nvalid; // 1..4 voxels of this group that exist (nz tail)
+    float x, y;
+};
+
+__device__ __forceinline__ bool lane_setup(const GridDesc &g, Lane &ln) {
+    uint32_t nblocks = gridDim.x;
+    uint64_t grp = (uint64_t)xcd_swizzle(blockIdx.x, nblocks) * kBlock + threadIdx.x;
+    if (grp >= g.ngroups) return false;
+    uint32_t col, kq;
+    if (g.ngroups <= 0xffffffffull) {
+        uint32_t g32 = (uint32_t)grp;
+        col = g32 / g.gpc;
+        kq = g32 - col * g.gpc;
+    } else {
+        col = (uint32_t)(grp / g.gpc);
+        kq = (uint32_t)(grp - (uint64_t)col * g.gpc);
+    }
+    uint32_t il = col / g.ny;  // common.h:6-8, z fastest
+    uint32_t j = col - il * g.ny;
+    ln.k0 = kq * 4u;
+    ln.nvalid = min(4u, g.nz - ln.k0);
+    ln.elem = (uint64_t)col * g.nz + ln.k0;
+    // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index
+    ln.x = g.ox + (float)(int)(il + g.i0) * g.vs;
+    ln.y = g.oy + (float)(int)j * g.vs;
+    return true;
+}
+
+// carve (backprojection.c:57-84) over views[0..nviews) with the state in registers.
+// FRESH: the state is known to be `init` everywhere (nothing has been applied since
+// create/clear), so it is not read.  VEC: nz % 4 == 0, state accessed as int4.
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                       const ViewDesc *__restrict__ views,
+                                                       int nviews, int32_t init) {
+    Lane ln;
+    if (!lane_setup(g, ln)) return;
+    int32_t lab[4], was[4];
+    int32_t *p = labels + ln.elem;
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lab[e] = init;
+    } else if (VEC) {
+        int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lab[e] = (e < (int)ln.nvalid) ? p[e] : -1;
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        was[e] = lab[e];
+        if (e < (int)ln.nvalid && lab[e] != -1) alive |= 1u << e;  // :67
+    }
+    if (!FRESH && alive == 0) return;  // nothing to do and nothing to write
+
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(ln.k0 + e) * g.vs;  // :73
+
+    for (int vi = 0; vi < nviews; ++vi) {
+        if (__ballot(alive != 0) == 0) break;  // whole wavefront carved
+        const ViewDesc d = views[vi];  // wave-uniform: scalar loads, once per view
+        float ax = d.R[0] * ln.x + d.R[1] * ln.y;
+        float ay = d.R[3] * ln.x + d.R[4] * ln.y;
+        float az = d.R[6] * ln.x + d.R[7] * ln.y;
+        const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (alive & (1u << e)) {
+                int u, v;
+                if (project(ax, ay, az, z[e], d, u, v)) {
+                    uint32_t word = ((uint32_t)(v >> 5) * (uint32_t)d.tiles_x + (uint32_t)(u >> 5)) * 32u +
+                                    (uint32_t)(v & 31);
+                    uint32_t w = bits[word];
+                    if (((w >> (u & 31)) & 1u) == 0) {  // :79
+                        lab[e] = -1;
+                        alive &= ~(1u << e);
+                    } else if (lab[e] == 0) {  // :81
+                        lab[e] = 1;
+                    }
+                }
+            }
+        }
+    }
+
+    if (VEC) {
+        bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] ||
+                       lab[3] != was[3];
+        if (changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < (int)ln.nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
+    }
+}
+
+// average (backprojection.c:36-55): value += mask[v][u] for every in-image view, in the
+// order given (float32 sum, order matters).
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void average_kernel(float *__restrict__ values, GridDesc g,
+                                                         const ViewDesc *__restrict__ views,
+                                                         int nviews, float init) {
+    Lane ln;
+    if (!lane_setup(g, ln)) return;
+    float val[4];
+    float *p = values + ln.elem;
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = init;
+    } else if (VEC) {
+        float4 q = *reinterpret_cast<const float4 *>(p);
+        val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = (e < (int)ln.nvalid) ? p[e] : 0.0f;
+    }
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(ln.k0 + e) * g.vs;
+
+    for (int vi = 0; vi < nviews; ++vi) {
+        const ViewDesc d = views[vi];  // wave-uniform: scalar loads, once per view
+        float ax = d.R[0] * ln.x + d.R[1] * ln.y;
+        float ay = d.R[3] * ln.x + d.R[4] * ln.y;
+        float az = d.R[6] * ln.x + d.R[7] * ln.y;
+        const float *m = static_cast<const float *>(d.mask);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int u, v;
+            if (e < (int)ln.nvalid && project(ax, ay, az, z[e], d, u, v)) {
+                val[e] = val[e] + m[(int64_t)v * d.W + u];  // :54, nearest texel
+            }
+        }
+    }
+    if (VEC) {
+        *reinterpret_cast<float4 *>(p) = make_float4(val[0], val[1], val[2], val[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < (int)ln.nvalid) p[e] = val[e];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
+                                                      uint32_t bits) {
+    uint64_t idx = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (idx + 4 <= n) {
+        *reinterpret_cast<uint4 *>(dst + idx) = make_uint4(bits, bits, bits, bits);
+    } else {
+        for (; idx < n; ++idx) dst[idx] = bits;
+    }
+}
+
+// Mask ingest: raw [V][H][W] pixels (u8 or i32) -> 1 bit/pixel (pixel != 0, the test at
+// backprojection.c:79 on the cast of cl.py:215), in 32x32 tiles.  One wavefront votes 64
+// consecutive pixels of a row with a ballot and writes the two 32-bit tile words.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
+                                                      int64_t row_stride, int64_t view_stride,
+                                                      int W, int H, int nviews, int tiles_x,
+                                                      uint32_t *__restrict__ out,
+                                                      int64_t out_view_words) {
+    const int lane = threadIdx.x & 63;
+    const int segs = (W + 63) >> 6;
+    int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int64_t total = (int64_t)nviews * H * segs;
+    if (wave >= total) return;
+    int seg = (int)(wave % segs);
+    int64_t r = wave / segs;
+    int v = (int)(r % H);
+    int view = (int)(r / H);
+    int u = seg * 64 + lane;
+    bool fg = false;
+    if (u < W) {
+        const char *row = reinterpret_cast<const char *>(raw) + view * view_stride + v * row_stride;
+        fg = reinterpret_cast<const T *>(row)[u] != 0;
+    }
+    unsigned long long vote = __ballot(fg);
+    uint32_t *o = out + view * out_view_words;
+    uint32_t base = (uint32_t)(v >> 5) * (uint32_t)tiles_x;
+    uint32_t rowin = (uint32_t)(v & 31);
+    if (lane == 0) {
+        o[(base + seg * 2) * 32u + rowin] = (uint32_t)vote;
+    } else if (lane == 32 && seg * 2 + 1 < tiles_x) {
+        o[(base + seg * 2 + 1) * 32u + rowin] = (uint32_t)(vote >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(_e == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE,            \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                        __LINE__);                                                           \
+    } while (0)
+
+struct Chunk {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+constexpr int kSlots = 4;
+constexpr int kNumKernels = 4;
+
+}  // namespace
+
+struct sc_engine {
+    int device = 0;
+    int mode = SC_MODE_CARVE;
+    int64_t nx = 0, ny = 0, nz = 0, i0 = 0, i1 = 0, n = 0;
+    float origin[3] = {0, 0, 0};
+    float vs = 1.0f;
+    float default_value = 0.0f;
+    void *state = nullptr;
+    bool fresh = true;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // deferred views
+    std::vector<ViewDesc> pending;
+    ViewDesc *views_dev = nullptr;
+    ViewDesc *views_pin = nullptr;
+    size_t views_cap = 0;
+    hipEvent_t views_ev = nullptr;
+    bool views_ev_armed = false;
+
+    // mask storage for pending views
+    std::vector<Chunk> chunks;
+
+    // host-mask staging ring
+    void *pin[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    void *raw[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t slot_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool slot_armed[kSlots] = {false, false, false, false};
+    size_t slot_bytes = 0;
+    int next_slot = 0;
+
+    // options
+    int64_t views_per_launch = 0;
+    int64_t view_order = 1;
+    int64_t time_kernels = 0;
+    int64_t max_pending = 256;
+
+    std::vector<TimedLaunch> timed[kNumKernels];
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int use_device(sc_engine *e) {
+    HIP_TRY(hipSetDevice(e->device));
+    return SC_OK;
+}
+
+int get_event(sc_engine *e, hipEvent_t *ev) {
+    if (!e->event_pool.empty()) {
+        *ev = e->event_pool.back();
+        e->event_pool.pop_back();
+        return SC_OK;
+    }
+    HIP_TRY(hipEventCreate(ev));
+    return SC_OK;
+}
+
+struct LaunchTimer {
+    sc_engine *e;
+    int kid;
+    TimedLaunch tl{};
+    bool on = false;
+    int begin() {
+        if (!e->time_kernels) return SC_OK;
+        int rc = get_event(e, &tl.start);
+        if (rc) return rc;
+        rc = get_event(e, &tl.stop);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(tl.start, e->stream));
+        on = true;
+        return SC_OK;
+    }
+    int end() {
+        if (!on) return SC_OK;
+        HIP_TRY(hipEventRecord(tl.stop, e->stream));
+        e->timed[kid].push_back(tl);
+        return SC_OK;
+    }
+};
+
+GridDesc grid_desc(const sc_engine *e) {
+    GridDesc g;
+    g.ox = e->origin[0];
+    g.oy = e->origin[1];
+    g.oz = e->origin[2];
+    g.vs = e->vs;
+    g.ny = (uint32_t)e->ny;
+    g.nz = (uint32_t)e->nz;
+    g.i0 = (uint32_t)e->i0;
+    g.gpc = (uint32_t)((e->nz + 3) / 4);
+    g.ngroups = (uint64_t)(e->i1 - e->i0) * (uint64_t)e->ny * g.gpc;
+    return g;
+}
+
+int32_t init_bits_i32(const sc_engine *e) { return (int32_t)e->default_value; }
+
+int materialize(sc_engine *e) {
+    if (!e->fresh) return SC_OK;
+    uint32_t bits;
+    if (e->mode == SC_MODE_CARVE) {
+        int32_t v = init_bits_i32(e);
+        memcpy(&bits, &v, 4);
+    } else {
+        memcpy(&bits, &e->default_value, 4);
+    }
+    uint64_t n = (uint64_t)e->n;
+    uint64_t blocks = (n + (uint64_t)kBlock * 4 - 1) / ((uint64_t)kBlock * 4);
+    LaunchTimer lt{e, SC_KERNEL_FILL};
+    int rc = lt.begin();
+    if (rc) return rc;
+    hipLaunchKernelGGL(fill_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                       static_cast<uint32_t *>(e->state), n, bits);
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    e->fresh = false;
+    return SC_OK;
+}
+
+// device storage for one pending view's mask, alive until the flush that consumes it
+int arena_alloc(sc_engine *e, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto &c : e->chunks) {
+        if (c.cap - c.used >= bytes) {
+            *out = c.base + c.used;
+            c.used += bytes;
+            return SC_OK;
+        }
+    }
+    Chunk c;
+    size_t last = e->chunks.empty() ? 0 : e->chunks.back().cap;
+    c.cap = std::max(bytes, std::max<size_t>(last * 2, (size_t)16 << 20));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.base), c.cap));
+    c.used = bytes;
+    e->chunks.push_back(c);
+    *out = c.base;
+    return SC_OK;
+}
+
+void arena_reset(sc_engine *e) {
+    // stream order protects reuse: later pack kernels / copies run after the launch that
+    // read the old contents
+    for (auto &c : e->chunks) c.used = 0;
+}
+
+int ensure_slots(sc_engine *e, size_t bytes) {
+    if (bytes <= e->slot_bytes) return SC_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int s = 0; s < kSlots; ++s) {
+        if (e->pin[s]) (void)hipHostFree(e->pin[s]);
+        if (e->raw[s]) (void)hipFree(e->raw[s]);
+        e->pin[s] = e->raw[s] = nullptr;
+        e->slot_armed[s] = false;
+    }
+    e->slot_bytes = 0;
+    for (int s = 0; s < kSlots; ++s) {
+        HIP_TRY(hipHostMalloc(&e->pin[s], bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&e->raw[s], bytes));
+        if (!e->slot_ev[s]) HIP_TRY(hipEventCreateWithFlags(&e->slot_ev[s], hipEventDisableTiming));
+    }
+    e->slot_bytes = bytes;
+    return SC_OK;
+}
+
+size_t elem_size(int dtype) { return dtype == SC_MASK_U8 ? 1 : 4; }
+
+int check_dtype(const sc_engine *e, int dtype) {
+    if (e->mode == SC_MODE_CARVE && (dtype == SC_MASK_U8 || dtype == SC_MASK_I32)) return SC_OK;
+    if (e->mode == SC_MODE_AVERAGE && dtype == SC_MASK_F32) return SC_OK;
+    return fail(SC_ERR_INVALID, "mask dtype %d does not fit engine mode %d", dtype, e->mode);
+}
+
+void fill_desc(ViewDesc &d, const float *K, const float *R, const float *t, const void *mask,
+               int H, int W) {
+    memcpy(d.K, K, sizeof d.K);
+    memcpy(d.R, R, sizeof d.R);
+    memcpy(d.t, t, sizeof d.t);
+    d.mask = mask;
+    d.W = W;
+    d.H = H;
+    d.tiles_x = (W + kTile - 1) / kTile;
+    d.pad = 0;
+    d.Wf = (float)W;
+    d.Hf = (float)H;
+}
+
+size_t packed_words(int H, int W) {
+    size_t tx = (size_t)(W + kTile - 1) / kTile, ty = (size_t)(H + kTile - 1) / kTile;
+    return tx * ty * 32;
+}
+
+// raw device pixels [V][H][W] -> packed tiles in the arena; appends V pending views
+int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                 const void *raw_dev, int H, int W, int dtype, int64_t row_stride,
+                 int64_t view_stride) {
+    size_t words = packed_words(H, W);
+    void *packed = nullptr;
+    int rc = arena_alloc(e, words * 4 * (size_t)V, &packed);
+    if (rc) return rc;
+    int tiles_x = (W + kTile - 1) / kTile;
+    int segs = (W + 63) / 64;
+    int64_t waves = (int64_t)V * H * segs;
+    int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+    LaunchTimer lt{e, SC_KERNEL_PACK};
+    rc = lt.begin();
+    if (rc) return rc;
+    if (dtype == SC_MASK_U8) {
+        hipLaunchKernelGGL(pack_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                           static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,
+                           tiles_x, static_cast<uint32_t *>(packed), (int64_t)words);
+    } else {
+        hipLaunchKernelGGL(pack_kernel<int32_t>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                           static_cast<const int32_t *>(raw_dev), row_stride, view_stride, W, H, V,
+                           tiles_x, static_cast<uint32_t *>(packed), (int64_t)words);
+    }
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    for (int q = 0; q < V; ++q) {
+        ViewDesc d;
+        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
+                  static_cast<uint32_t *>(packed) + (size_t)q * words, H, W);
+        e->pending.push_back(d);
+    }
+    return SC_OK;
+}
+
+// stride-interleaved order: widely separated views first, so most voxels are carved
+// within the first few views of a fused launch
+void interleave(std::vector<ViewDesc> &v) {
+    size_t n = v.size();
+    if (n < 3) return;
+    int bits = 0;
+    while (((size_t)1 << bits) < n) ++bits;
+    std::vector<std::pair<uint32_t, uint32_t>> key(n);
+    for (size_t q = 0; q < n; ++q) {
+        uint32_t r = 0;
+        for (int b = 0; b < bits; ++b)
+            if (q & ((size_t)1 << b)) r |= 1u << (bits - 1 - b);
+        key[q] = {r, (uint32_t)q};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<ViewDesc> out(n);
+    for (size_t q = 0; q < n; ++q) out[q] = v[key[q].second];
+    v.swap(out);
+}
+
+int flush(sc_engine *e) {
+    if (e->pending.empty()) return SC_OK;
+    size_t nv = e->pending.size();
+    if (nv > e->views_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->views_dev) (void)hipFree(e->views_dev);
+        if (e->views_pin) (void)hipHostFree(e->views_pin);
+        e->views_dev = e->views_pin = nullptr;
+        e->views_cap = 0;
+        e->views_ev_armed = false;
+        size_t cap = std::max<size_t>(nv, 128);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->views_dev), cap * sizeof(ViewDesc)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->views_pin), cap * sizeof(ViewDesc),
+                              hipHostMallocDefault));
+        e->views_cap = cap;
+    }
+    if (!e->views_ev) HIP_TRY(hipEventCreateWithFlags(&e->views_ev, hipEventDisableTiming));
+    if (e->views_ev_armed) {
+        // the previous flush's kernel must be done with views_dev, its copy with views_pin
+        HIP_TRY(hipEventSynchronize(e->views_ev));
+        e->views_ev_armed = false;
+    }
+    if (e->mode == SC_MODE_CARVE && e->view_order == 1) interleave(e->pending);
+    memcpy(e->views_pin, e->pending.data(), nv * sizeof(ViewDesc));
+    HIP_TRY(hipMemcpyAsync(e->views_dev, e->views_pin, nv * sizeof(ViewDesc),
+                           hipMemcpyHostToDevice, e->stream));
+
+    GridDesc g = grid_desc(e);
+    uint64_t blocks = (g.ngroups + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
+    bool vec = (e->nz % 4) == 0;
+    dim3 grid((uint32_t)blocks), block(kBlock);
+    LaunchTimer lt{e, e->mode == SC_MODE_CARVE ? SC_KERNEL_CARVE : SC_KERNEL_AVERAGE};
+    int rc = lt.begin();
+    if (rc) return rc;
+    if (e->mode == SC_MODE_CARVE) {
+        int32_t *st = static_cast<int32_t *>(e->state);
+        int32_t init = init_bits_i32(e);
+#define LAUNCH_CARVE(F, V)                                                                  \
+    hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, e->views_dev, \
+                       (int)nv, init)
+        if (e->fresh) {
+            if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
+        } else {
+            if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
+        }
+#undef LAUNCH_CARVE
+    } else {
+        float *st = static_cast<float *>(e->state);
+#define LAUNCH_AVG(F, V)                                                                      \
+    hipLaunchKernelGGL((average_kernel<F, V>), grid, block, 0, e->stream, st, g, e->views_dev, \
+                       (int)nv, e->default_value)
+        if (e->fresh) {
+            if (vec) LAUNCH_AVG(true, true); else LAUNCH_AVG(true, false);
+        } else {
+            if (vec) LAUNCH_AVG(false, true); else LAUNCH_AVG(false, false);
+        }
+#undef LAUNCH_AVG
+    }
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->views_ev, e->stream));
+    e->views_ev_armed = true;
+    e->fresh = false;
+    e->pending.clear();
+    arena_reset(e);
+    return SC_OK;
+}
+
+int after_enqueue(sc_engine *e) {
+    size_t np = e->pending.size();
+    if ((e->views_per_launch > 0 && (int64_t)np >= e->views_per_launch) ||
+        (int64_t)np >= e->max_pending)
+        return flush(e);
+    return SC_OK;
+}
+
+int check_view_args(const sc_engine *e, const float *K, const float *R, const float *t,
+                    const void *mask, int H, int W) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    if (!K || !R || !t || !mask) return fail(SC_ERR_INVALID, "null view argument");
+    if (H <= 0 || W <= 0 || H > (1 << 24) || W > (1 << 24))
+        return fail(SC_ERR_INVALID, "bad mask shape %d x %d", H, W);
+    return SC_OK;
+}
+
+int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t i1,
+           const float *origin, float vs, int mode, float default_value, int device) {
+    if (!out) return fail(SC_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!origin) return fail(SC_ERR_INVALID, "null origin");
+    if (nx <= 0 || ny <= 0 || nz <= 0) return fail(SC_ERR_INVALID, "shape must be positive");
+    // int -> float of an index must be exact
+    if (nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24))
+        return fail(SC_ERR_INVALID, "axis longer than 2^24 voxels");
+    if (i0 < 0 || i1 > nx || i0 >= i1) return fail(SC_ERR_INVALID, "bad slab [%lld, %lld)", (long long)i0, (long long)i1);
+    if (mode != SC_MODE_CARVE && mode != SC_MODE_AVERAGE)
+        return fail(SC_ERR_INVALID, "unknown mode %d", mode);
+    int ndev = 0;
+    int rc = sc_device_count(&ndev);
+    if (rc) return rc;
+    if (device < 0 || device >= ndev)
+        return fail(SC_ERR_DEVICE, "device %d not available (%d gfx950 device(s) visible)", device, ndev);
+    sc_engine *e = new (std::nothrow) sc_engine();
+    if (!e) return fail(SC_ERR_NOMEM, "host allocation failed");
+    e->device = device;
+    e->mode = mode;
+    e->nx = nx; e->ny = ny; e->nz = nz; e->i0 = i0; e->i1 = i1;
+    e->n = (i1 - i0) * ny * nz;
+    memcpy(e->origin, origin, sizeof e->origin);
+    e->vs = vs;
+    e->default_value = default_value;
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->n * 4);
+    if (he != hipSuccess) {
+        int code = he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE;
+        fail(code, "engine setup failed: %s", hipGetErrorString(he));
+        sc_destroy(e);
+        return code;
+    }
+    e->stream = e->own_stream;
+    e->fresh = true;
+    *out = e;
+    return SC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int sc_abi_version(void) { return SC_ABI_VERSION; }
+
+const char *sc_last_error(void) { return g_err.c_str(); }
+
+int sc_device_count(int *count) {
+    if (!count) return fail(SC_ERR_INVALID, "null count");
+    *count = 0;
+    int n = 0;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess) return fail(SC_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(he));
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SC_ERR_DEVICE, "device %d is %s; this engine is built for gfx950 only", d,
+                        prop.gcnArchName);
+        ++ok;
+    }
+    *count = ok;
+    return SC_OK;
+}
+
+int sc_create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],
+              float voxel_size, int mode, float default_value, int device) {
+    return create(out, nx, ny, nz, 0, nx, origin, voxel_size, mode, default_value, device);
+}
+
+int sc_create_slab(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t i1,
+                   const float origin[3], float voxel_size, int mode, float default_value,
+                   int device) {
+    return create(out, nx, ny, nz, i0, i1, origin, voxel_size, mode, default_value, device);
+}
+
+void sc_destroy(sc_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (int k = 0; k < kNumKernels; ++k)
+        for (auto &tl : e->timed[k]) {
+            (void)hipEventDestroy(tl.start);
+            (void)hipEventDestroy(tl.stop);
+        }
+    for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+    for (auto &c : e->chunks) (void)hipFree(c.base);
+    for (int s = 0; s < kSlots; ++s) {
+        if (e->pin[s]) (void)hipHostFree(e->pin[s]);
+        if (e->raw[s]) (void)hipFree(e->raw[s]);
+        if (e->slot_ev[s]) (void)hipEventDestroy(e->slot_ev[s]);
+    }
+    if (e->views_dev) (void)hipFree(e->views_dev);
+    if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->views_ev) (void)hipEventDestroy(e->views_ev);
+    if (e->state) (void)hipFree(e->state);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int sc_clear(sc_engine *e) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    e->pending.clear();
+    arena_reset(e);
+    e->fresh = true;  // materialised lazily: a fused launch never needs to read it
+    return SC_OK;
+}
+
+int sc_set_option(sc_engine *e, int key, int64_t value) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    switch (key) {
+        case SC_OPT_VIEWS_PER_LAUNCH:
+            if (value < 0) return fail(SC_ERR_INVALID, "views_per_launch must be >= 0");
+            e->views_per_launch = value;
+            return SC_OK;
+        case SC_OPT_VIEW_ORDER:
+            if (value != 0 && value != 1) return fail(SC_ERR_INVALID, "view_order must be 0 or 1");
+            e->view_order = value;
+            return SC_OK;
+        case SC_OPT_TIME_KERNELS:
+            e->time_kernels = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_MAX_PENDING:
+            if (value < 1) return fail(SC_ERR_INVALID, "max_pending must be >= 1");
+            e->max_pending = value;
+            return SC_OK;
+        default:
+            return fail(SC_ERR_INVALID, "unknown option %d", key);
+    }
+}
+
+int sc_set_stream(sc_engine *e, void *hip_stream) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    rc = flush(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return SC_OK;
+}
+
+int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
+                    const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes) {
+    int rc = check_view_args(e, K, R, t, mask, H, W);
+    if (rc) return rc;
+    rc = check_dtype(e, mask_dtype);
+    if (rc) return rc;
+    rc = use_device(e);
+    if (rc) return rc;
+    size_t es = elem_size(mask_dtype);
+    size_t row = (size_t)W * es;
+    if (row_stride_bytes == 0) row_stride_bytes = (int64_t)row;
+    if (row_stride_bytes < (int64_t)row) return fail(SC_ERR_INVALID, "row stride smaller than a row");
+    size_t bytes = row * (size_t)H;
+    rc = ensure_slots(e, bytes);
+    if (rc) return rc;
+    int s = e->next_slot;
+    e->next_slot = (s + 1) % kSlots;
+    if (e->slot_armed[s]) {
+        HIP_TRY(hipEventSynchronize(e->slot_ev[s]));
+        e->slot_armed[s] = false;
+    }
+    // consume the caller's buffer now (tight rows in the pinned slot)
+    if (row_stride_bytes == (int64_t)row) {
+        memcpy(e->pin[s], mask, bytes);
+    } else {
+        for (int r = 0; r < H; ++r)
+            memcpy(static_cast<char *>(e->pin[s]) + (size_t)r * row,
+                   static_cast<const char *>(mask) + (size_t)r * row_stride_bytes, row);
+    }
+    if (e->mode == SC_MODE_CARVE) {
+        HIP_TRY(hipMemcpyAsync(e->raw[s], e->pin[s], bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->slot_ev[s], e->stream));
+        e->slot_armed[s] = true;
+        rc = enqueue_pack(e, 1, K, R, t, e->raw[s], H, W, mask_dtype, (int64_t)row, (int64_t)bytes);
+        if (rc) return rc;
+    } else {
+        void *dst = nullptr;
+        rc = arena_alloc(e, bytes, &dst);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(dst, e->pin[s], bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->slot_ev[s], e->stream));
+        e->slot_armed[s] = true;
+        ViewDesc d;
+        fill_desc(d, K, R, t, dst, H, W);
+        e->pending.push_back(d);
+    }
+    return after_enqueue(e);
+}
+
+int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                     const void *const *masks, int H, int W, int mask_dtype,
+                     int64_t row_stride_bytes) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    if (V < 0 || (V > 0 && (!K || !R || !t || !masks))) return fail(SC_ERR_INVALID, "bad view batch");
+    for (int q = 0; q < V; ++q) {
+        int rc = sc_process_view(e, K + 4 * q, R + 9 * q, t + 3 * q, masks[q], H, W, mask_dtype,
+                                 row_stride_bytes);
+        if (rc) return rc;
+    }
+    return SC_OK;
+}
+
+int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                            const void *masks_dev, int H, int W, int mask_dtype) {
+    if (V == 0) return e ? SC_OK : fail(SC_ERR_INVALID, "null engine");
+    int rc = check_view_args(e, K, R, t, masks_dev, H, W);
+    if (rc) return rc;
+    if (V < 0) return fail(SC_ERR_INVALID, "negative view count");
+    rc = check_dtype(e, mask_dtype);
+    if (rc) return rc;
+    rc = use_device(e);
+    if (rc) return rc;
+    size_t es = elem_size(mask_dtype);
+    int64_t row = (int64_t)W * (int64_t)es, view = row * H;
+    if (e->mode == SC_MODE_CARVE) {
+        // honour views_per_launch by feeding the packer in launch-sized batches
+        int done = 0;
+        while (done < V) {
+            int64_t room = e->views_per_launch > 0
+                               ? e->views_per_launch - (int64_t)e->pending.size()
+                               : e->max_pending - (int64_t)e->pending.size();
+            int take = (int)std::min<int64_t>(V - done, std::max<int64_t>(room, 1));
+            rc = enqueue_pack(e, take, K + 4 * done, R + 9 * done, t + 3 * done,
+                              static_cast<const char *>(masks_dev) + (int64_t)done * view, H, W,
+                              mask_dtype, row, view);
+            if (rc) return rc;
+            rc = after_enqueue(e);
+            if (rc) return rc;
+            done += take;
+        }
+        return SC_OK;
+    }
+    for (int q = 0; q < V; ++q) {
+        ViewDesc d;
+        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
+                  static_cast<const char *>(masks_dev) + (int64_t)q * view, H, W);
+        e->pending.push_back(d);
+        rc = after_enqueue(e);
+        if (rc) return rc;
+    }
+    return SC_OK;
+}
+
+int sc_flush(sc_engine *e) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    return flush(e);
+}
+
+int sc_synchronize(sc_engine *e) {
+    int rc = sc_flush(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SC_OK;
+}
+
+int sc_get_values(sc_engine *e, void *out) {
+    if (!e || !out) return fail(SC_ERR_INVALID, "null argument");
+    int rc = sc_flush(e);
+    if (rc) return rc;
+    rc = materialize(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->state, (size_t)e->n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SC_OK;
+}
+
+int sc_values_device_ptr(sc_engine *e, void **ptr) {
+    if (!e || !ptr) return fail(SC_ERR_INVALID, "null argument");
+    int rc = sc_flush(e);
+    if (rc) return rc;
+    rc = materialize(e);
+    if (rc) return rc;
+    *ptr = e->state;
+    return SC_OK;
+}
+
+int64_t sc_num_voxels(const sc_engine *e) { return e ? e->n : 0; }
+
+int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *total_ms) {
+    if (!e || !launches || !total_ms) return fail(SC_ERR_INVALID, "null argument");
+    if (kernel_id < 0 || kernel_id >= kNumKernels) return fail(SC_ERR_INVALID, "bad kernel id");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double sum = 0.0;
+    for (auto &tl : e->timed[kernel_id]) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, tl.start, tl.stop));
+        sum += ms;
+    }
+    *launches = (int64_t)e->timed[kernel_id].size();
+    *total_ms = sum;
+    return SC_OK;
+}
+
+int sc_reset_kernel_stats(sc_engine *e) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < kNumKernels; ++k) {
+        for (auto &tl : e->timed[k]) {
+            e->event_pool.push_back(tl.start);
+            e->event_pool.push_back(tl.stop);
+        }
+        e->timed[k].clear();
+    }
+    return SC_OK;
+}
+
+int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr) {
+    if (!e || !ptr || bytes <= 0) return fail(SC_ERR_INVALID, "bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(ptr, (size_t)bytes));
+    return SC_OK;
+}
+
+int sc_dev_free(sc_engine *e, void *ptr) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(ptr));
+    return SC_OK;
+}
+
+int sc_dev_upload(sc_engine *e, void *dst_dev, const void *src_host, int64_t bytes) {
+    if (!e || !dst_dev || !src_host || bytes < 0) return fail(SC_ERR_INVALID, "bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return SC_OK;
+}
+
+int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t bytes) {
+    if (!e || !dst_host || !src_dev || bytes < 0) return fail(SC_ERR_INVALID, "bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return SC_OK;
+}
+
+}  // extern "C"

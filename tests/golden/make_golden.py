@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Regenerates the fixtures under tests/golden/ (run from the repo root, in the build
+container where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+Inputs  : the reference's own test data ``tests/testdata/virtual_plant`` (18 views x
+          channels, exact ``camera`` metadata per file) -- copied here as DATA (decoded
+          pixels + pose numbers), never as source text.
+Outputs : expected volumes computed by the CPU oracle (oracle/spacecarve_oracle.c), each
+          asserted equal to the independent NumPy restatement (oracle/oracle_np.py) before
+          it is written.  They are ORACLE outputs, not outputs of the reference's OpenCL
+          run (see DESIGN.md "Oracle" for the pin status); fixtures named ``ref_opencl_*``
+          come from oracle/ref_opencl/ instead.
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle_c, oracle_np  # noqa: E402
+from plant3dvision_amd import scenes  # noqa: E402
+from plant3dvision_amd.cl import img_as_float32  # noqa: E402
+from plant3dvision_amd.tasks.cl import grid_from_bounding_box  # noqa: E402
+from tests.helpers import histogram3, sha256  # noqa: E402
+
+REF = "/root/reference/tests/testdata/virtual_plant"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_virtual_plant():
+    from PIL import Image
+    bbox = json.load(open(os.path.join(REF, "metadata", "images.json")))["bounding_box"]
+    data = {"bbox": np.array([bbox["x"], bbox["y"], bbox["z"]], dtype=np.float64)}
+    for channel in ("stem", "background"):
+        masks, K, R, t = [], [], [], []
+        for f in sorted(glob.glob(os.path.join(REF, "images", f"*_{channel}.png"))):
+            stem = os.path.splitext(os.path.basename(f))[0]
+            md = json.load(open(os.path.join(REF, "metadata", "images", stem + ".json")))
+            assert md["channel"] == channel
+            cam = md["camera"]
+            masks.append(np.array(Image.open(f)))
+            K.append(cam["camera_model"]["params"][0:4])
+            R.append(cam["rotmat"])
+            t.append(cam["tvec"])
+        data[f"masks_{channel}"] = np.stack(masks).astype(np.uint8)
+        data[f"K_{channel}"] = np.array(K, dtype=np.float64)
+        data[f"R_{channel}"] = np.array(R, dtype=np.float64)
+        data[f"t_{channel}"] = np.array(t, dtype=np.float64)
+    return data
+
+
+def vp_views(data, channel, invert=False):
+    views = []
+    for q in range(data[f"masks_{channel}"].shape[0]):
+        m = data[f"masks_{channel}"][q]
+        if invert:
+            m = np.invert(m)  # cl.py:300-301
+        views.append((data[f"K_{channel}"][q].astype(np.float32),
+                      data[f"R_{channel}"][q].reshape(9).astype(np.float32),
+                      data[f"t_{channel}"][q].astype(np.float32), m))
+    return views
+
+
+def both_carve(shape, origin, vs, views, default_value=0):
+    a = oracle_c.carve(shape, origin, vs, views, default_value)
+    if np.prod(shape) <= 160 ** 3:
+        b = oracle_np.carve(shape, origin, vs, views, default_value)
+        assert np.array_equal(a, b), "C and NumPy oracles disagree"
+    return a
+
+
+def main():
+    data = load_virtual_plant()
+    np.savez_compressed(os.path.join(OUT, "virtual_plant_inputs.npz"), **data)
+    bbox = {"x": list(data["bbox"][0]), "y": list(data["bbox"][1]), "z": list(data["bbox"][2])}
+    exp = {}
+    for vs in (1.0, 0.5):
+        shape, origin = grid_from_bounding_box(bbox, vs)
+        tag = f"vs{str(vs).replace('.', '')}"
+        exp[f"shape_{tag}"] = np.array(shape)
+        exp[f"origin_{tag}"] = np.array(origin)
+        lab = both_carve(shape, origin, vs, vp_views(data, "stem"))
+        exp[f"carve_stem_{tag}"] = lab.astype(np.int8)
+        print("stem", tag, shape, histogram3(lab))
+        lab = both_carve(shape, origin, vs, vp_views(data, "background", invert=True))
+        exp[f"carve_background_invert_{tag}"] = lab.astype(np.int8)
+        print("background/invert", tag, shape, histogram3(lab))
+    shape, origin = grid_from_bounding_box(bbox, 1.0)
+    fviews = [(K, R, t, img_as_float32(m)) for K, R, t, m in vp_views(data, "stem")]
+    avg = oracle_c.average(shape, origin, 1.0, fviews)
+    assert np.array_equal(avg, oracle_np.average(shape, origin, 1.0, fviews))
+    exp["average_stem_nolog_vs10"] = avg
+    np.savez_compressed(os.path.join(OUT, "virtual_plant_expected.npz"), **exp)
+
+    syn = {}
+    for n, v, kind in ((32, 6, "plant"), (64, 12, "plant"), (48, 5, "noise")):
+        shape, origin, vs, views = scenes.make_scene(n, v, kind)
+        lab = both_carve(shape, origin, vs, views)
+        syn[f"{kind}_{n}_{v}"] = lab.astype(np.int8)
+        print(kind, n, v, histogram3(lab))
+    digests = {}
+    for n, v, kind in ((128, 12, "plant"), (128, 12, "noise"), (128, 12, "solid")):
+        shape, origin, vs, views = scenes.make_scene(n, v, kind)
+        lab = both_carve(shape, origin, vs, views)
+        digests[f"{kind}_{n}_{v}"] = {"sha256_int32": sha256(lab.astype(np.int32)),
+                                      "hist_m1_0_p1": histogram3(lab)}
+        print(kind, n, v, digests[f"{kind}_{n}_{v}"])
+    # non-cubic slice of the literal test_geom_pipe_real.toml grid (301x301x561, vs 0.5)
+    shape, origin, vs, views = scenes.make_scene((61, 45, 113), 8, "plant")
+    lab = both_carve(shape, origin, vs, views)
+    syn["plant_61x45x113_8"] = lab.astype(np.int8)
+    np.savez_compressed(os.path.join(OUT, "synthetic_expected.npz"), **syn)
+    json.dump(digests, open(os.path.join(OUT, "synthetic_digests.json"), "w"), indent=1,
+              sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""Test-only helpers: oracle-backed stand-ins so that host logic (label loops, sharding,
+Voxels post-processing) runs on CPU.  Never imported by the product."""
+import hashlib
+
+import numpy as np
+
+from oracle import oracle_c
+from plant3dvision_amd import _native as nat
+from plant3dvision_amd.cl import Backprojection
+
+
+class OracleEngine:
+    """Same surface as ``_native.Engine``, computed by the C oracle (whole grid or slab)."""
+
+    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.slab = (0, self.shape[0]) if slab is None else (int(slab[0]), int(slab[1]))
+        self.slab_shape = (self.slab[1] - self.slab[0], self.shape[1], self.shape[2])
+        self.mode = mode
+        self.dtype = np.int32 if mode == nat.SC_MODE_CARVE else np.float32
+        self.device = device
+        kind = "carving" if mode == nat.SC_MODE_CARVE else "averaging"
+        dv = int(default_value) if mode == nat.SC_MODE_CARVE else np.float32(default_value)
+        # the oracle keeps the whole grid; only the slab's flat range is ever updated
+        self._vol = oracle_c.OracleVolume(self.shape, origin, voxel_size, kind, dv)
+        plane = self.shape[1] * self.shape[2]
+        self._begin, self._end = self.slab[0] * plane, self.slab[1] * plane
+        self.views_seen = 0
+
+    def set_option(self, key, value):
+        pass
+
+    def set_stream(self, ptr):
+        pass
+
+    def clear(self):
+        self._vol.clear()
+
+    def process_view(self, K, R, t, mask, mask_dtype):
+        self._vol.process_view(K, R, t, mask, begin=self._begin, end=self._end)
+        self.views_seen += 1
+
+    def flush(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def get_values(self, out=None):
+        vals = self._vol.values[self.slab[0]:self.slab[1]]
+        if out is None:
+            return vals.copy()
+        out[...] = vals.reshape(out.shape)
+        return out
+
+    def values_device_ptr(self):
+        return 0
+
+    def num_voxels(self):
+        return int(np.prod(self.slab_shape))
+
+    def close(self):
+        pass
+
+
+class OracleBackprojection(Backprojection):
+    """``Backprojection`` host logic over the oracle engine (CPU tests only)."""
+
+    def init_buffers(self):
+        self._engine = OracleEngine(self.shape, self.origin, self.voxel_size, self._mode,
+                                    default_value=float(self.default_value))
+        self.values_h = np.ascontiguousarray(
+            self.default_value * np.ones(self.shape, dtype=self.dtype), dtype=self.dtype)
+
+
+class FakeFile:
+    """Duck-type of a plantdb ``File`` as ``process_label`` uses it (cl.py:282-298)."""
+
+    def __init__(self, fid, array, metadata):
+        self.id = fid
+        self.array = array
+        self._md = metadata
+
+    def get_metadata(self, key=None, default=None):
+        if key is None:
+            return self._md
+        return self._md.get(key, default)
+
+
+class FakeFileset:
+    def __init__(self, files, metadata=None):
+        self._files = files
+        self._md = metadata or {}
+
+    def get_files(self, query=None):
+        return list(self._files)
+
+    def get_metadata(self, key=None, default=None):
+        if key is None:
+            return self._md
+        return self._md.get(key, default)
+
+
+def files_from_views(views, camera_key="colmap_camera", channel=None):
+    from plant3dvision_amd.scenes import camera_dict
+    files = []
+    for q, (K, R, t, mask) in enumerate(views):
+        md = {camera_key: camera_dict(K, R, t)}
+        if channel is not None:
+            md["channel"] = channel
+        files.append(FakeFile(f"{q:05d}_{channel or 'mask'}", mask, md))
+    return files
+
+
+def sha256(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def histogram3(labels):
+    return [int((labels == -1).sum()), int((labels == 0).sum()), int((labels == 1).sum())]
+
+
+import functools  # noqa: E402
+
+from plant3dvision_amd import scenes as _scenes  # noqa: E402
+
+
+@functools.lru_cache(maxsize=24)
+def scene(n, n_views, kind="plant", **kw):
+    """Memoised ``scenes.make_scene`` (the masks are read-only by convention)."""
+    shape, origin, vs, views = _scenes.make_scene(n, n_views, kind, **kw)
+    for _, _, _, m in views:
+        m.setflags(write=False)
+    return shape, origin, vs, views

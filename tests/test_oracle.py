@@ -1,0 +1,255 @@
+"""CPU: the oracle against the reference's pinned conventions, its two restatements against
+each other, the committed golden fixtures, and the edge cases of SURVEY.md 8a (H1-H10)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np
+from plant3dvision_amd import proc3d, scenes
+from plant3dvision_amd.cl import img_as_float32
+from plant3dvision_amd.tasks.cl import grid_from_bounding_box
+from tests.helpers import histogram3, scene, sha256
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# -- conventions the reference's own tests pin ------------------------------------------------
+def test_index2point_known_answer():
+    # reference tests/unit/test_proc3d.py:12-20
+    indexes = np.zeros((2, 3))
+    indexes[0, :] = [0, 0, 0]
+    indexes[1, :] = [2, 2, 2]
+    origin = np.array([-0.5, -0.5, -0.5])
+    pts = proc3d.index2point(indexes, origin, 0.5)
+    assert pts.tolist()[0] == origin.tolist()
+    assert pts.tolist()[1] == [0.5, 0.5, 0.5]
+
+
+def test_point2index_known_answer():
+    # reference tests/unit/test_proc3d.py:22-30
+    origin = np.array([-0.5, -0.5, -0.5])
+    pts = np.zeros((2, 3))
+    pts[0, :] = origin
+    pts[1, :] = 0.5
+    idx = proc3d.point2index(pts, origin, 0.5)
+    assert idx.tolist()[0] == [0, 0, 0]
+    assert idx.tolist()[1] == [2, 2, 2]
+
+
+def test_oracle_voxel_centres_follow_index2point():
+    """The kernel's voxel centre (backprojection.c:71-73) is index2point's: a camera looking
+    down +z with identity pose sees voxel (i,j,k) at pixel (fx*x/z+cx, fy*y/z+cy)."""
+    origin, vs = [-0.5, -0.5, 1.0], 0.5
+    K = [100.0, 100.0, 50.0, 50.0]
+    R = np.eye(3).reshape(9)
+    t = [0.0, 0.0, 0.0]
+    ijk = np.array([[0, 0, 0], [2, 2, 2], [3, 1, 4]])
+    u, v, ok = oracle_c.project(ijk, origin, vs, K, R, t, 100, 100)
+    pts = proc3d.index2point(ijk, np.array(origin), vs)
+    eu = np.trunc(pts[:, 0] / pts[:, 2] * 100.0 + 50.0).astype(int)
+    ev = np.trunc(pts[:, 1] / pts[:, 2] * 100.0 + 50.0).astype(int)
+    assert ok.tolist() == [1, 1, 1]
+    assert u.tolist() == eu.tolist() and v.tolist() == ev.tolist()
+
+
+# -- the two restatements agree ---------------------------------------------------------------
+@pytest.mark.parametrize("n,v,kind", [(24, 5, "plant"), (33, 4, "noise"), ((20, 31, 18), 6, "plant"),
+                                      (16, 3, "solid"), (16, 3, "empty")])
+def test_c_and_numpy_oracles_agree_carve(n, v, kind):
+    shape, origin, vs, views = scene(n, v, kind)
+    a = oracle_c.carve(shape, origin, vs, views)
+    b = oracle_np.carve(shape, origin, vs, views)
+    c = oracle_np.carve_closed_form(shape, origin, vs, views)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, c)
+
+
+def test_c_oracle_multithreaded_is_identical():
+    shape, origin, vs, views = scene(40, 6, "plant")
+    a = oracle_c.carve(shape, origin, vs, views, nthreads=1)
+    b = oracle_c.carve(shape, origin, vs, views, nthreads=5)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("default_value", [0, 1, -1, 7])
+def test_default_value_semantics(default_value):
+    """backprojection.c:67,81: -1 is sticky, only 0 is promoted to 1, others survive."""
+    shape, origin, vs, views = scene(20, 4, "plant")
+    a = oracle_c.carve(shape, origin, vs, views, default_value)
+    b = oracle_np.carve(shape, origin, vs, views, default_value)
+    c = oracle_np.carve_closed_form(shape, origin, vs, views, default_value)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    if default_value == -1:
+        assert (a == -1).all()
+    if default_value == 7:
+        assert set(np.unique(a)) <= {-1, 7}
+
+
+def test_carve_is_order_independent():
+    """what makes view fusion / re-ordering / sharding legal."""
+    shape, origin, vs, views = scene(28, 7, "plant")
+    a = oracle_c.carve(shape, origin, vs, views)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        perm = rng.permutation(len(views))
+        b = oracle_c.carve(shape, origin, vs, [views[q] for q in perm])
+        assert np.array_equal(a, b)
+
+
+def test_average_oracles_agree_and_order_matters_only_in_rounding():
+    shape, origin, vs, views = scene(24, 6, "noise")
+    rng = np.random.default_rng(11)
+    fviews = [(K, R, t, rng.random(m.shape, dtype=np.float32) * 3 - 1) for K, R, t, m in views]
+    a = oracle_c.average(shape, origin, vs, fviews)
+    b = oracle_np.average(shape, origin, vs, fviews)
+    assert np.array_equal(a, b)
+    c = oracle_c.average(shape, origin, vs, fviews[::-1])
+    np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-5)
+
+
+# -- parity hazards ---------------------------------------------------------------------------
+def _pose_identity():
+    return np.eye(3, dtype=np.float32).reshape(9), np.zeros(3, dtype=np.float32)
+
+
+def test_h4_truncation_accepts_minus_one_to_zero():
+    """(int) truncates toward zero: u_f in (-1, 0) -> 0 is inside (backprojection.c:23-27)."""
+    R, t = _pose_identity()
+    K = [10.0, 10.0, -0.5, 0.5]  # point on the axis -> u_f = -0.5, v_f = 0.5
+    u, v, ok = oracle_c.project([[0, 0, 0]], [0.0, 0.0, 2.0], 1.0, K, R, t, 4, 4)
+    assert (int(u[0]), int(v[0]), int(ok[0])) == (0, 0, 1)
+    K = [10.0, 10.0, -1.0, 0.5]  # u_f = -1.0 exactly -> u = -1 -> rejected
+    u, v, ok = oracle_c.project([[0, 0, 0]], [0.0, 0.0, 2.0], 1.0, K, R, t, 4, 4)
+    assert int(u[0]) == -1 and int(ok[0]) == 0
+
+
+def test_h4_right_edge():
+    R, t = _pose_identity()
+    for cx, W, want in ((3.5, 4, 1), (4.0, 4, 0), (3.999, 4, 1)):
+        u, v, ok = oracle_c.project([[0, 0, 0]], [0.0, 0.0, 2.0], 1.0, [10.0, 10.0, cx, 0.5], R, t, W, 4)
+        assert int(ok[0]) == want, (cx, W)
+
+
+def test_h5_pz_zero_negative_nan():
+    R, t = _pose_identity()
+    K = [10.0, 10.0, 2.0, 2.0]
+    # p_z == 0 : not rejected by :13, rejected by the cast (inf/NaN -> INT_MIN)
+    u, v, ok = oracle_c.project([[1, 0, 0], [0, 0, 0]], [0.0, 0.0, 0.0], 1.0, K, R, t, 4, 4)
+    assert ok.tolist() == [0, 0]
+    assert int(u[0]) == -2 ** 31  # +inf
+    assert int(u[1]) == -2 ** 31  # 0/0 = NaN
+    # p_z < 0 : rejected although the mirrored pixel would be inside
+    u, v, ok = oracle_c.project([[0, 0, 0]], [0.0, 0.0, -2.0], 1.0, K, R, t, 4, 4)
+    assert int(ok[0]) == 0
+    # huge quotient overflows int32 -> INT_MIN -> rejected
+    u, v, ok = oracle_c.project([[1, 0, 0]], [0.0, 0.0, 1e-30], 1.0, [1e10, 1.0, 0.0, 0.0], R, t, 4, 4)
+    assert int(u[0]) == -2 ** 31 and int(ok[0]) == 0
+    # NaN pose: (p_z < 0) is false for NaN, the cast rejects
+    tn = np.array([0, 0, np.nan], dtype=np.float32)
+    u, v, ok = oracle_c.project([[0, 0, 0]], [0.0, 0.0, 1.0], 1.0, K, R, tn, 4, 4)
+    assert int(ok[0]) == 0
+    ok_np, _, _ = oracle_np.backproject([1, 1, 1], [0.0, 0.0, 1.0], 1.0, K, R, tn, 4, 4)
+    assert not ok_np.any()
+
+
+def test_h8_any_nonzero_grey_is_foreground():
+    shape, origin, vs, views = scene(16, 3, "plant")
+    grey = [(K, R, t, np.where(m != 0, 1 + (np.arange(m.size).reshape(m.shape) % 200), 0).astype(np.uint8))
+            for K, R, t, m in views]
+    assert np.array_equal(oracle_c.carve(shape, origin, vs, views),
+                          oracle_c.carve(shape, origin, vs, grey))
+
+
+def test_unseen_voxels_stay_zero_when_camera_is_inside_the_volume():
+    shape, origin, vs, views = scene(24, 4, "solid", radius_factor=0.3, width=64, height=48,
+                                                 fx=40.0, fy=40.0, cx=32.0, cy=24.0)
+    a = oracle_c.carve(shape, origin, vs, views)
+    b = oracle_np.carve(shape, origin, vs, views)
+    assert np.array_equal(a, b)
+    h = histogram3(a)
+    assert h[1] > 0 and h[2] > 0 and h[0] == 0  # some never seen, some kept, none carved
+
+
+# -- golden fixtures --------------------------------------------------------------------------
+def _vp_views(data, channel, invert=False):
+    views = []
+    for q in range(data[f"masks_{channel}"].shape[0]):
+        m = data[f"masks_{channel}"][q]
+        if invert:
+            m = np.invert(m)
+        views.append((data[f"K_{channel}"][q].astype(np.float32),
+                      data[f"R_{channel}"][q].reshape(9).astype(np.float32),
+                      data[f"t_{channel}"][q].astype(np.float32), m))
+    return views
+
+
+@pytest.fixture(scope="module")
+def virtual_plant():
+    return (np.load(os.path.join(GOLDEN, "virtual_plant_inputs.npz")),
+            np.load(os.path.join(GOLDEN, "virtual_plant_expected.npz")))
+
+
+def test_virtual_plant_grid_math(virtual_plant):
+    """tasks/cl.py:143-147 on the reference's own bounding box (metadata/images.json)."""
+    data, exp = virtual_plant
+    bbox = {"x": list(data["bbox"][0]), "y": list(data["bbox"][1]), "z": list(data["bbox"][2])}
+    shape, origin = grid_from_bounding_box(bbox, 1.0)
+    assert shape == [24, 24, 120] == exp["shape_vs10"].tolist()
+    shape, origin = grid_from_bounding_box(bbox, 0.5)
+    assert shape == [47, 48, 240]
+    assert origin == [bbox["x"][0], bbox["y"][0], bbox["z"][0]]
+
+
+def test_virtual_plant_pose_convention(virtual_plant):
+    """Appendix B: det R = +1, camera centre C = -R^T t lies on the scan circle
+    (scan.toml ScanPath: centre (-2, 3), radius 75, z 65)."""
+    data, _ = virtual_plant
+    for q in range(18):
+        R = data["R_stem"][q]
+        t = data["t_stem"][q]
+        assert abs(np.linalg.det(R) - 1.0) < 1e-5
+        C = -R.T @ t
+        assert abs(np.hypot(C[0] + 2.0, C[1] - 3.0) - 75.0) < 1e-2
+        assert abs(C[2] - 65.0) < 1e-2
+
+
+@pytest.mark.parametrize("tag,vs", [("vs10", 1.0), ("vs05", 0.5)])
+def test_virtual_plant_carve_golden(virtual_plant, tag, vs):
+    data, exp = virtual_plant
+    shape, origin = exp[f"shape_{tag}"].tolist(), exp[f"origin_{tag}"].tolist()
+    lab = oracle_c.carve(shape, origin, vs, _vp_views(data, "stem"))
+    assert np.array_equal(lab, exp[f"carve_stem_{tag}"].astype(np.int32))
+    lab = oracle_c.carve(shape, origin, vs, _vp_views(data, "background", invert=True))
+    assert np.array_equal(lab, exp[f"carve_background_invert_{tag}"].astype(np.int32))
+    if vs == 1.0:
+        lab = oracle_np.carve(shape, origin, vs, _vp_views(data, "stem"))
+        assert np.array_equal(lab, exp[f"carve_stem_{tag}"].astype(np.int32))
+
+
+def test_virtual_plant_average_golden(virtual_plant):
+    data, exp = virtual_plant
+    shape, origin = exp["shape_vs10"].tolist(), exp["origin_vs10"].tolist()
+    fviews = [(K, R, t, img_as_float32(m)) for K, R, t, m in _vp_views(data, "stem")]
+    avg = oracle_c.average(shape, origin, 1.0, fviews)
+    assert avg.dtype == np.float32
+    assert np.array_equal(avg, exp["average_stem_nolog_vs10"])
+
+
+def test_synthetic_golden_small():
+    exp = np.load(os.path.join(GOLDEN, "synthetic_expected.npz"))
+    for key, n, v, kind in (("plant_32_6", 32, 6, "plant"), ("noise_48_5", 48, 5, "noise"),
+                            ("plant_61x45x113_8", (61, 45, 113), 8, "plant")):
+        shape, origin, vs, views = scene(n, v, kind)
+        lab = oracle_c.carve(shape, origin, vs, views, nthreads=4)
+        assert np.array_equal(lab, exp[key].astype(np.int32)), key
+
+
+def test_synthetic_golden_cfg1_digest():
+    """BASELINE cfg 1 (128^3 x 12): SHA-256 of the int32 C-order grid + histogram."""
+    dig = json.load(open(os.path.join(GOLDEN, "synthetic_digests.json")))
+    shape, origin, vs, views = scene(128, 12, "plant")
+    lab = oracle_c.carve(shape, origin, vs, views, nthreads=8)
+    assert histogram3(lab) == dig["plant_128_12"]["hist_m1_0_p1"]
+    assert sha256(lab.astype(np.int32)) == dig["plant_128_12"]["sha256_int32"]
