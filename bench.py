@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvoxel.views/s of the space carve, 512^3 x 72 synthetic views per GPU.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1, or under torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic input: clear the grid, take
+the 72 uint8 masks that are ALREADY RESIDENT IN HBM, pack them to bit tiles and carve the
+whole slab (the ``Backprojection.process_fileset`` work after ingest).  The result stays in HBM.
+
+Workload (config.workload): BASELINE cfg 3, 512^3 voxels x 72 views, scene S1 "plant"
+(SURVEY.md 8d).  N GPUs: weak scaling -- every rank carves one X-slab of 512^3 voxels of a
+grid N times as large (N=8 is BASELINE cfg 4, 1024^3), no data-path collective (voxels are
+independent).  ``--gather`` times the optional grid assembly AFTER the timed region
+and reports it next to the headline; it is never part of ``value``.
+
+Two schedules of the same kernel are measured in the same run:
+  fused  (default, ``value``): all 72 views in one launch, state in registers, 4N bytes written;
+  stream (``stream`` object) : one launch per view as the reference does (cl.py:223-226), the
+         formulation SURVEY 8d's algorithmic-bytes figure (~4 B per voxel.view) is defined on.
+The ``roofline`` object describes the dominant kernel of the ``value`` path with ITS OWN
+algorithmic bytes; ``equiv_streaming_frac`` restates its speed in units of the streaming
+roofline (capped at 1, never an HBM-utilisation claim -- SURVEY 8d honesty guard).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}  # multiples of n per axis
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="per-GPU grid edge (voxels)")
+    ap.add_argument("--views", type=int, default=72)
+    ap.add_argument("--scene", default="plant", choices=["plant", "solid", "noise"])
+    ap.add_argument("--path", default="fused", choices=["fused", "stream"],
+                    help="schedule reported as `value` (the other is reported beside it)")
+    ap.add_argument("--gather", default="none", choices=["none", "allgather", "allgather8", "allreduce"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--skip-other-path", action="store_true")
+    return ap.parse_args()
+
+
+def global_shape(n, gpus):
+    if gpus in GRIDS:
+        m = GRIDS[gpus]
+        return [n * m[0], n * m[1], n * m[2]]
+    return [n * gpus, n, n]
+
+
+def run_steps(engine, nat, K, R, t, masks_dev, V, H, W, steps, vpl):
+    engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+    for _ in range(steps):
+        engine.clear()
+        engine.process_views_device(K, R, t, masks_dev, V, H, W, nat.SC_MASK_U8)
+        engine.flush()
+
+
+def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world):
+    """Barrier + synchronize on both sides, MAX over ranks; returns (seconds, kernel stats)."""
+    engine.set_option(nat.SC_OPT_TIME_KERNELS, 1)
+    engine.reset_kernel_stats()
+    if world > 1:
+        dist.barrier()
+    engine.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(engine, nat, *args_tuple, steps, vpl)
+    engine.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = {}
+    for name, kid in (("carve", nat.SC_KERNEL_CARVE), ("pack", nat.SC_KERNEL_PACK),
+                      ("fill", nat.SC_KERNEL_FILL)):
+        n, ms = engine.kernel_stats(kid)
+        stats[name] = {"launches": n, "total_ms": ms, "avg_ms": (ms / n if n else 0.0)}
+    engine.set_option(nat.SC_OPT_TIME_KERNELS, 0)
+    engine.reset_kernel_stats()
+    return dt, stats
+
+
+def cpu_baseline(shape, origin, vs, views, budget_s):
+    """The oracle (a port of the reference kernel, oracle/spacecarve_oracle.c) on this box's
+    host cores, on a bounded sample: a central block of X-planes of the same grid, all views."""
+    from oracle import oracle_c
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    nx, ny, nz = shape
+    plane = ny * nz
+    V = len(views)
+
+    def run(planes):
+        i0 = (nx - planes) // 2
+        vol = oracle_c.OracleVolume(shape, origin, vs, "carving", 0)
+        t0 = time.perf_counter()
+        for K, R, t, m in views:
+            vol.process_view(K, R, t, m, nthreads=cores, begin=i0 * plane, end=(i0 + planes) * plane)
+        return time.perf_counter() - t0
+
+    probe_planes = max(1, min(nx, 4))
+    t_probe = run(probe_planes)
+    planes = int(max(probe_planes, min(nx, probe_planes * budget_s / max(t_probe, 1e-6))))
+    t = run(planes) if planes > probe_planes else t_probe
+    vv = planes * plane * V
+    return {"value": vv / t / 1e6, "unit": "Mvoxel*views/s", "cores": cores, "kind": "port",
+            "sample": f"{planes} central X-planes of the {nx}x{ny}x{nz} grid x {V} views "
+                      f"({vv / 1e6:.0f} Mvoxel*views, {t:.1f} s), oracle/spacecarve_oracle.c, "
+                      f"int32 masks, {cores} threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from plant3dvision_amd import _native as nat
+    from plant3dvision_amd import scenes
+    from plant3dvision_amd.sharded import ShardedBackprojection
+
+    shape = global_shape(a.n, world)
+    gshape, origin, vs, views = scenes.make_scene(tuple(shape), a.views, a.scene)
+    V = len(views)
+    H, W = views[0][3].shape
+    sb = ShardedBackprojection(gshape, origin, vs, rank=rank, world_size=world, device=local_rank)
+    eng = sb.engine
+    n_local = eng.num_voxels()
+    n_total = int(np.prod(gshape))
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    masks_dev = eng.dev_alloc(stack.nbytes)
+    eng.dev_upload(masks_dev, stack)
+    K = np.stack([v[0] for v in views])
+    R = np.stack([v[1] for v in views])
+    t = np.stack([v[2] for v in views])
+    call = (K, R, t, masks_dev, V, H, W)
+
+    vpl = {"fused": 0, "stream": 1}
+    other = "stream" if a.path == "fused" else "fused"
+    # warmup both schedules (untimed)
+    run_steps(eng, nat, *call, a.warmup, vpl[a.path])
+    eng.synchronize()
+    dt, stats = timed(eng, nat, torch, dist, call, a.steps, vpl[a.path], world)
+    res_other = None
+    if not a.skip_other_path:
+        osteps = max(2, a.steps // 4) if other == "stream" else a.steps
+        run_steps(eng, nat, *call, 1, vpl[other])
+        eng.synchronize()
+        dto, statso = timed(eng, nat, torch, dist, call, osteps, vpl[other], world)
+        res_other = (dto, statso, osteps)
+
+    # optional grid assembly, outside the timed region
+    gather = None
+    if a.gather != "none":
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if a.gather == "allgather":
+            full = sb.all_gather()
+        elif a.gather == "allgather8":
+            full = sb.all_gather(compress=True)
+        else:
+            full = sb.all_reduce()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        gather = {"kind": a.gather, "ms": (time.perf_counter() - t0) * 1e3,
+                  "bytes_out_per_rank": int(full.numel() * full.element_size())}
+        del full
+
+    # --- roofline bookkeeping (per launch of the carve kernel, per rank) -------------------
+    b_alg_per_vv = (4.0 * n_local * V + 4.0 * n_local + V * W * H) / (n_local * V)
+    mask_bits_bytes = ((W + 31) // 32) * ((H + 31) // 32) * 128
+
+    def roof(path, st, traffic):
+        avg_ms = st["carve"]["avg_ms"]
+        if path == "fused":
+            bytes_launch = 4.0 * n_local + V * mask_bits_bytes  # state written once + bit tiles read
+            model = "fused launch: 4 B/voxel state write + V*W*H/8 B mask bit tiles (state never read)"
+            units = n_local * V
+        else:
+            bytes_launch = b_alg_per_vv * n_local  # SURVEY 8d per-unit figure x voxel.views/launch
+            model = "per-view launch: SURVEY 8d B_alg/(N*V) = %.3f B per voxel.view x N voxel.views" % b_alg_per_vv
+            units = n_local
+        ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "carve_kernel",
+             "avg_launch_ms": avg_ms, "launches": st["carve"]["launches"],
+             "algorithmic_bytes_per_launch": bytes_launch, "bytes_model": model,
+             "voxel_views_per_launch": units}
+        if path == "fused":
+            eq = (b_alg_per_vv * n_local * V) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0
+            r["equiv_streaming_frac"] = min(1.0, eq)
+            r["equiv_streaming_note"] = ("speed restated in units of the per-view streaming roofline "
+                                         "(SURVEY 8d); not HBM utilisation; uncapped %.2f" % eq)
+        return r
+
+    traffic = {}
+    if os.path.exists(a.traffic_json):
+        try:
+            traffic = json.load(open(a.traffic_json))
+        except Exception:
+            traffic = {}
+
+    def traffic_for(path):
+        key = f"{path}_{a.scene}_{a.n}_{a.views}"
+        ent = traffic.get(key)
+        return ent.get("hbm_bytes_per_launch") if isinstance(ent, dict) else None
+
+    if rank == 0:
+        value = n_total * V * a.steps / dt / 1e6
+        out = {
+            "metric": "Mvoxels*views/sec space-carve, 512^3 x 72 views per MI355X",
+            "value": value, "unit": "Mvoxel*views/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 addressing / int32 state",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE cfg 3: {a.n}^3 voxels x {V} views per GPU, scene S1 "
+                                   f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
+                       "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
+                       "parallelism": f"x-slab x{world}, no data-path collective",
+                       "path": a.path, "views_per_launch": V if a.path == "fused" else 1},
+            "roofline": roof(a.path, stats, traffic_for(a.path)),
+            "kernels": stats,
+        }
+        if res_other is not None:
+            dto, statso, osteps = res_other
+            out[other] = {"value": n_total * V * osteps / dto / 1e6, "unit": "Mvoxel*views/s",
+                          "steps": osteps, "ms_per_step": dto / osteps * 1e3,
+                          "roofline": roof(other, statso, traffic_for(other)), "kernels": statso}
+        if gather is not None:
+            out["gather"] = gather
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(gshape, origin, vs, views, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.dev_free(masks_dev)
+    sb.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

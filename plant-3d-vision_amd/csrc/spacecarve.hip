@@ -132,9 +132,9 @@ __device__ __forceinline__ bool lane_setup(const GridDesc &g, Lane &ln) {
 // FRESH: the state is known to be `init` everywhere (nothing has been applied since
 // create/clear), so it is not read.  VEC: nz % 4 == 0, state accessed as int4.
 template <bool FRESH, bool VEC>
-__global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ labels, GridDesc g,
-                                                       const ViewDesc *__restrict__ views,
-                                                       int nviews, int32_t init) {
+__device__ __forceinline__ void carve_body(int32_t *__restrict__ labels, const GridDesc &g,
+                                           const ViewDesc *__restrict__ views, int nviews,
+                                           int32_t init) {
     Lane ln;
     if (!lane_setup(g, ln)) return;
     int32_t lab[4], was[4];
@@ -198,12 +198,28 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
     }
 }
 
+// Many views per launch: descriptors in device memory.
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                       const ViewDesc *__restrict__ views,
+                                                       int nviews, int32_t init) {
+    carve_body<FRESH, VEC>(labels, g, views, nviews, init);
+}
+
+// One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
+// the kernel arguments, so a launch needs no copy and no host-side wait.
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ labels, GridDesc g,
+                                                         ViewDesc view, int32_t init) {
+    carve_body<FRESH, VEC>(labels, g, &view, 1, init);
+}
+
 // average (backprojection.c:36-55): value += mask[v][u] for every in-image view, in the
 // order given (float32 sum, order matters).
 template <bool FRESH, bool VEC>
-__global__ __launch_bounds__(kBlock) void average_kernel(float *__restrict__ values, GridDesc g,
-                                                         const ViewDesc *__restrict__ views,
-                                                         int nviews, float init) {
+__device__ __forceinline__ void average_body(float *__restrict__ values, const GridDesc &g,
+                                             const ViewDesc *__restrict__ views, int nviews,
+                                             float init) {
     Lane ln;
     if (!lane_setup(g, ln)) return;
     float val[4];
@@ -243,6 +259,19 @@ __global__ __launch_bounds__(kBlock) void average_kernel(float *__restrict__ val
         for (int e = 0; e < 4; ++e)
             if (e < (int)ln.nvalid) p[e] = val[e];
     }
+}
+
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void average_kernel(float *__restrict__ values, GridDesc g,
+                                                         const ViewDesc *__restrict__ views,
+                                                         int nviews, float init) {
+    average_body<FRESH, VEC>(values, g, views, nviews, init);
+}
+
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ values, GridDesc g,
+                                                           ViewDesc view, float init) {
+    average_body<FRESH, VEC>(values, g, &view, 1, init);
 }
 
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
@@ -343,11 +372,9 @@ struct sc_engine {
 
     // deferred views
     std::vector<ViewDesc> pending;
-    ViewDesc *views_dev = nullptr;
+    ViewDesc *views_dev = nullptr;  // ring of descriptors, consumed in stream order
     ViewDesc *views_pin = nullptr;
-    size_t views_cap = 0;
-    hipEvent_t views_ev = nullptr;
-    bool views_ev_armed = false;
+    size_t views_cap = 0, views_head = 0;
 
     // mask storage for pending views
     std::vector<Chunk> chunks;
@@ -578,47 +605,57 @@ void interleave(std::vector<ViewDesc> &v) {
     v.swap(out);
 }
 
-int flush(sc_engine *e) {
+// Launch the first `count` pending views (count == 0: all of them).
+int flush(sc_engine *e, size_t count = 0) {
     if (e->pending.empty()) return SC_OK;
-    size_t nv = e->pending.size();
-    if (nv > e->views_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (e->views_dev) (void)hipFree(e->views_dev);
-        if (e->views_pin) (void)hipHostFree(e->views_pin);
-        e->views_dev = e->views_pin = nullptr;
-        e->views_cap = 0;
-        e->views_ev_armed = false;
-        size_t cap = std::max<size_t>(nv, 128);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->views_dev), cap * sizeof(ViewDesc)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->views_pin), cap * sizeof(ViewDesc),
-                              hipHostMallocDefault));
-        e->views_cap = cap;
-    }
-    if (!e->views_ev) HIP_TRY(hipEventCreateWithFlags(&e->views_ev, hipEventDisableTiming));
-    if (e->views_ev_armed) {
-        // the previous flush's kernel must be done with views_dev, its copy with views_pin
-        HIP_TRY(hipEventSynchronize(e->views_ev));
-        e->views_ev_armed = false;
-    }
-    if (e->mode == SC_MODE_CARVE && e->view_order == 1) interleave(e->pending);
-    memcpy(e->views_pin, e->pending.data(), nv * sizeof(ViewDesc));
-    HIP_TRY(hipMemcpyAsync(e->views_dev, e->views_pin, nv * sizeof(ViewDesc),
-                           hipMemcpyHostToDevice, e->stream));
-
+    size_t nv = count ? std::min(count, e->pending.size()) : e->pending.size();
     GridDesc g = grid_desc(e);
     uint64_t blocks = (g.ngroups + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
     bool vec = (e->nz % 4) == 0;
     dim3 grid((uint32_t)blocks), block(kBlock);
+    const ViewDesc *vd = nullptr;
+    if (nv > 1) {
+        if (e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
+            interleave(e->pending);
+        // descriptor ring: slots are reused only after a wrap, which waits for the stream
+        if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            e->views_head = 0;
+        }
+        if (nv > e->views_cap) {
+            if (e->views_dev) (void)hipFree(e->views_dev);
+            if (e->views_pin) (void)hipHostFree(e->views_pin);
+            e->views_dev = e->views_pin = nullptr;
+            e->views_cap = 0;
+            size_t cap = std::max<size_t>(nv * 4, 1024);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->views_dev), cap * sizeof(ViewDesc)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->views_pin), cap * sizeof(ViewDesc),
+                                  hipHostMallocDefault));
+            e->views_cap = cap;
+        }
+        ViewDesc *pin = e->views_pin + e->views_head, *dev = e->views_dev + e->views_head;
+        memcpy(pin, e->pending.data(), nv * sizeof(ViewDesc));
+        HIP_TRY(hipMemcpyAsync(dev, pin, nv * sizeof(ViewDesc), hipMemcpyHostToDevice, e->stream));
+        e->views_head += nv;
+        vd = dev;
+    }
+    const ViewDesc &one = e->pending[0];
     LaunchTimer lt{e, e->mode == SC_MODE_CARVE ? SC_KERNEL_CARVE : SC_KERNEL_AVERAGE};
     int rc = lt.begin();
     if (rc) return rc;
     if (e->mode == SC_MODE_CARVE) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
-#define LAUNCH_CARVE(F, V)                                                                  \
-    hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, e->views_dev, \
-                       (int)nv, init)
+#define LAUNCH_CARVE(F, V)                                                                       \
+    do {                                                                                         \
+        if (nv == 1)                                                                             \
+            hipLaunchKernelGGL((carve_kernel_1<F, V>), grid, block, 0, e->stream, st, g, one,    \
+                               init);                                                            \
+        else                                                                                     \
+            hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd,       \
+                               (int)nv, init);                                                   \
+    } while (0)
         if (e->fresh) {
             if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
         } else {
@@ -627,9 +664,15 @@ int flush(sc_engine *e) {
 #undef LAUNCH_CARVE
     } else {
         float *st = static_cast<float *>(e->state);
-#define LAUNCH_AVG(F, V)                                                                      \
-    hipLaunchKernelGGL((average_kernel<F, V>), grid, block, 0, e->stream, st, g, e->views_dev, \
-                       (int)nv, e->default_value)
+#define LAUNCH_AVG(F, V)                                                                         \
+    do {                                                                                         \
+        if (nv == 1)                                                                             \
+            hipLaunchKernelGGL((average_kernel_1<F, V>), grid, block, 0, e->stream, st, g, one,  \
+                               e->default_value);                                                \
+        else                                                                                     \
+            hipLaunchKernelGGL((average_kernel<F, V>), grid, block, 0, e->stream, st, g, vd,     \
+                               (int)nv, e->default_value);                                       \
+    } while (0)
         if (e->fresh) {
             if (vec) LAUNCH_AVG(true, true); else LAUNCH_AVG(true, false);
         } else {
@@ -640,19 +683,21 @@ int flush(sc_engine *e) {
     HIP_TRY(hipGetLastError());
     rc = lt.end();
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e->views_ev, e->stream));
-    e->views_ev_armed = true;
     e->fresh = false;
-    e->pending.clear();
-    arena_reset(e);
+    e->pending.erase(e->pending.begin(), e->pending.begin() + (ptrdiff_t)nv);
+    if (e->pending.empty()) arena_reset(e);  // masks of launched views are dead in stream order
     return SC_OK;
 }
 
 int after_enqueue(sc_engine *e) {
-    size_t np = e->pending.size();
-    if ((e->views_per_launch > 0 && (int64_t)np >= e->views_per_launch) ||
-        (int64_t)np >= e->max_pending)
-        return flush(e);
+    if (e->views_per_launch > 0) {
+        while ((int64_t)e->pending.size() >= e->views_per_launch) {
+            int rc = flush(e, (size_t)e->views_per_launch);
+            if (rc) return rc;
+        }
+        return SC_OK;
+    }
+    if ((int64_t)e->pending.size() >= e->max_pending) return flush(e);
     return SC_OK;
 }
 
@@ -766,7 +811,6 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
-    if (e->views_ev) (void)hipEventDestroy(e->views_ev);
     if (e->state) (void)hipFree(e->state);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -891,22 +935,10 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
     size_t es = elem_size(mask_dtype);
     int64_t row = (int64_t)W * (int64_t)es, view = row * H;
     if (e->mode == SC_MODE_CARVE) {
-        // honour views_per_launch by feeding the packer in launch-sized batches
-        int done = 0;
-        while (done < V) {
-            int64_t room = e->views_per_launch > 0
-                               ? e->views_per_launch - (int64_t)e->pending.size()
-                               : e->max_pending - (int64_t)e->pending.size();
-            int take = (int)std::min<int64_t>(V - done, std::max<int64_t>(room, 1));
-            rc = enqueue_pack(e, take, K + 4 * done, R + 9 * done, t + 3 * done,
-                              static_cast<const char *>(masks_dev) + (int64_t)done * view, H, W,
-                              mask_dtype, row, view);
-            if (rc) return rc;
-            rc = after_enqueue(e);
-            if (rc) return rc;
-            done += take;
-        }
-        return SC_OK;
+        // one pack launch for the whole batch, then carve launches per views_per_launch
+        rc = enqueue_pack(e, V, K, R, t, masks_dev, H, W, mask_dtype, row, view);
+        if (rc) return rc;
+        return after_enqueue(e);
     }
     for (int q = 0; q < V; ++q) {
         ViewDesc d;

@@ -1,0 +1,348 @@
+"""GPU: the HIP engine, called through the C ABI, against the CPU oracle and the committed
+golden fixtures.  Bar: bit-exact for carve (int32) AND for average (float32 -- the sum is
+performed in the same order with the same IEEE operations, so tolerance is zero)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c
+from plant3dvision_amd import _native as nat
+from plant3dvision_amd.cl import EPS, Backprojection, img_as_float32
+from plant3dvision_amd.tasks import cl as tasks_cl
+from tests.helpers import files_from_views, histogram3, scene, sha256
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def hip_carve(shape, origin, vs, views, default_value=0, views_per_launch=0, device=0,
+              view_order=1):
+    bp = Backprojection(shape, origin, vs, default_value=default_value, device=device,
+                        views_per_launch=views_per_launch)
+    bp._engine.set_option(nat.SC_OPT_VIEW_ORDER, view_order)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    out = bp.get_values().copy()
+    bp.close()
+    return out
+
+
+def hip_average(shape, origin, vs, fviews, default_value=0, views_per_launch=0, device=0):
+    bp = Backprojection(shape, origin, vs, type="averaging", default_value=default_value,
+                        device=device, views_per_launch=views_per_launch)
+    for K, R, t, m in fviews:
+        bp.process_view(K, R, t, m)
+    out = bp.get_values().copy()
+    bp.close()
+    return out
+
+
+def test_library_sees_gfx950(gpu_device):
+    assert nat.device_count() >= 1
+
+
+def test_ctor_like_reference_unit_test(gpu_device):
+    # reference tests/unit/test_cl.py:5-9, plus what the reference never checks: the values
+    bp = Backprojection([10, 10, 10], [0.0, 0.0, 0.0], 1.0)
+    v = bp.get_values()
+    assert v.dtype == np.int32 and v.shape == (10, 10, 10) and (v == 0).all()
+    bp = Backprojection([10, 10, 10], [0.0, 0.0, 0.0], 1.0, 'averaging', default_value=2.5)
+    v = bp.get_values()
+    assert v.dtype == np.float32 and (v == 2.5).all()
+
+
+@pytest.mark.parametrize("n,v,kind", [(32, 6, "plant"), (48, 5, "noise"), ((20, 31, 18), 6, "plant"),
+                                      ((7, 5, 3), 4, "plant"), ((9, 9, 1), 3, "noise"),
+                                      ((61, 45, 113), 8, "plant"), (16, 3, "solid"), (16, 3, "empty")])
+@pytest.mark.parametrize("vpl", [0, 1, 3])
+def test_carve_matches_oracle(gpu_device, n, v, kind, vpl):
+    """vpl = views per launch: 0 fused, 1 the reference's one-launch-per-view, 3 chunks."""
+    shape, origin, vs, views = scene(n, v, kind)
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
+    got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+    assert got.dtype == np.int32
+    assert np.array_equal(got, want), histogram3(got)
+
+
+def test_carve_given_order_equals_interleaved_order(gpu_device):
+    shape, origin, vs, views = scene(40, 9, "plant")
+    a = hip_carve(shape, origin, vs, views, view_order=0)
+    b = hip_carve(shape, origin, vs, views, view_order=1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, oracle_c.carve(shape, origin, vs, views))
+
+
+@pytest.mark.parametrize("default_value", [1, -1, 7])
+def test_carve_default_values(gpu_device, default_value):
+    shape, origin, vs, views = scene(20, 4, "plant")
+    want = oracle_c.carve(shape, origin, vs, views, default_value)
+    for vpl in (0, 1):
+        got = hip_carve(shape, origin, vs, views, default_value, views_per_launch=vpl)
+        assert np.array_equal(got, want)
+
+
+def test_camera_inside_volume_unseen_and_behind(gpu_device):
+    """p_z <= 0 voxels, off-image voxels (label stays 0), tiny images."""
+    shape, origin, vs, views = scene(24, 4, "solid", radius_factor=0.3, width=64, height=48,
+                                     fx=40.0, fy=40.0, cx=32.0, cy=24.0)
+    want = oracle_c.carve(shape, origin, vs, views)
+    assert histogram3(want)[1] > 0
+    assert np.array_equal(hip_carve(shape, origin, vs, views), want)
+    shape, origin, vs, views = scene(30, 6, "noise", radius_factor=0.45, width=100, height=37,
+                                     fx=55.0, fy=50.0, cx=50.0, cy=18.0, tilt_deg=12.0)
+    want = oracle_c.carve(shape, origin, vs, views)
+    assert min(histogram3(want)) > 0  # all three labels occur
+    for vpl in (0, 1):
+        assert np.array_equal(hip_carve(shape, origin, vs, views, views_per_launch=vpl), want)
+
+
+def test_degenerate_poses_nan_inf_zero_depth(gpu_device):
+    """H4/H5: NaN, inf and p_z == 0 must be rejected exactly as the canonical cast does."""
+    shape, origin, vs = [8, 8, 8], [0.0, 0.0, 0.0], 1.0
+    m = np.full((16, 16), 255, dtype=np.uint8)
+    m[::2] = 0
+    eye = np.eye(3, dtype=np.float32).reshape(9)
+    views = [
+        ([10.0, 10.0, 8.0, 8.0], eye, [0.0, 0.0, 0.0], m),           # p_z == 0 plane at k = 0
+        ([10.0, 10.0, 8.0, 8.0], eye, [0.0, 0.0, -3.0], m),          # some voxels behind
+        ([10.0, 10.0, 8.0, 8.0], eye, [0.0, 0.0, np.nan], m),        # NaN depth
+        ([np.inf, 10.0, 8.0, 8.0], eye, [0.0, 0.0, 1.0], m),         # inf focal
+        ([1e30, 1e30, 8.0, 8.0], eye, [1e30, 0.0, 1e-30], m),        # overflow to inf
+        ([10.0, 10.0, -0.5, 7.5], eye, [0.0, 0.0, 1.0], m),          # u_f in (-1, 0) for x = 0
+    ]
+    want = oracle_c.carve(shape, origin, vs, views)
+    for vpl in (0, 1):
+        assert np.array_equal(hip_carve(shape, origin, vs, views, views_per_launch=vpl), want)
+
+
+def test_mask_dtypes_bool_int32_grey(gpu_device):
+    shape, origin, vs, views = scene(24, 4, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    as_bool = [(K, R, t, m != 0) for K, R, t, m in views]
+    as_i32 = [(K, R, t, m.astype(np.int32) * 1000) for K, R, t, m in views]
+    grey = [(K, R, t, np.where(m != 0, 1 + (np.arange(m.size).reshape(m.shape) % 200), 0).astype(np.uint8))
+            for K, R, t, m in views]
+    as_f64 = [(K, R, t, m.astype(np.float64) / 255.0 * 0.9) for K, R, t, m in views]  # int32 cast -> 0
+    for vv in (as_bool, as_i32, grey):
+        assert np.array_equal(hip_carve(shape, origin, vs, vv), want)
+    assert np.array_equal(hip_carve(shape, origin, vs, as_f64), oracle_c.carve(shape, origin, vs, as_f64))
+
+
+def test_odd_image_sizes(gpu_device):
+    for (w, h) in ((33, 17), (64, 64), (65, 31), (1, 1), (129, 3)):
+        shape, origin, vs, views = scene(20, 4, "noise", width=w, height=h, fx=0.8 * w, fy=0.8 * w,
+                                         cx=w / 2.0, cy=h / 2.0)
+        want = oracle_c.carve(shape, origin, vs, views)
+        assert np.array_equal(hip_carve(shape, origin, vs, views), want), (w, h)
+
+
+def test_clear_and_reuse(gpu_device):
+    shape, origin, vs, views = scene(24, 5, "plant")
+    bp = Backprojection(shape, origin, vs)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    first = bp.get_values().copy()
+    # more views after a read-back continue from the stored state (non-fresh path)
+    inv = [(K, R, t, np.invert(m)) for K, R, t, m in views[:2]]
+    for K, R, t, m in inv:
+        bp.process_view(K, R, t, m)
+    second = bp.get_values().copy()
+    assert np.array_equal(second, oracle_c.carve(shape, origin, vs, list(views) + inv))
+    bp.clear()
+    assert (bp.get_values() == 0).all()
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    assert np.array_equal(bp.get_values(), first)
+
+
+@pytest.mark.parametrize("vpl", [0, 1, 2])
+def test_average_matches_oracle_bitwise(gpu_device, vpl):
+    shape, origin, vs, views = scene((20, 17, 22), 6, "noise", width=160, height=120, fx=130.0,
+                                     fy=130.0, cx=80.0, cy=60.0)
+    rng = np.random.default_rng(5)
+    fviews = [(K, R, t, (rng.random(m.shape, dtype=np.float32) * 4 - 2)) for K, R, t, m in views]
+    want = oracle_c.average(shape, origin, vs, fviews, default_value=0.25)
+    got = hip_average(shape, origin, vs, fviews, default_value=0.25, views_per_launch=vpl)
+    assert got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # tolerance: 0 ulp
+
+
+def test_average_log_path_uint8_masks(gpu_device):
+    shape, origin, vs, views = scene(16, 4, "plant")
+    bp = Backprojection(shape, origin, vs, type="averaging", log=True)
+    vol = bp.process_fileset(files_from_views(views, "colmap_camera"), "colmap_camera")
+    fviews = [(K, R, t, np.log(EPS + img_as_float32(m))) for K, R, t, m in views]
+    assert np.array_equal(vol, oracle_c.average(shape, origin, vs, fviews))
+
+
+def test_process_fileset_with_labels(gpu_device):
+    shape, origin, vs, views = scene(16, 3, "plant")
+    stem = files_from_views(views, "camera", channel="stem")
+    other = files_from_views([(K, R, t, np.invert(m)) for K, R, t, m in views], "camera", channel="bg")
+    bp = Backprojection(shape, origin, vs, labels=["stem", "bg"])
+    res = bp.process_fileset(stem + other, "camera")
+    assert res.dtype == np.float64 and res.shape == (2, *shape)
+    assert np.array_equal(res[0], oracle_c.carve(shape, origin, vs, views))
+    assert np.array_equal(res[1], oracle_c.carve(shape, origin, vs, [(K, R, t, np.invert(m)) for K, R, t, m in views]))
+
+
+def test_voxels_run_end_to_end(gpu_device):
+    shape, origin, vs, views = scene(24, 6, "plant")
+    bbox = {a: [o, o + (n - 1) * vs] for a, o, n in zip("xyz", origin, shape)}
+    vol, labels, md = tasks_cl.voxels_run(files_from_views(views), bbox, voxel_size=vs)
+    assert labels is None and md["origin"] == origin
+    assert np.array_equal(vol, oracle_c.carve(shape, origin, vs, views))
+
+
+# -- committed golden fixtures ----------------------------------------------------------------
+def _vp_views(data, channel, invert=False):
+    out = []
+    for q in range(data[f"masks_{channel}"].shape[0]):
+        m = data[f"masks_{channel}"][q]
+        out.append((data[f"K_{channel}"][q].astype(np.float32),
+                    data[f"R_{channel}"][q].reshape(9).astype(np.float32),
+                    data[f"t_{channel}"][q].astype(np.float32), np.invert(m) if invert else m))
+    return out
+
+
+@pytest.mark.parametrize("tag,vs", [("vs10", 1.0), ("vs05", 0.5)])
+def test_virtual_plant_golden(gpu_device, tag, vs):
+    data = np.load(os.path.join(GOLDEN, "virtual_plant_inputs.npz"))
+    exp = np.load(os.path.join(GOLDEN, "virtual_plant_expected.npz"))
+    shape, origin = exp[f"shape_{tag}"].tolist(), exp[f"origin_{tag}"].tolist()
+    for vpl in (0, 1):
+        got = hip_carve(shape, origin, vs, _vp_views(data, "stem"), views_per_launch=vpl)
+        assert np.array_equal(got, exp[f"carve_stem_{tag}"].astype(np.int32))
+        got = hip_carve(shape, origin, vs, _vp_views(data, "background", True), views_per_launch=vpl)
+        assert np.array_equal(got, exp[f"carve_background_invert_{tag}"].astype(np.int32))
+
+
+def test_virtual_plant_average_golden(gpu_device):
+    data = np.load(os.path.join(GOLDEN, "virtual_plant_inputs.npz"))
+    exp = np.load(os.path.join(GOLDEN, "virtual_plant_expected.npz"))
+    shape, origin = exp["shape_vs10"].tolist(), exp["origin_vs10"].tolist()
+    bp = Backprojection(shape, origin, 1.0, type="averaging", log=False)
+    for K, R, t, m in _vp_views(data, "stem"):
+        bp.process_view(K, R, t, m)  # uint8 in, img_as_float32 inside (cl.py:205-206)
+    assert np.array_equal(bp.get_values(), exp["average_stem_nolog_vs10"])
+
+
+def test_synthetic_golden(gpu_device):
+    exp = np.load(os.path.join(GOLDEN, "synthetic_expected.npz"))
+    for key, n, v, kind in (("plant_32_6", 32, 6, "plant"), ("plant_64_12", 64, 12, "plant"),
+                            ("noise_48_5", 48, 5, "noise"), ("plant_61x45x113_8", (61, 45, 113), 8, "plant")):
+        shape, origin, vs, views = scene(n, v, kind)
+        assert np.array_equal(hip_carve(shape, origin, vs, views), exp[key].astype(np.int32)), key
+
+
+@pytest.mark.parametrize("kind", ["plant", "noise", "solid"])
+def test_cfg1_digests(gpu_device, kind):
+    """BASELINE cfg 1 (128^3 x 12 views): SHA-256 of the int32 grid vs the committed digest."""
+    dig = json.load(open(os.path.join(GOLDEN, "synthetic_digests.json")))[f"{kind}_128_12"]
+    shape, origin, vs, views = scene(128, 12, kind)
+    for vpl in (0, 1):
+        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+        assert histogram3(got) == dig["hist_m1_0_p1"]
+        assert sha256(got) == dig["sha256_int32"]
+
+
+@pytest.mark.parametrize("vpl", [0, 1, 5])
+def test_masks_resident_in_hbm_path(gpu_device, vpl):
+    """sc_process_views_device (bench / Masks2D path): masks already in device memory."""
+    shape, origin, vs, views = scene(64, 12, "plant")
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    V, H, W = stack.shape
+    for _ in range(2):  # second round: clear + same device masks again
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want)
+        e.clear()
+    e.dev_free(ptr)
+    e.close()
+
+
+def test_average_masks_resident_in_hbm(gpu_device):
+    shape, origin, vs, views = scene(24, 5, "noise", width=96, height=80, fx=80.0, fy=80.0, cx=48.0, cy=40.0)
+    rng = np.random.default_rng(9)
+    stack = rng.random((len(views), 80, 96), dtype=np.float32)
+    fviews = [(K, R, t, stack[q]) for q, (K, R, t, _) in enumerate(views)]
+    want = oracle_c.average(shape, origin, vs, fviews)
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE)
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    e.process_views_device(K, R, t, ptr, len(views), 80, 96, nat.SC_MASK_F32)
+    assert np.array_equal(e.get_values(), want)
+    e.dev_free(ptr)
+    e.close()
+
+
+# -- larger sizes: oracle on all host threads, then size-independent properties ----------------
+def test_cfg2_256_cubed_36_views_vs_oracle(gpu_device):
+    shape, origin, vs, views = scene(256, 36, "plant")
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=os.cpu_count() or 8)
+    for vpl in (0, 1):
+        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+        assert np.array_equal(got, want)
+
+
+def test_slabs_concatenate_to_the_whole_grid(gpu_device):
+    """Sharding property: X-slabs computed from GLOBAL indices are bit-identical."""
+    shape, origin, vs, views = scene((50, 24, 36), 5, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    parts = []
+    for i0, i1 in ((0, 13), (13, 14), (14, 50)):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, slab=(i0, i1))
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        parts.append(e.get_values())
+        e.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), want)
+
+
+def test_full_size_512_cubed_72_views_properties(gpu_device):
+    """BASELINE cfg 3 at full size: the oracle would take minutes, so check properties the
+    domain offers: fused == per-view schedule == permuted order (order independence),
+    idempotence (re-applying every view changes nothing) and the closed form on a random
+    voxel sample against the oracle's projection."""
+    shape, origin, vs, views = scene(512, 72, "plant")
+    fused = hip_carve(shape, origin, vs, views, views_per_launch=0)
+    dig = sha256(fused)
+    per_view = hip_carve(shape, origin, vs, views, views_per_launch=1, view_order=0)
+    assert sha256(per_view) == dig
+    del per_view
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(len(views))
+    # idempotence + permutation in one engine
+    bp = Backprojection(shape, origin, vs)
+    for q in perm:
+        bp.process_view(*views[q])
+    bp.synchronize()
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    again = bp.get_values()
+    assert sha256(again) == dig
+    bp.close()
+    # closed form on 20k random voxels via the oracle's projection
+    nsamp = 20000
+    ijk = np.stack([rng.integers(0, s, nsamp) for s in shape], axis=1).astype(np.int32)
+    carved = np.zeros(nsamp, dtype=bool)
+    seen = np.zeros(nsamp, dtype=bool)
+    for K, R, t, m in views:
+        u, v, ok = oracle_c.project(ijk, origin, vs, K, R, t, m.shape[1], m.shape[0])
+        ok = ok.astype(bool)
+        hit = np.zeros(nsamp, dtype=bool)
+        hit[ok] = m[v[ok], u[ok]] != 0
+        carved |= ok & ~hit
+        seen |= ok
+    want = np.where(carved, -1, np.where(seen, 1, 0)).astype(np.int32)
+    assert np.array_equal(fused[ijk[:, 0], ijk[:, 1], ijk[:, 2]], want)
+    h = histogram3(fused)
+    assert h[2] > 0 and h[0] > 100 * h[2]

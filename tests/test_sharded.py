@@ -1,0 +1,103 @@
+"""N>1 path: slab partition + grid assembly.  CPU: world_size-2/3 gloo process groups with
+the oracle standing in for the device (host logic only).  GPU: the same class over the HIP
+engine in one process (world_size 1) -- multi-GPU runs belong to the driver."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle_c
+from plant3dvision_amd.sharded import ShardedBackprojection, slab_bounds
+from tests.helpers import OracleEngine, scene
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_slab_bounds_cover_the_axis_exactly():
+    for nx, w in ((512, 8), (301, 8), (7, 7), (10, 3), (1024, 8)):
+        b = [slab_bounds(nx, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == nx
+        assert all(b[r][1] == b[r + 1][0] for r in range(w - 1))
+        sizes = [i1 - i0 for i0, i1 in b]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    with pytest.raises(ValueError):
+        slab_bounds(3, 4, 0)
+
+
+def _worker(rank, world, port, shape, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, origin, vs, views = scene(tuple(shape), 5, "plant")
+        if mode == "averaging":
+            rng = np.random.default_rng(1)
+            views = [(K, R, t, rng.random(m.shape, dtype=np.float32)) for K, R, t, m in views]
+        sb = ShardedBackprojection(shape, origin, vs, type=mode, engine_factory=OracleEngine)
+        assert (sb.rank, sb.world_size) == (rank, world)
+        for K, R, t, m in views:
+            sb.process_view(K, R, t, m)
+        full_ag = sb.all_gather().numpy()
+        full_ar = sb.all_reduce().numpy()
+        host = sb.gather_to_host(dst=0)
+        res = {"rank": rank, "slab": sb.slab, "ag": full_ag, "ar": full_ar, "host": host}
+        if mode == "carving":
+            res["ag8"] = sb.all_gather(compress=True).numpy()
+        q.put(res)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,mode", [(2, (16, 10, 12), "carving"), (3, (17, 9, 8), "carving"),
+                                              (2, (9, 8, 12), "averaging")])
+def test_gloo_sharded_equals_single(world, shape, mode):
+    _, origin, vs, views = scene(tuple(shape), 5, "plant")
+    if mode == "carving":
+        want = oracle_c.carve(list(shape), origin, vs, views)
+    else:
+        rng = np.random.default_rng(1)
+        fviews = [(K, R, t, rng.random(m.shape, dtype=np.float32)) for K, R, t, m in views]
+        want = oracle_c.average(list(shape), origin, vs, fviews)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, list(shape), mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for res in results:
+        assert np.array_equal(res["ag"], want)
+        assert np.array_equal(res["ar"], want)
+        if mode == "carving":
+            assert np.array_equal(res["ag8"], want)
+        if res["rank"] == 0:
+            assert np.array_equal(res["host"], want)
+        else:
+            assert res["host"] is None
+
+
+@pytest.mark.gpu
+def test_sharded_class_over_hip_engine_single_rank(gpu_device):
+    shape, origin, vs, views = scene((40, 24, 32), 6, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    sb = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, device=0)
+    for K, R, t, m in views:
+        sb.process_view(K, R, t, m)
+    assert np.array_equal(sb.get_local(), want)
+    assert np.array_equal(sb.gather_to_host(), want)
+    # zero-copy view of the engine's device memory through torch (what RCCL would send)
+    assert np.array_equal(sb.all_gather().cpu().numpy(), want)
+    assert np.array_equal(sb.all_reduce().cpu().numpy(), want)
+    sb.close()
