@@ -101,33 +101,37 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world):
 
 def cpu_baseline(shape, origin, vs, views, budget_s):
     """The oracle (a port of the reference kernel, oracle/spacecarve_oracle.c) on this box's
-    host cores, on a bounded sample: a central block of X-planes of the same grid, all views."""
+    host cores, on a bounded sample: a central block of X-planes of the same grid, all views.
+    Threads: the box's CPU share for one GPU (16), or fewer if fewer are available."""
     from oracle import oracle_c
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
     nx, ny, nz = shape
     plane = ny * nz
     V = len(views)
+    masks32 = [np.ascontiguousarray(m, dtype=np.int32) for _, _, _, m in views]  # cl.py:215, untimed
 
     def run(planes):
         i0 = (nx - planes) // 2
         vol = oracle_c.OracleVolume(shape, origin, vs, "carving", 0)
         t0 = time.perf_counter()
-        for K, R, t, m in views:
-            vol.process_view(K, R, t, m, nthreads=cores, begin=i0 * plane, end=(i0 + planes) * plane)
+        for (K, R, t, _), m32 in zip(views, masks32):
+            vol.process_view(K, R, t, m32, nthreads=cores, begin=i0 * plane, end=(i0 + planes) * plane)
         return time.perf_counter() - t0
 
-    probe_planes = max(1, min(nx, 4))
-    t_probe = run(probe_planes)
-    planes = int(max(probe_planes, min(nx, probe_planes * budget_s / max(t_probe, 1e-6))))
-    t = run(planes) if planes > probe_planes else t_probe
+    planes = max(1, min(nx, 8))
+    t = run(planes)
+    while planes < nx and t < budget_s / 3.0:
+        planes = min(nx, max(planes * 2, int(planes * (budget_s * 0.7) / max(t, 1e-3))))
+        t = run(planes)
     vv = planes * plane * V
     return {"value": vv / t / 1e6, "unit": "Mvoxel*views/s", "cores": cores, "kind": "port",
             "sample": f"{planes} central X-planes of the {nx}x{ny}x{nz} grid x {V} views "
-                      f"({vv / 1e6:.0f} Mvoxel*views, {t:.1f} s), oracle/spacecarve_oracle.c, "
-                      f"int32 masks, {cores} threads"}
+                      f"({vv / 1e6:.0f} Mvoxel*views in {t:.1f} s), oracle/spacecarve_oracle.c, "
+                      f"int32 masks as cl.py:215, {cores} threads of {avail} visible"}
 
 
 def main():
