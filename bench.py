@@ -90,8 +90,8 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = {}
-    for name, kid in (("carve", nat.SC_KERNEL_CARVE), ("pack", nat.SC_KERNEL_PACK),
-                      ("fill", nat.SC_KERNEL_FILL)):
+    for name, kid in (("carve", nat.SC_KERNEL_CARVE), ("list", nat.SC_KERNEL_LIST),
+                      ("pack", nat.SC_KERNEL_PACK), ("fill", nat.SC_KERNEL_FILL)):
         n, ms = engine.kernel_stats(kid)
         stats[name] = {"launches": n, "total_ms": ms, "avg_ms": (ms / n if n else 0.0)}
     engine.set_option(nat.SC_OPT_TIME_KERNELS, 0)

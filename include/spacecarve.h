@@ -52,19 +52,23 @@ extern "C" {
 #define SC_OPT_VIEWS_PER_LAUNCH 1 /* 0 (default): defer views, fuse all pending views into one
                                      launch at flush; n>0: launch every n views (1 = one launch
                                      per view, the reference's schedule cl.py:223-226)        */
-#define SC_OPT_VIEW_ORDER 2       /* carve only. 0: as given; 1 (default): stride-interleaved
-                                     order inside a fused launch (legal: the carve state is
+#define SC_OPT_VIEW_ORDER 2       /* carve only. 0: as given; 1 (default): inside a fused launch,
+                                     most-perpendicular-first order (legal: the carve state is
                                      order-independent). average always keeps
                                      the given order (float sum).                             */
 #define SC_OPT_TIME_KERNELS 3     /* 1: bracket every kernel launch with HIP events on the
                                      engine's stream; read with sc_kernel_stats              */
 #define SC_OPT_MAX_PENDING 4      /* deferred views that force a flush (default 256)          */
+#define SC_OPT_COMPACT 5          /* carve only. 1 (default): a fused launch of >= 6 views is dense
+                                     for its first two views, then finishes the survivors from
+                                     compacted lists; 0: every view is applied densely           */
 
 /* kernel ids for sc_kernel_stats */
 #define SC_KERNEL_CARVE 0
 #define SC_KERNEL_AVERAGE 1
 #define SC_KERNEL_PACK 2
 #define SC_KERNEL_FILL 3
+#define SC_KERNEL_LIST 4 /* survivor-list stages + dense resume of a fused carve */
 
 typedef struct sc_engine sc_engine;
 

@@ -15,6 +15,9 @@
 //     launch = the reference's schedule).  The carve update is order-independent, so
 //     dead lanes drop out and a wavefront leaves the view loop as soon as a ballot says
 //     every one of its voxels is carved.
+//   * A fused carve (many views) is dense only for its first two views; the few voxels
+//     still alive are then compacted into survivor lists (wave-aggregated atomics on 256
+//     sharded counters) and finished by a persistent kernel with one lane per survivor.
 //   * Carve masks live in HBM as 1 bit per pixel in 32x32-pixel tiles (one 128-byte line
 //     per tile): the 64..256 z-neighbours a wavefront projects land on a short image
 //     segment of arbitrary orientation, i.e. on a handful of lines, whatever the camera roll.
@@ -30,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -66,16 +70,28 @@ struct GridDesc {
 };
 
 constexpr int kBlock = 256;
-constexpr int kTile = 32;  // mask tile edge in pixels (32 rows x 32 bits = 128 B)
+constexpr int kTile = 32;        // mask tile edge in pixels (32 rows x 32 bits = 128 B)
+constexpr int kSub = 256;        // sharded append counters = sub-lists of a survivor list
+constexpr int kStreamGroups = 4; // 16-byte groups per lane in the per-view streaming kernel
+constexpr int kXcdRun = 16;      // consecutive logical blocks kept on one XCD
 
-// XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
-// each XCD one contiguous eighth of the grid: neighbouring bricks then share mask lines
-// in the same L2.  Speed only; any placement gives the same result.
-__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblocks) {
-    uint32_t full = nblocks & ~7u;
+// Survivor lists of the fused carve (see carve_list_kernel).  Zeroed before every fused launch.
+struct ListCtl {
+    uint32_t count[2][kSub];  // entries appended per sub-list, ping-pong between stages
+    uint32_t overflow;        // a sub-list ran out of room: the dense resume kernel takes over
+    uint32_t pad[3];
+};
+
+// XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
+// kXcdRun consecutive logical blocks (neighbouring columns, which project onto the same mask
+// lines) stay on one XCD's L2, and the runs are dealt round-robin so that every XCD sees the
+// same mix of busy (near the object) and idle regions.  Speed only: any placement gives the
+// same result.
+__device__ __forceinline__ uint32_t spread_block(uint32_t bid, uint32_t nblocks) {
+    uint32_t full = nblocks - nblocks % (8u * kXcdRun);
     if (bid >= full) return bid;
-    uint32_t cpx = full >> 3;
-    return (bid & 7u) * cpx + (bid >> 3);
+    uint32_t xcd = bid & 7u, seq = bid >> 3;
+    return ((seq / kXcdRun) * 8u + xcd) * kXcdRun + (seq % kXcdRun);
 }
 
 // backproject_point (backprojection.c:3-34) with the x/y partial sums hoisted.
@@ -97,17 +113,19 @@ __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
     return ok;
 }
 
-struct Lane {
-    uint64_t elem;   // offset of the lane's first voxel in the slab state
+__device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
+    return ((uint32_t)(v >> 5) * (uint32_t)tiles_x + (uint32_t)(u >> 5)) * 32u + (uint32_t)(v & 31);
+}
+
+struct Vox4 {
+    uint64_t elem;   // offset of the group's first voxel in the slab state
     uint32_t k0;     // z index of that voxel
     uint32_t nvalid; // 1..4 voxels of this group that exist (nz tail)
     float x, y;
 };
 
-__device__ __forceinline__ bool lane_setup(const GridDesc &g, Lane &ln) {
-    uint32_t nblocks = gridDim.x;
-    uint64_t grp = (uint64_t)xcd_swizzle(blockIdx.x, nblocks) * kBlock + threadIdx.x;
-    if (grp >= g.ngroups) return false;
+// group index -> column and z run (common.h:6-8: z fastest), voxel centre x, y
+__device__ __forceinline__ void decode_group(const GridDesc &g, uint64_t grp, Vox4 &vx) {
     uint32_t col, kq;
     if (g.ngroups <= 0xffffffffull) {
         uint32_t g32 = (uint32_t)grp;
@@ -117,71 +135,86 @@ __device__ __forceinline__ bool lane_setup(const GridDesc &g, Lane &ln) {
         col = (uint32_t)(grp / g.gpc);
         kq = (uint32_t)(grp - (uint64_t)col * g.gpc);
     }
-    uint32_t il = col / g.ny;  // common.h:6-8, z fastest
+    uint32_t il = col / g.ny;
     uint32_t j = col - il * g.ny;
-    ln.k0 = kq * 4u;
-    ln.nvalid = min(4u, g.nz - ln.k0);
-    ln.elem = (uint64_t)col * g.nz + ln.k0;
+    vx.k0 = kq * 4u;
+    vx.nvalid = min(4u, g.nz - vx.k0);
+    vx.elem = (uint64_t)col * g.nz + vx.k0;
     // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index
-    ln.x = g.ox + (float)(int)(il + g.i0) * g.vs;
-    ln.y = g.oy + (float)(int)j * g.vs;
-    return true;
+    vx.x = g.ox + (float)(int)(il + g.i0) * g.vs;
+    vx.y = g.oy + (float)(int)j * g.vs;
 }
 
-// carve (backprojection.c:57-84) over views[0..nviews) with the state in registers.
-// FRESH: the state is known to be `init` everywhere (nothing has been applied since
-// create/clear), so it is not read.  VEC: nz % 4 == 0, state accessed as int4.
+// Where a fused launch appends the voxels that are still alive after its dense views.
+struct Append {
+    uint32_t *list;   // nullptr: no append
+    ListCtl *ctl;
+    uint32_t subcap;  // entries per sub-list
+    uint32_t sub;     // sub-list of this block
+};
+
+// carve (backprojection.c:57-84) of one 4-voxel group over views[0..nviews), state in
+// registers.  FRESH: the state is known to be `init` everywhere (nothing applied since
+// create/clear) and is not read.  VEC: nz % 4 == 0, state accessed as int4 (`pre` holds the
+// group's state, already loaded by the caller so that loads of several groups overlap).
 template <bool FRESH, bool VEC>
-__device__ __forceinline__ void carve_body(int32_t *__restrict__ labels, const GridDesc &g,
-                                           const ViewDesc *__restrict__ views, int nviews,
-                                           int32_t init) {
-    Lane ln;
-    if (!lane_setup(g, ln)) return;
+__device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const GridDesc &g,
+                                            const ViewDesc *__restrict__ views, int nviews,
+                                            int32_t init, uint64_t grp, int4 pre,
+                                            const Append &ap) {
+    Vox4 vx;
     int32_t lab[4], was[4];
-    int32_t *p = labels + ln.elem;
+    if (!VEC) decode_group(g, grp, vx);  // the address needs the column
+    int32_t *p = labels + (VEC ? grp * 4 : vx.elem);
     if (FRESH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) lab[e] = init;
     } else if (VEC) {
-        int4 q = *reinterpret_cast<const int4 *>(p);
-        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+        lab[0] = pre.x; lab[1] = pre.y; lab[2] = pre.z; lab[3] = pre.w;
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lab[e] = (e < (int)ln.nvalid) ? p[e] : -1;
+        for (int e = 0; e < 4; ++e) lab[e] = (e < (int)vx.nvalid) ? p[e] : -1;
     }
     uint32_t alive = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         was[e] = lab[e];
-        if (e < (int)ln.nvalid && lab[e] != -1) alive |= 1u << e;  // :67
+        if ((VEC || e < (int)vx.nvalid) && lab[e] != -1) alive |= 1u << e;  // :67
     }
     if (!FRESH && alive == 0) return;  // nothing to do and nothing to write
+    if (VEC) decode_group(g, grp, vx);
 
     float z[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(ln.k0 + e) * g.vs;  // :73
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(vx.k0 + e) * g.vs;  // :73
 
     for (int vi = 0; vi < nviews; ++vi) {
         if (__ballot(alive != 0) == 0) break;  // whole wavefront carved
-        const ViewDesc d = views[vi];  // wave-uniform: scalar loads, once per view
-        float ax = d.R[0] * ln.x + d.R[1] * ln.y;
-        float ay = d.R[3] * ln.x + d.R[4] * ln.y;
-        float az = d.R[6] * ln.x + d.R[7] * ln.y;
+        const ViewDesc d = views[vi];          // wave-uniform: scalar loads, once per view
+        float ax = d.R[0] * vx.x + d.R[1] * vx.y;
+        float ay = d.R[3] * vx.x + d.R[4] * vx.y;
+        float az = d.R[6] * vx.x + d.R[7] * vx.y;
         const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
+        bool ok[4];
+        uint32_t w[4];
+        int sh[4];
+        // all four projections first, then the four gathers in flight together
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (alive & (1u << e)) {
-                int u, v;
-                if (project(ax, ay, az, z[e], d, u, v)) {
-                    uint32_t word = ((uint32_t)(v >> 5) * (uint32_t)d.tiles_x + (uint32_t)(u >> 5)) * 32u +
-                                    (uint32_t)(v & 31);
-                    uint32_t w = bits[word];
-                    if (((w >> (u & 31)) & 1u) == 0) {  // :79
-                        lab[e] = -1;
-                        alive &= ~(1u << e);
-                    } else if (lab[e] == 0) {  // :81
-                        lab[e] = 1;
-                    }
+            int u, v;
+            ok[e] = project(ax, ay, az, z[e], d, u, v) & ((alive >> e) & 1u);
+            sh[e] = u & 31;
+            w[e] = 0;
+            if (ok[e]) w[e] = bits[mask_word_index(u, v, d.tiles_x)];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ok[e]) {
+                if (((w[e] >> sh[e]) & 1u) == 0) {  // :79
+                    lab[e] = -1;
+                    alive &= ~(1u << e);
+                } else if (lab[e] == 0) {  // :81
+                    lab[e] = 1;
                 }
             }
         }
@@ -194,24 +227,191 @@ __device__ __forceinline__ void carve_body(int32_t *__restrict__ labels, const G
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (e < (int)ln.nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
+            if (e < (int)vx.nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
+    }
+
+    if (ap.list != nullptr) {
+        // survivors -> sub-list `ap.sub`: one atomic per wavefront, entries = slab-local voxel
+        // index, bit 31 = "label is still 0" (a later foreground hit must write 1)
+        unsigned long long b[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = __ballot((alive >> e) & 1u);
+            total += (uint32_t)__popcll(b[e]);
+        }
+        if (total != 0) {  // wave-uniform
+            unsigned long long act = __ballot(1);
+            uint32_t lane = __lane_id();
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)act) - 1))
+                base = atomicAdd(&ap.ctl->count[0][ap.sub], total);
+            base = __shfl(base, __ffsll((long long)act) - 1);
+            if (base + total > ap.subcap) {
+                if (lane == (uint32_t)(__ffsll((long long)act) - 1)) ap.ctl->overflow = 1u;
+            } else {
+                uint32_t *dst = ap.list + (size_t)ap.sub * ap.subcap + base;
+                unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                uint32_t off = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((alive >> e) & 1u) {
+                        uint32_t rank = off + (uint32_t)__popcll(b[e] & below);
+                        dst[rank] = (uint32_t)(vx.elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
+                    }
+                    off += (uint32_t)__popcll(b[e]);
+                }
+            }
+        }
     }
 }
 
-// Many views per launch: descriptors in device memory.
+// A chunk of views per launch: one group per lane; optionally appends the survivors.
 template <bool FRESH, bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                        const ViewDesc *__restrict__ views,
-                                                       int nviews, int32_t init) {
-    carve_body<FRESH, VEC>(labels, g, views, nviews, init);
+                                                       int nviews, int32_t init, Append ap) {
+    uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    uint64_t grp = (uint64_t)lb * kBlock + threadIdx.x;
+    if (grp >= g.ngroups) return;
+    int4 pre = make_int4(0, 0, 0, 0);
+    if (!FRESH && VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
+    ap.sub = lb % kSub;
+    carve_group<FRESH, VEC>(labels, g, views, nviews, init, grp, pre, ap);
 }
 
 // One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
-// the kernel arguments, so a launch needs no copy and no host-side wait.
+// the kernel arguments (no copy, no host-side wait), and each lane walks kStreamGroups
+// 16-byte groups with the next group's state load already in flight -- after the first view
+// nearly every wavefront only streams its state through and leaves.
 template <bool FRESH, bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ labels, GridDesc g,
                                                          ViewDesc view, int32_t init) {
-    carve_body<FRESH, VEC>(labels, g, &view, 1, init);
+    constexpr int G = (!FRESH && VEC) ? kStreamGroups : 1;
+    uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    uint64_t grp = (uint64_t)lb * (kBlock * G) + threadIdx.x;
+    Append none{nullptr, nullptr, 0u, 0u};
+    int4 cur = make_int4(-1, -1, -1, -1);
+    if (G > 1 && grp < g.ngroups) cur = *reinterpret_cast<const int4 *>(labels + grp * 4);
+#pragma unroll 1
+    for (int s = 0; s < G; ++s, grp += kBlock) {
+        int4 nxt = make_int4(-1, -1, -1, -1);
+        if (G > 1 && s + 1 < G && grp + kBlock < g.ngroups)
+            nxt = *reinterpret_cast<const int4 *>(labels + (grp + kBlock) * 4);
+        if (grp < g.ngroups) carve_group<FRESH, VEC>(labels, g, &view, 1, init, grp, cur, none);
+        cur = nxt;
+    }
+}
+
+// Fused carve, sparse phase: one lane per SURVIVOR.  Reads the survivor sub-lists a previous
+// stage appended, applies views[0..nviews) with every lane busy, writes the labels that
+// change straight into the grid (carved -> -1 at once, 0 -> 1 at the end) and, when `lout`
+// is given, appends what is still alive for the next stage.  A persistent grid walks the
+// (sub-list, 256-entry chunk) items; the counts live in device memory, so the host never
+// waits to learn how many survivors there are.
+__global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                            const ViewDesc *__restrict__ views,
+                                                            int nviews,
+                                                            const uint32_t *__restrict__ lin,
+                                                            uint32_t *__restrict__ lout,
+                                                            ListCtl *ctl, int sin, uint32_t subcap) {
+    __shared__ uint32_t pref[kSub + 1];
+    if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
+    const uint32_t tid = threadIdx.x;
+    {
+        uint32_t c = (min(ctl->count[sin][tid], subcap) + (kBlock - 1)) / kBlock;  // kSub == kBlock
+        if (tid == 0) pref[0] = 0;
+        pref[tid + 1] = c;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            uint32_t val = pref[tid + 1];
+            uint32_t add = (tid >= off) ? pref[tid + 1 - off] : 0u;
+            __syncthreads();
+            pref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
+    const uint32_t items = pref[kSub];
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= item (block-uniform)
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (pref[mid] <= item) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo;
+        const uint32_t e = (item - pref[s]) * kBlock + tid;
+        const uint32_t cnt = min(ctl->count[sin][s], subcap);
+        if (e < cnt) {
+            uint32_t entry = lin[(size_t)s * subcap + e];
+            uint32_t idx = entry & 0x7fffffffu;
+            bool zero = (entry >> 31) != 0;  // label is still 0
+            bool flipped = false, alive = true;
+            uint32_t col = idx / g.nz;
+            uint32_t k = idx - col * g.nz;
+            uint32_t il = col / g.ny;
+            uint32_t j = col - il * g.ny;
+            float x = g.ox + (float)(int)(il + g.i0) * g.vs;  // backprojection.c:71-73
+            float y = g.oy + (float)(int)j * g.vs;
+            float z = g.oz + (float)(int)k * g.vs;
+            for (int vi = 0; vi < nviews; ++vi) {
+                if (__ballot(alive) == 0) break;
+                const ViewDesc d = views[vi];
+                float ax = d.R[0] * x + d.R[1] * y;
+                float ay = d.R[3] * x + d.R[4] * y;
+                float az = d.R[6] * x + d.R[7] * y;
+                int u, v;
+                bool ok = project(ax, ay, az, z, d, u, v) & alive;
+                if (ok) {
+                    uint32_t w = static_cast<const uint32_t *>(d.mask)[mask_word_index(u, v, d.tiles_x)];
+                    if (((w >> (u & 31)) & 1u) == 0) {  // :79
+                        alive = false;
+                        labels[idx] = -1;
+                    } else if (zero) {  // :81
+                        zero = false;
+                        flipped = true;
+                    }
+                }
+            }
+            if (alive && flipped) labels[idx] = 1;
+            if (lout != nullptr) {
+                unsigned long long b = __ballot(alive);
+                if (b != 0) {
+                    unsigned long long act = __ballot(1);
+                    int leader = __ffsll((long long)act) - 1;
+                    uint32_t lane = __lane_id();
+                    uint32_t base = 0;
+                    if ((int)lane == leader)
+                        base = atomicAdd(&ctl->count[sin ^ 1][s], (uint32_t)__popcll(b));
+                    base = __shfl(base, leader);
+                    // survivors of sub-list s never outnumber its entries: no overflow here
+                    if (alive) {
+                        unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                        lout[(size_t)s * subcap + base + (uint32_t)__popcll(b & below)] =
+                            idx | (zero ? 0x80000000u : 0u);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
+// nothing), a persistent grid applies the remaining views densely instead.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                              const ViewDesc *__restrict__ views,
+                                                              int nviews, const ListCtl *ctl) {
+    if (!ctl->overflow) return;
+    Append none{nullptr, nullptr, 0u, 0u};
+    uint64_t nblk = (g.ngroups + kBlock - 1) / kBlock;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        uint64_t grp = blk * kBlock + threadIdx.x;
+        if (grp < g.ngroups) {
+            int4 pre = make_int4(0, 0, 0, 0);
+            if (VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
+            carve_group<false, VEC>(labels, g, views, nviews, 0, grp, pre, none);
+        }
+    }
 }
 
 // average (backprojection.c:36-55): value += mask[v][u] for every in-image view, in the
@@ -220,10 +420,13 @@ template <bool FRESH, bool VEC>
 __device__ __forceinline__ void average_body(float *__restrict__ values, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              float init) {
-    Lane ln;
-    if (!lane_setup(g, ln)) return;
+    uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    uint64_t grp = (uint64_t)lb * kBlock + threadIdx.x;
+    if (grp >= g.ngroups) return;
+    Vox4 vx;
+    decode_group(g, grp, vx);
     float val[4];
-    float *p = values + ln.elem;
+    float *p = values + vx.elem;
     if (FRESH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] = init;
@@ -232,32 +435,37 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
         val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = (e < (int)ln.nvalid) ? p[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) val[e] = (e < (int)vx.nvalid) ? p[e] : 0.0f;
     }
     float z[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(ln.k0 + e) * g.vs;
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(vx.k0 + e) * g.vs;
 
     for (int vi = 0; vi < nviews; ++vi) {
-        const ViewDesc d = views[vi];  // wave-uniform: scalar loads, once per view
-        float ax = d.R[0] * ln.x + d.R[1] * ln.y;
-        float ay = d.R[3] * ln.x + d.R[4] * ln.y;
-        float az = d.R[6] * ln.x + d.R[7] * ln.y;
+        const ViewDesc d = views[vi];
+        float ax = d.R[0] * vx.x + d.R[1] * vx.y;
+        float ay = d.R[3] * vx.x + d.R[4] * vx.y;
+        float az = d.R[6] * vx.x + d.R[7] * vx.y;
         const float *m = static_cast<const float *>(d.mask);
+        bool ok[4];
+        float add[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int u, v;
-            if (e < (int)ln.nvalid && project(ax, ay, az, z[e], d, u, v)) {
-                val[e] = val[e] + m[(int64_t)v * d.W + u];  // :54, nearest texel
-            }
+            ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
+            add[e] = 0.0f;
+            if (ok[e]) add[e] = m[(int64_t)v * d.W + u];  // nearest texel
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ok[e]) val[e] = val[e] + add[e];  // :54
     }
     if (VEC) {
         *reinterpret_cast<float4 *>(p) = make_float4(val[0], val[1], val[2], val[3]);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (e < (int)ln.nvalid) p[e] = val[e];
+            if (e < (int)vx.nvalid) p[e] = val[e];
     }
 }
 
@@ -284,9 +492,9 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst
     }
 }
 
-// Mask ingest: raw [V][H][W] pixels (u8 or i32) -> 1 bit/pixel (pixel != 0, the test at
-// backprojection.c:79 on the cast of cl.py:215), in 32x32 tiles.  One wavefront votes 64
-// consecutive pixels of a row with a ballot and writes the two 32-bit tile words.
+// Mask ingest, general form: raw [V][H][W] pixels (u8 or i32) -> 1 bit/pixel (pixel != 0, the
+// test at backprojection.c:79 on the cast of cl.py:215), in 32x32 tiles.  One wavefront votes
+// 64 consecutive pixels of a row with a ballot and writes the two 32-bit tile words.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
                                                       int64_t row_stride, int64_t view_stride,
@@ -316,6 +524,47 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
         o[(base + seg * 2) * 32u + rowin] = (uint32_t)vote;
     } else if (lane == 32 && seg * 2 + 1 < tiles_x) {
         o[(base + seg * 2 + 1) * 32u + rowin] = (uint32_t)(vote >> 32);
+    }
+}
+
+// Mask ingest, fast form for uint8 masks whose rows are 16-byte aligned multiples of 16 px:
+// a wavefront makes ONE 32x32 tile.  Lane l (< 32) loads the left 16 pixels of tile row l,
+// lane 32+l the right 16; 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per
+// dword), the halves meet through one shuffle, and lanes 0..31 store the tile's 32 words as
+// one 128-byte line.  The four wavefronts of a block take four adjacent tiles, so the block
+// reads whole 128-byte lines of every pixel row.
+__device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
+    uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
+    return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
+}
+
+__global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restrict__ raw,
+                                                        int64_t row_stride, int64_t view_stride,
+                                                        int W, int H, int nviews, int tiles_x,
+                                                        int tiles_y, uint32_t *__restrict__ out,
+                                                        int64_t out_view_words) {
+    const int lane = threadIdx.x & 63;
+    const int txb = (tiles_x + 3) >> 2;  // blocks per tile row
+    int64_t b = blockIdx.x;
+    int bx = (int)(b % txb);
+    int64_t r = b / txb;
+    int ty = (int)(r % tiles_y);
+    int view = (int)(r / tiles_y);
+    if (view >= nviews) return;
+    int tx = bx * 4 + (threadIdx.x >> 6);
+    if (tx >= tiles_x) return;  // whole wavefront
+    int v = ty * 32 + (lane & 31);
+    int u0 = tx * 32 + (lane >> 5) * 16;
+    uint32_t half = 0;
+    if (v < H && u0 < W) {  // W % 16 == 0: a 16-pixel run is inside the row or outside it
+        const uint4 q = *reinterpret_cast<const uint4 *>(raw + view * view_stride + (int64_t)v * row_stride + u0);
+        half = nonzero_nibble(q.x) | (nonzero_nibble(q.y) << 4) | (nonzero_nibble(q.z) << 8) |
+               (nonzero_nibble(q.w) << 12);
+    }
+    uint32_t other = __shfl_xor(half, 32);
+    if (lane < 32) {
+        uint32_t word = half | (other << 16);
+        out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + lane] = word;
     }
 }
 
@@ -354,7 +603,7 @@ struct TimedLaunch {
 };
 
 constexpr int kSlots = 4;
-constexpr int kNumKernels = 4;
+constexpr int kNumKernels = 5;
 
 }  // namespace
 
@@ -379,6 +628,11 @@ struct sc_engine {
     // mask storage for pending views
     std::vector<Chunk> chunks;
 
+    // survivor lists of the fused carve
+    uint32_t *lists = nullptr;  // 2 x (kSub * subcap) entries
+    ListCtl *ctl = nullptr;
+    uint32_t subcap = 0;
+
     // host-mask staging ring
     void *pin[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     void *raw[kSlots] = {nullptr, nullptr, nullptr, nullptr};
@@ -392,6 +646,7 @@ struct sc_engine {
     int64_t view_order = 1;
     int64_t time_kernels = 0;
     int64_t max_pending = 256;
+    int64_t compact = 1;
 
     std::vector<TimedLaunch> timed[kNumKernels];
     std::vector<hipEvent_t> event_pool;
@@ -556,22 +811,36 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     void *packed = nullptr;
     int rc = arena_alloc(e, words * 4 * (size_t)V, &packed);
     if (rc) return rc;
-    int tiles_x = (W + kTile - 1) / kTile;
-    int segs = (W + 63) / 64;
-    int64_t waves = (int64_t)V * H * segs;
-    int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
-    if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+    int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     LaunchTimer lt{e, SC_KERNEL_PACK};
-    rc = lt.begin();
-    if (rc) return rc;
-    if (dtype == SC_MASK_U8) {
-        hipLaunchKernelGGL(pack_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+    bool fast = dtype == SC_MASK_U8 && (W % 16) == 0 && (row_stride % 16) == 0 &&
+                (view_stride % 16) == 0 && (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
+    if (fast) {
+        int64_t blocks = (int64_t)V * tiles_y * ((tiles_x + 3) / 4);
+        if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+        rc = lt.begin();
+        if (rc) return rc;
+        hipLaunchKernelGGL(pack16_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
                            static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,
-                           tiles_x, static_cast<uint32_t *>(packed), (int64_t)words);
+                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words);
     } else {
-        hipLaunchKernelGGL(pack_kernel<int32_t>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
-                           static_cast<const int32_t *>(raw_dev), row_stride, view_stride, W, H, V,
-                           tiles_x, static_cast<uint32_t *>(packed), (int64_t)words);
+        int segs = (W + 63) / 64;
+        int64_t waves = (int64_t)V * H * segs;
+        int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+        if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+        rc = lt.begin();
+        if (rc) return rc;
+        if (dtype == SC_MASK_U8) {
+            hipLaunchKernelGGL(pack_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
+                               e->stream, static_cast<const uint8_t *>(raw_dev), row_stride,
+                               view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
+                               (int64_t)words);
+        } else {
+            hipLaunchKernelGGL(pack_kernel<int32_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
+                               e->stream, static_cast<const int32_t *>(raw_dev), row_stride,
+                               view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
+                               (int64_t)words);
+        }
     }
     HIP_TRY(hipGetLastError());
     rc = lt.end();
@@ -585,24 +854,48 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     return SC_OK;
 }
 
-// stride-interleaved order: widely separated views first, so most voxels are carved
-// within the first few views of a fused launch
-void interleave(std::vector<ViewDesc> &v) {
+// Order of the views inside a fused carve launch: greedily pick the view whose optical axis
+// (third row of R) is most perpendicular to every axis already chosen (|cos| ignores the
+// sign: opposite cameras see mirrored silhouettes).  Perpendicular silhouettes intersect in the
+// smallest volume, so almost everything is carved by the first two views.  Legal because the
+// carve state is order-independent; `average` never re-orders.
+void order_views(std::vector<ViewDesc> &v) {
     size_t n = v.size();
-    if (n < 3) return;
-    int bits = 0;
-    while (((size_t)1 << bits) < n) ++bits;
-    std::vector<std::pair<uint32_t, uint32_t>> key(n);
-    for (size_t q = 0; q < n; ++q) {
-        uint32_t r = 0;
-        for (int b = 0; b < bits; ++b)
-            if (q & ((size_t)1 << b)) r |= 1u << (bits - 1 - b);
-        key[q] = {r, (uint32_t)q};
+    if (n < 3 || n > 4096) return;
+    std::vector<float> worst(n, 0.0f);
+    std::vector<char> used(n, 0);
+    std::vector<ViewDesc> out;
+    out.reserve(n);
+    size_t cur = 0;
+    for (size_t step = 0; step < n; ++step) {
+        used[cur] = 1;
+        out.push_back(v[cur]);
+        const float *a = v[cur].R + 6;
+        size_t best = n;
+        for (size_t q = 0; q < n; ++q) {
+            if (used[q]) continue;
+            const float *b = v[q].R + 6;
+            float c = std::fabs(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+            if (c > worst[q]) worst[q] = c;
+            if (best == n || worst[q] < worst[best]) best = q;
+        }
+        cur = best;
     }
-    std::sort(key.begin(), key.end());
-    std::vector<ViewDesc> out(n);
-    for (size_t q = 0; q < n; ++q) out[q] = v[key[q].second];
     v.swap(out);
+}
+
+constexpr int kDenseViews = 2;     // views applied to every voxel before compaction
+constexpr int kStage1Views = 8;    // views applied to the first survivor list
+constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
+constexpr uint32_t kListBlocks = 2048;  // persistent grid of the list / resume kernels
+
+int ensure_lists(sc_engine *e) {
+    if (e->lists) return SC_OK;
+    uint64_t total = std::max<uint64_t>((uint64_t)e->n / 8, (uint64_t)kSub * 1024);
+    e->subcap = (uint32_t)((total + kSub - 1) / kSub);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lists), (size_t)2 * kSub * e->subcap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->ctl), sizeof(ListCtl)));
+    return SC_OK;
 }
 
 // Launch the first `count` pending views (count == 0: all of them).
@@ -617,7 +910,7 @@ int flush(sc_engine *e, size_t count = 0) {
     const ViewDesc *vd = nullptr;
     if (nv > 1) {
         if (e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
-            interleave(e->pending);
+            order_views(e->pending);
         // descriptor ring: slots are reused only after a wrap, which waits for the stream
         if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
             HIP_TRY(hipStreamSynchronize(e->stream));
@@ -641,29 +934,81 @@ int flush(sc_engine *e, size_t count = 0) {
         vd = dev;
     }
     const ViewDesc &one = e->pending[0];
-    LaunchTimer lt{e, e->mode == SC_MODE_CARVE ? SC_KERNEL_CARVE : SC_KERNEL_AVERAGE};
-    int rc = lt.begin();
-    if (rc) return rc;
+    int rc;
     if (e->mode == SC_MODE_CARVE) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
-#define LAUNCH_CARVE(F, V)                                                                       \
-    do {                                                                                         \
-        if (nv == 1)                                                                             \
-            hipLaunchKernelGGL((carve_kernel_1<F, V>), grid, block, 0, e->stream, st, g, one,    \
-                               init);                                                            \
-        else                                                                                     \
-            hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd,       \
-                               (int)nv, init);                                                   \
-    } while (0)
-        if (e->fresh) {
-            if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
-        } else {
-            if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
+        // fused carve with survivor compaction: dense for kDenseViews, then lists
+        bool compact = e->compact && nv >= (size_t)kMinFusedViews && (uint64_t)e->n < 0x80000000ull;
+        Append ap{nullptr, nullptr, 0u, 0u};
+        int dense_views = (int)nv;
+        if (compact) {
+            rc = ensure_lists(e);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
+            ap.list = e->lists;
+            ap.ctl = e->ctl;
+            ap.subcap = e->subcap;
+            dense_views = kDenseViews;
         }
+        LaunchTimer lt{e, SC_KERNEL_CARVE};
+        rc = lt.begin();
+        if (rc) return rc;
+        if (nv == 1) {
+            // kStreamGroups groups per lane when the state is streamed through (see kernel)
+            uint32_t per_block = (!e->fresh && vec) ? kBlock * kStreamGroups : kBlock;
+            dim3 grid1((uint32_t)((g.ngroups + per_block - 1) / per_block));
+#define LAUNCH_CARVE1(F, V) \
+    hipLaunchKernelGGL((carve_kernel_1<F, V>), grid1, block, 0, e->stream, st, g, one, init)
+            if (e->fresh) {
+                if (vec) LAUNCH_CARVE1(true, true); else LAUNCH_CARVE1(true, false);
+            } else {
+                if (vec) LAUNCH_CARVE1(false, true); else LAUNCH_CARVE1(false, false);
+            }
+#undef LAUNCH_CARVE1
+        } else {
+#define LAUNCH_CARVE(F, V)                                                                    \
+    hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
+                       init, ap)
+            if (e->fresh) {
+                if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
+            } else {
+                if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
+            }
 #undef LAUNCH_CARVE
+        }
+        HIP_TRY(hipGetLastError());
+        rc = lt.end();
+        if (rc) return rc;
+        if (compact) {
+            int s1 = (int)std::min<size_t>(nv, (size_t)kDenseViews + kStage1Views);
+            uint32_t *l0 = e->lists, *l1 = e->lists + (size_t)kSub * e->subcap;
+            LaunchTimer lt2{e, SC_KERNEL_LIST};
+            rc = lt2.begin();
+            if (rc) return rc;
+            bool two = (size_t)s1 < nv;
+            hipLaunchKernelGGL(carve_list_kernel, dim3(kListBlocks), block, 0, e->stream, st, g,
+                               vd + kDenseViews, s1 - kDenseViews, l0, two ? l1 : nullptr, e->ctl, 0,
+                               e->subcap);
+            if (two)
+                hipLaunchKernelGGL(carve_list_kernel, dim3(kListBlocks), block, 0, e->stream, st, g,
+                                   vd + s1, (int)nv - s1, l1, static_cast<uint32_t *>(nullptr), e->ctl,
+                                   1, e->subcap);
+            if (vec)
+                hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(kListBlocks), block, 0, e->stream,
+                                   st, g, vd + kDenseViews, (int)nv - kDenseViews, e->ctl);
+            else
+                hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(kListBlocks), block, 0, e->stream,
+                                   st, g, vd + kDenseViews, (int)nv - kDenseViews, e->ctl);
+            HIP_TRY(hipGetLastError());
+            rc = lt2.end();
+            if (rc) return rc;
+        }
     } else {
         float *st = static_cast<float *>(e->state);
+        LaunchTimer lt{e, SC_KERNEL_AVERAGE};
+        rc = lt.begin();
+        if (rc) return rc;
 #define LAUNCH_AVG(F, V)                                                                         \
     do {                                                                                         \
         if (nv == 1)                                                                             \
@@ -679,10 +1024,10 @@ int flush(sc_engine *e, size_t count = 0) {
             if (vec) LAUNCH_AVG(false, true); else LAUNCH_AVG(false, false);
         }
 #undef LAUNCH_AVG
+        HIP_TRY(hipGetLastError());
+        rc = lt.end();
+        if (rc) return rc;
     }
-    HIP_TRY(hipGetLastError());
-    rc = lt.end();
-    if (rc) return rc;
     e->fresh = false;
     e->pending.erase(e->pending.begin(), e->pending.begin() + (ptrdiff_t)nv);
     if (e->pending.empty()) arena_reset(e);  // masks of launched views are dead in stream order
@@ -811,6 +1156,8 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->lists) (void)hipFree(e->lists);
+    if (e->ctl) (void)hipFree(e->ctl);
     if (e->state) (void)hipFree(e->state);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -839,6 +1186,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_TIME_KERNELS:
             e->time_kernels = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_COMPACT:
+            e->compact = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_MAX_PENDING:
             if (value < 1) return fail(SC_ERR_INVALID, "max_pending must be >= 1");

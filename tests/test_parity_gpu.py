@@ -18,10 +18,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def hip_carve(shape, origin, vs, views, default_value=0, views_per_launch=0, device=0,
-              view_order=1):
+              view_order=1, compact=1):
     bp = Backprojection(shape, origin, vs, default_value=default_value, device=device,
                         views_per_launch=views_per_launch)
     bp._engine.set_option(nat.SC_OPT_VIEW_ORDER, view_order)
+    bp._engine.set_option(nat.SC_OPT_COMPACT, compact)
     for K, R, t, m in views:
         bp.process_view(K, R, t, m)
     out = bp.get_values().copy()
@@ -56,22 +57,59 @@ def test_ctor_like_reference_unit_test(gpu_device):
 @pytest.mark.parametrize("n,v,kind", [(32, 6, "plant"), (48, 5, "noise"), ((20, 31, 18), 6, "plant"),
                                       ((7, 5, 3), 4, "plant"), ((9, 9, 1), 3, "noise"),
                                       ((61, 45, 113), 8, "plant"), (16, 3, "solid"), (16, 3, "empty")])
-@pytest.mark.parametrize("vpl", [0, 1, 3])
-def test_carve_matches_oracle(gpu_device, n, v, kind, vpl):
-    """vpl = views per launch: 0 fused, 1 the reference's one-launch-per-view, 3 chunks."""
+@pytest.mark.parametrize("vpl,compact", [(0, 1), (0, 0), (1, 1), (3, 1)])
+def test_carve_matches_oracle(gpu_device, n, v, kind, vpl, compact):
+    """vpl = views per launch: 0 fused (with / without survivor compaction), 1 the
+    reference's one-launch-per-view, 3 chunks."""
     shape, origin, vs, views = scene(n, v, kind)
     want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
-    got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+    got = hip_carve(shape, origin, vs, views, views_per_launch=vpl, compact=compact)
     assert got.dtype == np.int32
     assert np.array_equal(got, want), histogram3(got)
 
 
-def test_carve_given_order_equals_interleaved_order(gpu_device):
+def test_carve_given_order_equals_perpendicular_first_order(gpu_device):
     shape, origin, vs, views = scene(40, 9, "plant")
-    a = hip_carve(shape, origin, vs, views, view_order=0)
-    b = hip_carve(shape, origin, vs, views, view_order=1)
-    assert np.array_equal(a, b)
-    assert np.array_equal(a, oracle_c.carve(shape, origin, vs, views))
+    want = oracle_c.carve(shape, origin, vs, views)
+    for order in (0, 1):
+        for compact in (0, 1):
+            assert np.array_equal(hip_carve(shape, origin, vs, views, view_order=order, compact=compact), want)
+
+
+@pytest.mark.parametrize("kind,n,v", [("solid", 40, 12), ("noise", 40, 12), ("solid", (33, 20, 30), 9)])
+def test_survivor_list_overflow_falls_back_to_dense_resume(gpu_device, kind, n, v):
+    """Masks that carve little overflow the survivor sub-lists (capacity N/8): the dense
+    resume kernel must finish the remaining views with the same result."""
+    shape, origin, vs, views = scene(n, v, kind)
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
+    assert np.array_equal(hip_carve(shape, origin, vs, views, compact=1), want)
+    assert np.array_equal(hip_carve(shape, origin, vs, views, compact=0), want)
+
+
+def test_fused_compaction_with_slab_and_default_values(gpu_device):
+    shape, origin, vs, views = scene((40, 28, 36), 14, "plant")
+    for dv in (0, 3):
+        want = oracle_c.carve(shape, origin, vs, views, dv, nthreads=4)
+        parts = []
+        for i0, i1 in ((0, 17), (17, 40)):
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=dv, slab=(i0, i1))
+            for K, R, t, m in views:
+                e.process_view(K, R, t, m, nat.SC_MASK_U8)
+            parts.append(e.get_values())
+            e.close()
+        assert np.array_equal(np.concatenate(parts, axis=0), want)
+
+
+def test_fused_on_non_fresh_state(gpu_device):
+    """Second fused launch starts from stored labels (non-FRESH dense stage + lists)."""
+    shape, origin, vs, views = scene(48, 16, "plant")
+    bp = Backprojection(shape, origin, vs)
+    for K, R, t, m in views[:8]:
+        bp.process_view(K, R, t, m)
+    bp.synchronize()
+    for K, R, t, m in views[8:]:
+        bp.process_view(K, R, t, m)
+    assert np.array_equal(bp.get_values(), oracle_c.carve(shape, origin, vs, views, nthreads=4))
 
 
 @pytest.mark.parametrize("default_value", [1, -1, 7])
@@ -242,8 +280,8 @@ def test_cfg1_digests(gpu_device, kind):
     """BASELINE cfg 1 (128^3 x 12 views): SHA-256 of the int32 grid vs the committed digest."""
     dig = json.load(open(os.path.join(GOLDEN, "synthetic_digests.json")))[f"{kind}_128_12"]
     shape, origin, vs, views = scene(128, 12, kind)
-    for vpl in (0, 1):
-        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+    for vpl, compact in ((0, 1), (0, 0), (1, 1)):
+        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl, compact=compact)
         assert histogram3(got) == dig["hist_m1_0_p1"]
         assert sha256(got) == dig["sha256_int32"]
 
@@ -288,8 +326,8 @@ def test_average_masks_resident_in_hbm(gpu_device):
 def test_cfg2_256_cubed_36_views_vs_oracle(gpu_device):
     shape, origin, vs, views = scene(256, 36, "plant")
     want = oracle_c.carve(shape, origin, vs, views, nthreads=os.cpu_count() or 8)
-    for vpl in (0, 1):
-        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl)
+    for vpl, compact in ((0, 1), (0, 0), (1, 1)):
+        got = hip_carve(shape, origin, vs, views, views_per_launch=vpl, compact=compact)
         assert np.array_equal(got, want)
 
 
@@ -315,6 +353,7 @@ def test_full_size_512_cubed_72_views_properties(gpu_device):
     shape, origin, vs, views = scene(512, 72, "plant")
     fused = hip_carve(shape, origin, vs, views, views_per_launch=0)
     dig = sha256(fused)
+    assert sha256(hip_carve(shape, origin, vs, views, views_per_launch=0, compact=0)) == dig
     per_view = hip_carve(shape, origin, vs, views, views_per_launch=1, view_order=0)
     assert sha256(per_view) == dig
     del per_view
