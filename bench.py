@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--skip-other-path", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option KEY=VALUE (sc_set_option)")
     return ap.parse_args()
 
 
@@ -171,6 +172,9 @@ def main():
     t = np.stack([v[2] for v in views])
     call = (K, R, t, masks_dev, V, H, W)
 
+    for kv in a.opt:
+        k, val = kv.split("=")
+        eng.set_option(int(k), int(val))
     vpl = {"fused": 0, "stream": 1}
     other = "stream" if a.path == "fused" else "fused"
     # warmup both schedules (untimed)

@@ -63,6 +63,12 @@ extern "C" {
                                      for its first two views, then finishes the survivors from
                                      compacted lists; 0: every view is applied densely           */
 
+/* tuning knobs of the fused carve (defaults in parentheses); results never depend on them */
+#define SC_OPT_DENSE_VIEWS 6      /* views applied to every voxel before compaction (2)       */
+#define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
+#define SC_OPT_LIST_BLOCKS 8      /* persistent grid of the list / resume kernels (2048)      */
+#define SC_OPT_VIEW_GROUP 9       /* views per work item in the final survivor stage (8)      */
+
 /* kernel ids for sc_kernel_stats */
 #define SC_KERNEL_CARVE 0
 #define SC_KERNEL_AVERAGE 1

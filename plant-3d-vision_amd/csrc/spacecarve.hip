@@ -76,10 +76,16 @@ constexpr int kStreamGroups = 4; // 16-byte groups per lane in the per-view stre
 constexpr int kXcdRun = 16;      // consecutive logical blocks kept on one XCD
 
 // Survivor lists of the fused carve (see carve_list_kernel).  Zeroed before every fused launch.
+// Every counter sits on a 128-byte line of its own: returning device-scope atomics on one
+// line serialise (~90 per microsecond measured), on different lines they do not.
+struct alignas(128) ListCounter {
+    uint32_t n;
+    uint32_t pad[31];
+};
 struct ListCtl {
-    uint32_t count[2][kSub];  // entries appended per sub-list, ping-pong between stages
-    uint32_t overflow;        // a sub-list ran out of room: the dense resume kernel takes over
-    uint32_t pad[3];
+    ListCounter count[2][kSub];  // entries appended per sub-list, ping-pong between stages
+    uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
+    uint32_t pad[31];
 };
 
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
@@ -245,7 +251,7 @@ __device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const 
             uint32_t lane = __lane_id();
             uint32_t base = 0;
             if (lane == (uint32_t)(__ffsll((long long)act) - 1))
-                base = atomicAdd(&ap.ctl->count[0][ap.sub], total);
+                base = atomicAdd(&ap.ctl->count[0][ap.sub].n, total);
             base = __shfl(base, __ffsll((long long)act) - 1);
             if (base + total > ap.subcap) {
                 if (lane == (uint32_t)(__ffsll((long long)act) - 1)) ap.ctl->overflow = 1u;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
     if (grp >= g.ngroups) return;
     int4 pre = make_int4(0, 0, 0, 0);
     if (!FRESH && VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
-    ap.sub = lb % kSub;
+    ap.sub = (lb / kXcdRun) % kSub;  // neighbouring blocks feed one sub-list: coherent chunks
     carve_group<FRESH, VEC>(labels, g, views, nviews, init, grp, pre, ap);
 }
 
@@ -304,22 +310,30 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
 }
 
 // Fused carve, sparse phase: one lane per SURVIVOR.  Reads the survivor sub-lists a previous
-// stage appended, applies views[0..nviews) with every lane busy, writes the labels that
-// change straight into the grid (carved -> -1 at once, 0 -> 1 at the end) and, when `lout`
-// is given, appends what is still alive for the next stage.  A persistent grid walks the
-// (sub-list, 256-entry chunk) items; the counts live in device memory, so the host never
-// waits to learn how many survivors there are.
+// stage appended and applies views with every lane busy, two views per iteration (two
+// independent projection chains and two gathers in flight per lane).  A persistent grid of
+// wavefronts walks the work items; the counts live in device memory, so the host never waits
+// to learn how many survivors there are.
+//   FINAL == false: an item is a 64-entry chunk and ALL `nviews` views; labels that change
+//     are written (carved -> -1 at once, 0 -> 1 at the end) and what is still alive is appended
+//     to `lout` for the next stage.
+//   FINAL == true : an item is a 64-entry chunk times a GROUP of `vgsize` views, so that there
+//     are many more items than wavefronts (no tail); groups of one chunk may run concurrently
+//     on different wavefronts, which is exact because a carve is a plain store of -1 (final,
+//     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
+template <bool FINAL>
 __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                             const ViewDesc *__restrict__ views,
                                                             int nviews,
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
-                                                            ListCtl *ctl, int sin, uint32_t subcap) {
+                                                            ListCtl *ctl, int sin, uint32_t subcap,
+                                                            int vgsize) {
     __shared__ uint32_t pref[kSub + 1];
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
     const uint32_t tid = threadIdx.x;
     {
-        uint32_t c = (min(ctl->count[sin][tid], subcap) + (kBlock - 1)) / kBlock;  // kSub == kBlock
+        uint32_t c = (min(ctl->count[sin][tid].n, subcap) + 63u) / 64u;  // kSub == kBlock
         if (tid == 0) pref[0] = 0;
         pref[tid + 1] = c;
         __syncthreads();
@@ -331,16 +345,29 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
             __syncthreads();
         }
     }
-    const uint32_t items = pref[kSub];
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= item (block-uniform)
+    const uint32_t chunks = pref[kSub];
+    const uint32_t vgroups = FINAL ? (uint32_t)((nviews + vgsize - 1) / vgsize) : 1u;
+    const uint64_t items = (uint64_t)chunks * vgroups;
+    const uint32_t lane = tid & 63u;
+    const uint64_t nworkers = (uint64_t)gridDim.x * (kBlock / 64);
+    // the wavefront index must be a scalar for the compiler, or everything derived from the
+    // item (view range, descriptors) is treated as divergent and fetched with vector loads
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint64_t item = (uint64_t)blockIdx.x * (kBlock / 64) + wave; item < items;
+         item += nworkers) {
+        // neighbouring wavefronts take neighbouring chunks of the same view group
+        const uint32_t vgi = (uint32_t)(item / chunks);
+        const uint32_t c = (uint32_t)(item - (uint64_t)vgi * chunks);
+        uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= c (wave-uniform)
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
-            if (pref[mid] <= item) lo = mid; else hi = mid;
+            if (pref[mid] <= c) lo = mid; else hi = mid;
         }
         const uint32_t s = lo;
-        const uint32_t e = (item - pref[s]) * kBlock + tid;
-        const uint32_t cnt = min(ctl->count[sin][s], subcap);
+        const uint32_t e = (c - pref[s]) * 64u + lane;
+        const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
+        const int v0 = FINAL ? (int)vgi * vgsize : 0;
+        const int v1 = FINAL ? min(nviews, v0 + vgsize) : nviews;
         if (e < cnt) {
             uint32_t entry = lin[(size_t)s * subcap + e];
             uint32_t idx = entry & 0x7fffffffu;
@@ -353,35 +380,38 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
             float x = g.ox + (float)(int)(il + g.i0) * g.vs;  // backprojection.c:71-73
             float y = g.oy + (float)(int)j * g.vs;
             float z = g.oz + (float)(int)k * g.vs;
-            for (int vi = 0; vi < nviews; ++vi) {
+            for (int vi = v0; vi < v1; vi += 2) {
                 if (__ballot(alive) == 0) break;
-                const ViewDesc d = views[vi];
-                float ax = d.R[0] * x + d.R[1] * y;
-                float ay = d.R[3] * x + d.R[4] * y;
-                float az = d.R[6] * x + d.R[7] * y;
-                int u, v;
-                bool ok = project(ax, ay, az, z, d, u, v) & alive;
-                if (ok) {
-                    uint32_t w = static_cast<const uint32_t *>(d.mask)[mask_word_index(u, v, d.tiles_x)];
-                    if (((w >> (u & 31)) & 1u) == 0) {  // :79
-                        alive = false;
-                        labels[idx] = -1;
-                    } else if (zero) {  // :81
-                        zero = false;
-                        flipped = true;
-                    }
+                const bool two = vi + 1 < v1;  // wave-uniform
+                const ViewDesc da = views[vi];
+                const ViewDesc db = views[two ? vi + 1 : vi];
+                int ua, va, ub, vb;
+                bool oka = project(da.R[0] * x + da.R[1] * y, da.R[3] * x + da.R[4] * y,
+                                   da.R[6] * x + da.R[7] * y, z, da, ua, va) & alive;
+                bool okb = project(db.R[0] * x + db.R[1] * y, db.R[3] * x + db.R[4] * y,
+                                   db.R[6] * x + db.R[7] * y, z, db, ub, vb) & alive & two;
+                uint32_t wa = 0, wb = 0;
+                if (oka) wa = static_cast<const uint32_t *>(da.mask)[mask_word_index(ua, va, da.tiles_x)];
+                if (okb) wb = static_cast<const uint32_t *>(db.mask)[mask_word_index(ub, vb, db.tiles_x)];
+                bool fga = ((wa >> (ua & 31)) & 1u) != 0, fgb = ((wb >> (ub & 31)) & 1u) != 0;
+                // two applications of backprojection.c:79-83; a zero pixel in either view wins
+                if ((oka & !fga) | (okb & !fgb)) {
+                    alive = false;
+                    labels[idx] = -1;
+                } else if (zero & ((oka & fga) | (okb & fgb))) {
+                    zero = false;
+                    if (FINAL) atomicCAS(&labels[idx], 0, 1); else flipped = true;
                 }
             }
-            if (alive && flipped) labels[idx] = 1;
-            if (lout != nullptr) {
+            if (!FINAL) {
+                if (alive && flipped) labels[idx] = 1;
                 unsigned long long b = __ballot(alive);
                 if (b != 0) {
                     unsigned long long act = __ballot(1);
                     int leader = __ffsll((long long)act) - 1;
-                    uint32_t lane = __lane_id();
                     uint32_t base = 0;
                     if ((int)lane == leader)
-                        base = atomicAdd(&ctl->count[sin ^ 1][s], (uint32_t)__popcll(b));
+                        base = atomicAdd(&ctl->count[sin ^ 1][s].n, (uint32_t)__popcll(b));
                     base = __shfl(base, leader);
                     // survivors of sub-list s never outnumber its entries: no overflow here
                     if (alive) {
@@ -647,6 +677,10 @@ struct sc_engine {
     int64_t time_kernels = 0;
     int64_t max_pending = 256;
     int64_t compact = 1;
+    int64_t dense_views = 2;     // views applied to every voxel before compaction
+    int64_t stage1_views = 8;    // views applied to the first survivor list
+    int64_t list_blocks = 2048;  // persistent grid of the list / resume kernels
+    int64_t view_group = 8;      // views per work item in the final list stage
 
     std::vector<TimedLaunch> timed[kNumKernels];
     std::vector<hipEvent_t> event_pool;
@@ -884,10 +918,7 @@ void order_views(std::vector<ViewDesc> &v) {
     v.swap(out);
 }
 
-constexpr int kDenseViews = 2;     // views applied to every voxel before compaction
-constexpr int kStage1Views = 8;    // views applied to the first survivor list
 constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
-constexpr uint32_t kListBlocks = 2048;  // persistent grid of the list / resume kernels
 
 int ensure_lists(sc_engine *e) {
     if (e->lists) return SC_OK;
@@ -939,7 +970,10 @@ int flush(sc_engine *e, size_t count = 0) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
         // fused carve with survivor compaction: dense for kDenseViews, then lists
-        bool compact = e->compact && nv >= (size_t)kMinFusedViews && (uint64_t)e->n < 0x80000000ull;
+        const int kDenseViews = (int)e->dense_views, kStage1Views = (int)e->stage1_views;
+        const uint32_t kListBlocks = (uint32_t)e->list_blocks;
+        bool compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)kDenseViews &&
+                       (uint64_t)e->n < 0x80000000ull;
         Append ap{nullptr, nullptr, 0u, 0u};
         int dense_views = (int)nv;
         if (compact) {
@@ -987,13 +1021,18 @@ int flush(sc_engine *e, size_t count = 0) {
             rc = lt2.begin();
             if (rc) return rc;
             bool two = (size_t)s1 < nv;
-            hipLaunchKernelGGL(carve_list_kernel, dim3(kListBlocks), block, 0, e->stream, st, g,
-                               vd + kDenseViews, s1 - kDenseViews, l0, two ? l1 : nullptr, e->ctl, 0,
-                               e->subcap);
-            if (two)
-                hipLaunchKernelGGL(carve_list_kernel, dim3(kListBlocks), block, 0, e->stream, st, g,
-                                   vd + s1, (int)nv - s1, l1, static_cast<uint32_t *>(nullptr), e->ctl,
-                                   1, e->subcap);
+            int vg = (int)e->view_group;
+            if (two) {
+                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(kListBlocks), block, 0, e->stream, st,
+                                   g, vd + kDenseViews, s1 - kDenseViews, l0, l1, e->ctl, 0, e->subcap, vg);
+                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(kListBlocks), block, 0, e->stream, st,
+                                   g, vd + s1, (int)nv - s1, l1, static_cast<uint32_t *>(nullptr), e->ctl,
+                                   1, e->subcap, vg);
+            } else {
+                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(kListBlocks), block, 0, e->stream, st,
+                                   g, vd + kDenseViews, s1 - kDenseViews, l0,
+                                   static_cast<uint32_t *>(nullptr), e->ctl, 0, e->subcap, vg);
+            }
             if (vec)
                 hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(kListBlocks), block, 0, e->stream,
                                    st, g, vd + kDenseViews, (int)nv - kDenseViews, e->ctl);
@@ -1189,6 +1228,22 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_COMPACT:
             e->compact = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_DENSE_VIEWS:
+            if (value < 1 || value > 64) return fail(SC_ERR_INVALID, "dense_views must be in [1, 64]");
+            e->dense_views = value;
+            return SC_OK;
+        case SC_OPT_STAGE1_VIEWS:
+            if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "stage1_views must be in [1, 4096]");
+            e->stage1_views = value;
+            return SC_OK;
+        case SC_OPT_LIST_BLOCKS:
+            if (value < 1 || value > 65536) return fail(SC_ERR_INVALID, "list_blocks must be in [1, 65536]");
+            e->list_blocks = value;
+            return SC_OK;
+        case SC_OPT_VIEW_GROUP:
+            if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "view_group must be in [1, 4096]");
+            e->view_group = value;
             return SC_OK;
         case SC_OPT_MAX_PENDING:
             if (value < 1) return fail(SC_ERR_INVALID, "max_pending must be >= 1");
