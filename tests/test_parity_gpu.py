@@ -86,6 +86,24 @@ def test_survivor_list_overflow_falls_back_to_dense_resume(gpu_device, kind, n, 
     assert np.array_equal(hip_carve(shape, origin, vs, views, compact=0), want)
 
 
+@pytest.mark.parametrize("shape,kw", [
+    ((6, 5, 512), dict(radius_factor=2.0)),                      # tall columns: full-wave z-runs
+    ((6, 5, 512), dict(radius_factor=0.2)),                      # camera ring INSIDE the columns' extent
+    ((5, 4, 768), dict(radius_factor=0.6, tilt_deg=35.0)),       # oblique: runs cross many tiles
+    ((4, 4, 1024), dict(radius_factor=1.0, width=200, height=90, fx=150.0, fy=150.0, cx=100.0, cy=45.0)),
+    ((3, 7, 561), dict(radius_factor=1.5)),                      # nz % 4 != 0, wavefronts span columns
+])
+@pytest.mark.parametrize("kind", ["plant", "noise", "empty"])
+def test_tall_columns_close_and_oblique_cameras(gpu_device, shape, kw, kind):
+    """Long z-runs (full wavefronts inside one column), cameras inside the columns' extent,
+    oblique views, runs that leave the image or pass behind the camera, nz % 4 != 0."""
+    sh, origin, vs, views = scene(shape, 7, kind, **kw)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    for vpl in (0, 1):
+        assert np.array_equal(hip_carve(sh, origin, vs, views, views_per_launch=vpl), want), \
+            (vpl, histogram3(want))
+
+
 def test_fused_compaction_with_slab_and_default_values(gpu_device):
     shape, origin, vs, views = scene((40, 28, 36), 14, "plant")
     for dv in (0, 3):
