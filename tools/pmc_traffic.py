@@ -37,7 +37,8 @@ def mean_counter(tag, which):
 
 def short(name):
     for key in ("carve_kernel_1<false", "carve_kernel_1<true", "carve_kernel<true", "carve_kernel<false",
-                "average_kernel", "pack_kernel", "pack16_kernel", "fill_kernel"):
+                "carve_list_kernel<true", "carve_list_kernel<false", "carve_resume_kernel<true",
+                "carve_resume_kernel<false", "average_kernel", "pack_kernel", "pack16_kernel", "fill_kernel"):
         if key in name:
             return key + (">" if "<" in key else "")
     return name[:40]

@@ -1,3 +1,4 @@
 R=$GRAFT_REPO_ROOT
-cd $R && timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python $R/bench.py --steps 20 --warmup 3 --cpu-seconds 0 | python -c "import json,sys; d=json.load(sys.stdin); print(round(d['ms_per_step'],4), d['value'], {k:round(v['avg_ms'],4) for k,v in d['kernels'].items()}, 'stream', round(d['stream']['ms_per_step'],3), round(d['stream']['roofline']['frac'],3))"
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --dist-backend gloo --share-device > gpurun_out/bench_2rank.json 2> gpurun_out/bench_2rank.err; echo rc=$?; tail -3 gpurun_out/bench_2rank.err; cat gpurun_out/bench_2rank.json | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['n_gpus'], d['value'], d['ms_per_step'], d['config']['global_grid'], d['config']['slab_per_gpu'], d['scaling'])"
