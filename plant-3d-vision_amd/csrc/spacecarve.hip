@@ -125,7 +125,16 @@ __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
 }
 
 __device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
-    return ((uint32_t)(v >> 5) * (uint32_t)tiles_x + (uint32_t)(u >> 5)) * 32u + (uint32_t)(v & 31);
+    // all factors are < 2^24 for in-image pixels: the 24-bit multiply is full rate
+    return (__umul24((uint32_t)(v >> 5), (uint32_t)tiles_x) + (uint32_t)(u >> 5)) * 32u +
+           (uint32_t)(v & 31);
+}
+
+// The mask pointer comes out of a descriptor, so the compiler cannot tell its address space and
+// would emit flat loads; it is always global memory.
+typedef const __attribute__((address_space(1))) uint32_t *gmask_t;
+__device__ __forceinline__ uint32_t load_mask_word(const void *mask, uint32_t word) {
+    return ((gmask_t)(uintptr_t)mask)[word];
 }
 
 struct Vox4 {
@@ -215,8 +224,8 @@ __device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const 
             int u, v;
             ok[e] = project(ax, ay, az, z[e], d, u, v) & ((alive >> e) & 1u);
             sh[e] = u & 31;
-            w[e] = 0;
-            if (ok[e]) w[e] = bits[mask_word_index(u, v, d.tiles_x)];
+            // unconditional gather (word 0 when the voxel is out): no branch per element
+            w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u, v, d.tiles_x) : 0u);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -396,8 +405,8 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
                 bool okb = project(db.R[0] * x + db.R[1] * y, db.R[3] * x + db.R[4] * y,
                                    db.R[6] * x + db.R[7] * y, z, db, ub, vb) & alive & two;
                 uint32_t wa = 0, wb = 0;
-                if (oka) wa = static_cast<const uint32_t *>(da.mask)[mask_word_index(ua, va, da.tiles_x)];
-                if (okb) wb = static_cast<const uint32_t *>(db.mask)[mask_word_index(ub, vb, db.tiles_x)];
+                if (oka) wa = load_mask_word(da.mask, mask_word_index(ua, va, da.tiles_x));
+                if (okb) wb = load_mask_word(db.mask, mask_word_index(ub, vb, db.tiles_x));
                 bool fga = ((wa >> (ua & 31)) & 1u) != 0, fgb = ((wb >> (ub & 31)) & 1u) != 0;
                 // two applications of backprojection.c:79-83; a zero pixel in either view wins
                 if ((oka & !fga) | (okb & !fgb)) {
