@@ -158,6 +158,13 @@ int64_t sc_num_voxels(const sc_engine *e);
 int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *total_ms);
 int sc_reset_kernel_stats(sc_engine *e);
 
+/* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on
+ * `count` pseudo-random operand triples (mode 0: raw bit patterns, 1: projection-like
+ * magnitudes) and reports how many quotients differ bit-for-bit (must be 0) and how many
+ * triples took the fast path. */
+int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
+                         uint64_t *mismatches, uint64_t *fast_pairs);
+
 /* Device-memory helpers so that hosts without a HIP binding can stage inputs in HBM
  * (bench.py, tests): plain hipMalloc / hipMemcpy / hipFree on the engine's device. */
 int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr);

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "sc_num_voxels": ("q", ["p"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
+    "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
     "sc_dev_free": ("i", ["p", "p"]),
     "sc_dev_upload": ("i", ["p", "p", "p", "q"]),
@@ -55,8 +56,9 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float,
+       "I": ctypes.c_uint32,
        "s": ctypes.c_char_p, "v": None}
-_CDEF = {"p": "void *", "i": "int", "q": "int64_t", "f": "float", "s": "const char *",
+_CDEF = {"p": "void *", "i": "int", "q": "int64_t", "f": "float", "s": "const char *", "I": "uint32_t",
          "v": "void"}
 
 
@@ -285,6 +287,12 @@ class Engine:
 
     def reset_kernel_stats(self):
         self._call("sc_reset_kernel_stats")
+
+    def selftest_division(self, count, seed=1, mode=1):
+        """(mismatches, fast_pairs) of the shared-reciprocal division vs hipcc's IEEE division."""
+        out = np.zeros(2, dtype=np.uint64)
+        self._call("sc_selftest_division", int(count), int(seed), int(mode), addr(out), addr(out) + 8)
+        return int(out[0]), int(out[1])
 
     # -- device memory helpers --------------------------------------------------------
     def dev_alloc(self, nbytes):

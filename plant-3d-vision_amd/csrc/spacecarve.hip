@@ -105,6 +105,37 @@ __device__ __forceinline__ uint32_t spread_block(uint32_t bid, uint32_t nblocks)
     return (grp * 8u + xcd) * kXcdRun + (seq % kXcdRun);
 }
 
+// Correctly rounded p/pz for BOTH image coordinates from ONE reciprocal.
+// hipcc expands an IEEE f32 division into  div_scale x2, rcp, 2 fma (Newton step on the
+// reciprocal), mul, 4 fma (two corrections of the quotient), div_fmas, div_fixup.  When the
+// operands are in a range where v_div_scale scales nothing and v_div_fixup fixes nothing
+// (denominator and both numerators normal, within 2^+-40: see the V_DIV_SCALE_F32 rules), that
+// expansion is exactly the plain-FMA sequence below, so running it by hand with the refined
+// reciprocal SHARED between the two numerators gives bit-identical quotients with 13
+// instructions instead of 22 (and one quarter-rate v_rcp_f32 instead of two).  Any lane outside
+// the range sends its whole wavefront through the compiler's division.
+// sc_selftest_division() compares the two bit-for-bit on 2^32 operand pairs.
+__device__ __forceinline__ bool div_fast_range(float px, float py, float pz) {
+    // fmin/fmax drop a NaN operand, so NaNs are excluded by explicit (ordered) comparisons
+    bool ordered = !__builtin_isunordered(px, py);
+    float lo = fminf(fabsf(px), fabsf(py));
+    float hi = fmaxf(fmaxf(fabsf(px), fabsf(py)), pz);
+    return ordered & (pz > 0x1p-40f) & (lo > 0x1p-40f) & (hi < 0x1p40f);  // also false for
+                                                            // zero numerators, pz <= 0, inf
+}
+__device__ __forceinline__ float refined_rcp(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
 // backproject_point (backprojection.c:3-34) with the x/y partial sums hoisted.
 // a{x,y,z} = R[0]*x + R[1]*y etc. (rounded as the reference rounds them).
 __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
@@ -112,8 +143,17 @@ __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
     float pz = (az + d.R[8] * z) + d.t[2];  // :11
     float px = (ax + d.R[2] * z) + d.t[0];  // :17
     float py = (ay + d.R[5] * z) + d.t[1];  // :18
-    float uf = (px / pz) * d.K[0] + d.K[2];  // :20
-    float vf = (py / pz) * d.K[1] + d.K[3];  // :21
+    float qx, qy;
+    if (__ballot(!div_fast_range(px, py, pz)) == 0) {  // wave-uniform
+        float r = refined_rcp(pz);
+        qx = div_by_rcp(px, pz, r);
+        qy = div_by_rcp(py, pz, r);
+    } else {
+        qx = px / pz;
+        qy = py / pz;
+    }
+    float uf = qx * d.K[0] + d.K[2];  // :20
+    float vf = qy * d.K[1] + d.K[3];  // :21
     // :13 rejects pz < 0 (not NaN, not -0); :23-31 reject (int)uf outside [0, W-1].
     // Truncation toward zero accepts uf in (-1, 0); NaN/inf/huge fail the comparisons,
     // which is what the cvttss2si INT_MIN result does in the canonical restatement.
@@ -524,6 +564,39 @@ template <bool FRESH, bool VEC>
 __global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ values, GridDesc g,
                                                            ViewDesc view, float init) {
     average_body<FRESH, VEC>(values, g, &view, 1, init);
+}
+
+// Self-test of the shared-reciprocal division against the compiler's IEEE division.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(kBlock) void div_selftest_kernel(uint64_t count, uint32_t seed, int mode,
+                                                              unsigned long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long bad = 0, fast = 0;
+    for (; i < count; i += stride) {
+        uint32_t a = mix32((uint32_t)i ^ seed), b = mix32((uint32_t)(i >> 32) + a + seed * 0x9e3779b9u);
+        uint32_t c = mix32(a ^ (b * 0x85ebca6bu) ^ 0x1234567u), e = mix32(c + b);
+        float n1, n2, dd;
+        if (mode == 0) {  // raw bit patterns: every class of float
+            n1 = __uint_as_float(a); n2 = __uint_as_float(b); dd = __uint_as_float(c);
+        } else {          // projection-like magnitudes, random mantissas and signs
+            n1 = __uint_as_float((a & 0x807fffffu) | ((110u + (e & 31u)) << 23));
+            n2 = __uint_as_float((b & 0x807fffffu) | ((110u + ((e >> 5) & 31u)) << 23));
+            dd = __uint_as_float((c & 0x007fffffu) | ((118u + ((e >> 10) & 15u)) << 23));
+        }
+        if (div_fast_range(n1, n2, dd)) {
+            ++fast;
+            float r = refined_rcp(dd);
+            float q1 = div_by_rcp(n1, dd, r), q2 = div_by_rcp(n2, dd, r);
+            float w1 = n1 / dd, w2 = n2 / dd;
+            bad += (__float_as_uint(q1) != __float_as_uint(w1)) + (__float_as_uint(q2) != __float_as_uint(w2));
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (fast) atomicAdd(&out[1], fast);
 }
 
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
@@ -1436,6 +1509,26 @@ int sc_reset_kernel_stats(sc_engine *e) {
         }
         e->timed[k].clear();
     }
+    return SC_OK;
+}
+
+int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
+                         uint64_t *mismatches, uint64_t *fast_pairs) {
+    if (!e || !mismatches || !fast_pairs || count < 0) return fail(SC_ERR_INVALID, "bad argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    unsigned long long *out = nullptr, host[2] = {0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&out), sizeof host));
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof host, e->stream));
+    hipLaunchKernelGGL(div_selftest_kernel, dim3(4096), dim3(kBlock), 0, e->stream, (uint64_t)count,
+                       seed, mode, out);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void)hipFree(out);
+    if (he != hipSuccess) return fail(SC_ERR_DEVICE, "division self-test failed: %s", hipGetErrorString(he));
+    *mismatches = host[0];
+    *fast_pairs = host[1];
     return SC_OK;
 }
 

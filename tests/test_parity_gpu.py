@@ -44,6 +44,20 @@ def test_library_sees_gfx950(gpu_device):
     assert nat.device_count() >= 1
 
 
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 77), (0, 5)])
+def test_shared_reciprocal_division_is_bit_identical(gpu_device, mode, seed):
+    """The kernels divide p_x and p_y by p_z through one refined reciprocal; inside its
+    operand range that must equal hipcc's IEEE division bit for bit (2^32 triples a run)."""
+    e = nat.Engine([4, 4, 4], [0, 0, 0], 1.0, nat.SC_MODE_CARVE)
+    bad, fast = e.selftest_division(1 << 32, seed=seed, mode=mode)
+    e.close()
+    assert bad == 0
+    if mode == 1:
+        assert fast == 1 << 32  # projection-like operands all take the fast path
+    else:
+        assert 0 < fast < 1 << 31  # raw bit patterns mostly fall outside the range
+
+
 def test_ctor_like_reference_unit_test(gpu_device):
     # reference tests/unit/test_cl.py:5-9, plus what the reference never checks: the values
     bp = Backprojection([10, 10, 10], [0.0, 0.0, 0.0], 1.0)
