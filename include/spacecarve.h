@@ -47,6 +47,10 @@ extern "C" {
 #define SC_MASK_U8 0  /* carve: foreground = (value != 0), the test at backprojection.c:79 */
 #define SC_MASK_I32 1 /* carve: what cl.py:215 casts to                                    */
 #define SC_MASK_F32 2 /* average: the value added at backprojection.c:54                   */
+#define SC_MASK_U8_INV 3   /* carve: uint8 mask to be inverted first, i.e. `np.invert(mask)` of
+                              cl.py:300-301 done on the device: foreground = (value != 255)   */
+#define SC_MASK_BOOL_INV 4 /* carve: bool mask (bytes 0/1) to be inverted first (logical not):
+                              foreground = (value == 0)                                       */
 
 /* sc_set_option keys */
 #define SC_OPT_VIEWS_PER_LAUNCH 1 /* 0 (default): defer views, fuse all pending views into one

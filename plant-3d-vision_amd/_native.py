@@ -20,7 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "spacecarve.h")
 SC_OK = 0
 SC_ERR_INVALID, SC_ERR_DEVICE, SC_ERR_NOMEM, SC_ERR_STATE = -1, -2, -3, -4
 SC_MODE_CARVE, SC_MODE_AVERAGE = 0, 1
-SC_MASK_U8, SC_MASK_I32, SC_MASK_F32 = 0, 1, 2
+SC_MASK_U8, SC_MASK_I32, SC_MASK_F32, SC_MASK_U8_INV, SC_MASK_BOOL_INV = 0, 1, 2, 3, 4
 SC_OPT_VIEWS_PER_LAUNCH, SC_OPT_VIEW_ORDER, SC_OPT_TIME_KERNELS, SC_OPT_MAX_PENDING = 1, 2, 3, 4
 SC_OPT_COMPACT, SC_OPT_DENSE_VIEWS, SC_OPT_STAGE1_VIEWS, SC_OPT_LIST_BLOCKS = 5, 6, 7, 8
 SC_OPT_VIEW_GROUP = 9

@@ -13,7 +13,10 @@ HIP engine behind ``include/spacecarve.h``.  Differences a caller can observe:
 * There is no CPU path: constructing an instance without the built library or without a
   gfx950 GPU raises.
 """
+import collections
 import logging
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -95,7 +98,7 @@ class Backprojection(object):
     """
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, labels=None,
-                 log=False, device=0, views_per_launch=0):
+                 log=False, device=0, views_per_launch=0, decode_workers=None):
         self.shape = shape
         self.origin = origin
         self.voxel_size = voxel_size
@@ -119,6 +122,10 @@ class Backprojection(object):
 
         self.device = device
         self.views_per_launch = views_per_launch
+        # image files are decoded ahead of the device on this many threads (1 = the reference's
+        # strictly serial read -> process loop, cl.py:282-303); results do not depend on it
+        self.decode_workers = (min(8, os.cpu_count() or 1) if decode_workers is None
+                               else max(1, int(decode_workers)))
         self.values_h = None
         self.values_d = None
         self.intrinsics_d = None
@@ -152,7 +159,18 @@ class Backprojection(object):
         tvec: translation; mask: 2-D array (uint8/bool/int for carving, anything
         ``img_as_float32`` accepts for averaging).
         """
+        self._submit_view(intrinsics, rot, tvec, mask, invert=False)
+        return
+
+    def _submit_view(self, intrinsics, rot, tvec, mask, invert):
+        """``process_view`` plus the fileset loop's optional ``np.invert`` (cl.py:300-301).
+        For 1-byte carving masks the inversion is folded into the device-side bit packing
+        (``SC_MASK_U8_INV`` / ``SC_MASK_BOOL_INV``); every other case inverts on the host
+        exactly as the reference does."""
         mask = np.asarray(mask)
+        fold = invert and self.dtype == np.int32 and mask.dtype in (np.uint8, np.bool_)
+        if invert and not fold:
+            mask = np.invert(mask)
         if self.dtype == np.float32 and mask.dtype != np.float32:
             mask = img_as_float32(mask)  # cl.py:205-206
         if self.log and self.dtype == np.float32:
@@ -163,9 +181,11 @@ class Backprojection(object):
             # cl.py:215 casts to int32 and the kernel tests == 0 (backprojection.c:79);
             # for 1-byte masks that test is done on the bytes themselves
             if mask.dtype == np.bool_:
-                mask_h, code = np.ascontiguousarray(mask).view(np.uint8), nat.SC_MASK_U8
+                mask_h = np.ascontiguousarray(mask).view(np.uint8)
+                code = nat.SC_MASK_BOOL_INV if fold else nat.SC_MASK_U8
             elif mask.dtype == np.uint8:
-                mask_h, code = np.ascontiguousarray(mask), nat.SC_MASK_U8
+                mask_h = np.ascontiguousarray(mask)
+                code = nat.SC_MASK_U8_INV if fold else nat.SC_MASK_U8
             else:
                 mask_h, code = np.ascontiguousarray(mask, dtype=np.int32), nat.SC_MASK_I32
         else:
@@ -210,6 +230,7 @@ class Backprojection(object):
         if hasattr(fs, "get_files") and not isinstance(fs, (list, tuple)):
             fs = fs.get_files()  # cl.py:279-280
 
+        selected = []
         for fi in fs:
             if label is not None and fi.get_metadata("channel") != label:  # cl.py:284
                 continue
@@ -219,13 +240,35 @@ class Backprojection(object):
                 logger.warning(
                     f"Could not get camera params from '{camera_metadata}' for {fi.id}, skipping...")
                 continue
+            selected.append((fi, cam))
+
+        def submit(cam, mask):
             intrinsics = np.array(cam["camera_model"]['params'][0:4], dtype=np.float32)  # :293
             rot = np.array(sum(cam['rotmat'], []), dtype=np.float32)  # :295
             tvec = np.array(cam['tvec'], dtype=np.float32)  # :296
-            mask = read_image(fi)  # :298
-            if invert:
-                mask = np.invert(mask)  # :300-301
-            self.process_view(intrinsics, rot, tvec, mask)
+            self._submit_view(intrinsics, rot, tvec, mask, invert)  # :300-303
+
+        if self.decode_workers <= 1 or len(selected) <= 1:
+            for fi, cam in selected:
+                submit(cam, read_image(fi))  # :298
+        else:
+            # decode ahead on a few threads, submit strictly in file order (the float sum of the
+            # averaging kernel depends on it); the device packs/carves while the host decodes
+            window = 2 * self.decode_workers
+            with ThreadPoolExecutor(max_workers=self.decode_workers) as pool:
+                pending = collections.deque()
+                it = iter(selected)
+                for fi, cam in it:
+                    pending.append((cam, pool.submit(read_image, fi)))
+                    if len(pending) >= window:
+                        break
+                while pending:
+                    cam, fut = pending.popleft()
+                    mask = fut.result()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        pending.append((nxt[1], pool.submit(read_image, nxt[0])))
+                    submit(cam, mask)
 
         return self.get_values()
 

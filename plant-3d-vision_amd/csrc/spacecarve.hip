@@ -609,15 +609,16 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst
     }
 }
 
-// Mask ingest, general form: raw [V][H][W] pixels (u8 or i32) -> 1 bit/pixel (pixel != 0, the
-// test at backprojection.c:79 on the cast of cl.py:215), in 32x32 tiles.  One wavefront votes
+// Mask ingest, general form: raw [V][H][W] pixels (u8 or i32) -> 1 bit/pixel (pixel !=
+// background; background 0 is the test at backprojection.c:79 on the cast of cl.py:215, 255 / 1
+// fold the fileset loop's np.invert of a uint8 / bool mask, cl.py:300-301), in 32x32 tiles.  One wavefront votes
 // 64 consecutive pixels of a row with a ballot and writes the two 32-bit tile words.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
                                                       int64_t row_stride, int64_t view_stride,
                                                       int W, int H, int nviews, int tiles_x,
                                                       uint32_t *__restrict__ out,
-                                                      int64_t out_view_words) {
+                                                      int64_t out_view_words, T background) {
     const int lane = threadIdx.x & 63;
     const int segs = (W + 63) >> 6;
     int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
     bool fg = false;
     if (u < W) {
         const char *row = reinterpret_cast<const char *>(raw) + view * view_stride + v * row_stride;
-        fg = reinterpret_cast<const T *>(row)[u] != 0;
+        fg = reinterpret_cast<const T *>(row)[u] != background;
     }
     unsigned long long vote = __ballot(fg);
     uint32_t *o = out + view * out_view_words;
@@ -644,44 +645,54 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
     }
 }
 
-// Mask ingest, fast form for uint8 masks whose rows are 16-byte aligned multiples of 16 px:
-// a wavefront makes ONE 32x32 tile.  Lane l (< 32) loads the left 16 pixels of tile row l,
-// lane 32+l the right 16; 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per
-// dword), the halves meet through one shuffle, and lanes 0..31 store the tile's 32 words as
-// one 128-byte line.  The four wavefronts of a block take four adjacent tiles, so the block
-// reads whole 128-byte lines of every pixel row.
+// Mask ingest, fast form for 1-byte masks whose rows are 16-byte aligned multiples of 16 px.
+// A block turns 128-pixel x 32-row panels into 32x32 tiles.  Lane l of wavefront w loads 16
+// pixels: row 8w + l/8 of the panel, 16-byte chunk l%8 of that row's 128-byte line -- so every
+// wavefront load instruction reads 8 whole lines, and kPackRows of them are in flight per lane.
+// 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per dword), neighbouring lanes
+// join their halves with one shuffle, and the even lanes store the tile words.
 __device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
     uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
     return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
 }
 
+constexpr int kPackRows = 4;  // tile rows per block: that many 16-byte loads in flight per lane
+
 __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restrict__ raw,
                                                         int64_t row_stride, int64_t view_stride,
                                                         int W, int H, int nviews, int tiles_x,
                                                         int tiles_y, uint32_t *__restrict__ out,
-                                                        int64_t out_view_words) {
+                                                        int64_t out_view_words, uint32_t flip) {
+    // flip: 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
     const int lane = threadIdx.x & 63;
-    const int txb = (tiles_x + 3) >> 2;  // blocks per tile row
+    const int txb = (tiles_x + 3) >> 2;                      // panels per tile row
+    const int tyb = (tiles_y + kPackRows - 1) / kPackRows;   // block rows per view
     int64_t b = blockIdx.x;
     int bx = (int)(b % txb);
     int64_t r = b / txb;
-    int ty = (int)(r % tiles_y);
-    int view = (int)(r / tiles_y);
+    int by = (int)(r % tyb);
+    int view = (int)(r / tyb);
     if (view >= nviews) return;
-    int tx = bx * 4 + (threadIdx.x >> 6);
-    if (tx >= tiles_x) return;  // whole wavefront
-    int v = ty * 32 + (lane & 31);
-    int u0 = tx * 32 + (lane >> 5) * 16;
-    uint32_t half = 0;
-    if (v < H && u0 < W) {  // W % 16 == 0: a 16-pixel run is inside the row or outside it
-        const uint4 q = *reinterpret_cast<const uint4 *>(raw + view * view_stride + (int64_t)v * row_stride + u0);
-        half = nonzero_nibble(q.x) | (nonzero_nibble(q.y) << 4) | (nonzero_nibble(q.z) << 8) |
-               (nonzero_nibble(q.w) << 12);
+    int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
+    int c = lane & 7;                                      // 16-pixel chunk inside the panel
+    int u0 = bx * 128 + c * 16;
+    int tx = bx * 4 + (c >> 1);
+    uint4 q[kPackRows];
+#pragma unroll
+    for (int k = 0; k < kPackRows; ++k) {
+        int v = (by * kPackRows + k) * 32 + row;
+        q[k] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
+        if (v < H && u0 < W)  // W % 16 == 0: a 16-pixel run is inside the row or outside it
+            q[k] = *reinterpret_cast<const uint4 *>(raw + view * view_stride + (int64_t)v * row_stride + u0);
     }
-    uint32_t other = __shfl_xor(half, 32);
-    if (lane < 32) {
-        uint32_t word = half | (other << 16);
-        out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + lane] = word;
+#pragma unroll
+    for (int k = 0; k < kPackRows; ++k) {
+        int ty = by * kPackRows + k;
+        uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
+                        (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
+        uint32_t other = __shfl_xor(half, 1);
+        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
+            out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = half | (other << 16);
     }
 }
 
@@ -897,10 +908,14 @@ int ensure_slots(sc_engine *e, size_t bytes) {
     return SC_OK;
 }
 
-size_t elem_size(int dtype) { return dtype == SC_MASK_U8 ? 1 : 4; }
+size_t elem_size(int dtype) {
+    return (dtype == SC_MASK_U8 || dtype == SC_MASK_U8_INV || dtype == SC_MASK_BOOL_INV) ? 1 : 4;
+}
 
 int check_dtype(const sc_engine *e, int dtype) {
-    if (e->mode == SC_MODE_CARVE && (dtype == SC_MASK_U8 || dtype == SC_MASK_I32)) return SC_OK;
+    if (e->mode == SC_MODE_CARVE && (dtype == SC_MASK_U8 || dtype == SC_MASK_I32 ||
+                                     dtype == SC_MASK_U8_INV || dtype == SC_MASK_BOOL_INV))
+        return SC_OK;
     if (e->mode == SC_MODE_AVERAGE && dtype == SC_MASK_F32) return SC_OK;
     return fail(SC_ERR_INVALID, "mask dtype %d does not fit engine mode %d", dtype, e->mode);
 }
@@ -934,16 +949,18 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     if (rc) return rc;
     int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     LaunchTimer lt{e, SC_KERNEL_PACK};
-    bool fast = dtype == SC_MASK_U8 && (W % 16) == 0 && (row_stride % 16) == 0 &&
+    bool bytes = dtype != SC_MASK_I32;
+    uint32_t flip = dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
+    bool fast = bytes && (W % 16) == 0 && (row_stride % 16) == 0 &&
                 (view_stride % 16) == 0 && (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
     if (fast) {
-        int64_t blocks = (int64_t)V * tiles_y * ((tiles_x + 3) / 4);
+        int64_t blocks = (int64_t)V * ((tiles_y + kPackRows - 1) / kPackRows) * ((tiles_x + 3) / 4);
         if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
         rc = lt.begin();
         if (rc) return rc;
         hipLaunchKernelGGL(pack16_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
                            static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,
-                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words);
+                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip);
     } else {
         int segs = (W + 63) / 64;
         int64_t waves = (int64_t)V * H * segs;
@@ -951,16 +968,18 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
         if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
         rc = lt.begin();
         if (rc) return rc;
-        if (dtype == SC_MASK_U8) {
+        if (bytes) {
+            // background byte: 0, or 255 / 1 when the mask is to be inverted first
+            uint8_t bg = dtype == SC_MASK_U8_INV ? 255 : dtype == SC_MASK_BOOL_INV ? 1 : 0;
             hipLaunchKernelGGL(pack_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
                                e->stream, static_cast<const uint8_t *>(raw_dev), row_stride,
                                view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
-                               (int64_t)words);
+                               (int64_t)words, bg);
         } else {
             hipLaunchKernelGGL(pack_kernel<int32_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
                                e->stream, static_cast<const int32_t *>(raw_dev), row_stride,
                                view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
-                               (int64_t)words);
+                               (int64_t)words, (int32_t)0);
         }
     }
     HIP_TRY(hipGetLastError());

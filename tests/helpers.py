@@ -37,6 +37,10 @@ class OracleEngine:
         self._vol.clear()
 
     def process_view(self, K, R, t, mask, mask_dtype):
+        if mask_dtype == nat.SC_MASK_U8_INV:      # what the device folds into its bit packing
+            mask = np.invert(np.asarray(mask, dtype=np.uint8))
+        elif mask_dtype == nat.SC_MASK_BOOL_INV:
+            mask = np.invert(np.asarray(mask).astype(np.bool_))
         self._vol.process_view(K, R, t, mask, begin=self._begin, end=self._end)
         self.views_seen += 1
 

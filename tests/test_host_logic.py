@@ -70,6 +70,16 @@ def test_invert_is_numpy_invert_on_raw_dtype():
     assert np.array_equal(vol, oracle_c.carve(shape, origin, vs, inv))
 
 
+def test_invert_bool_and_int_masks():
+    shape, origin, vs, views = scene(12, 3, "plant")
+    for conv in (lambda m: m != 0, lambda m: m.astype(np.int32)):
+        vv = [(K, R, t, conv(m)) for K, R, t, m in views]
+        bp = OracleBackprojection(shape, origin, vs, decode_workers=3)
+        vol = bp.process_fileset(files_from_views(vv, "colmap_camera"), "colmap_camera", invert=True)
+        inv = [(K, R, t, np.invert(m)) for K, R, t, m in vv]
+        assert np.array_equal(vol, oracle_c.carve(shape, origin, vs, inv))
+
+
 def test_averaging_log_path_matches_reference_ops():
     shape, origin, vs, views = scene(10, 3, "plant")
     bp = OracleBackprojection(shape, origin, vs, type="averaging", log=True)

@@ -200,6 +200,39 @@ def test_mask_dtypes_bool_int32_grey(gpu_device):
     assert np.array_equal(hip_carve(shape, origin, vs, as_f64), oracle_c.carve(shape, origin, vs, as_f64))
 
 
+@pytest.mark.parametrize("w,h", [(160, 96), (33, 17), (1440, 1080)])
+def test_invert_folded_into_device_packing(gpu_device, w, h):
+    """``process_fileset(invert=True)``: uint8 / bool masks are inverted by the pack kernels
+    (fast 16-px path and general path); other dtypes on the host.  All must equal the
+    reference's ``np.invert`` on the raw dtype (cl.py:300-301)."""
+    n = 20 if w < 1000 else 32
+    shape, origin, vs, views = scene(n, 5, "noise", width=w, height=h, fx=0.8 * w, fy=0.8 * w,
+                                     cx=w / 2.0, cy=h / 2.0)
+    grey = [(K, R, t, np.where(m != 0, 255 - (np.arange(m.size).reshape(m.shape) % 3), 0).astype(np.uint8))
+            for K, R, t, m in views]  # values 0, 253, 254, 255: only 255 becomes background
+    for vv, tag in ((grey, "u8"), ([(K, R, t, m != 0) for K, R, t, m in views], "bool"),
+                    ([(K, R, t, m.astype(np.int32)) for K, R, t, m in grey], "i32")):
+        want = oracle_c.carve(shape, origin, vs, [(K, R, t, np.invert(m)) for K, R, t, m in vv])
+        bp = Backprojection(shape, origin, vs)
+        got = bp.process_fileset(files_from_views(vv, "colmap_camera"), "colmap_camera", invert=True)
+        assert np.array_equal(got, want), tag
+        bp.close()
+
+
+def test_decode_workers_do_not_change_results(gpu_device):
+    shape, origin, vs, views = scene(24, 9, "plant")
+    rng = np.random.default_rng(2)
+    fviews = [(K, R, t, (rng.random(m.shape, dtype=np.float32))) for K, R, t, m in views]
+    files = files_from_views(fviews, "colmap_camera")
+    outs = []
+    for workers in (1, 4):
+        bp = Backprojection(shape, origin, vs, type="averaging", decode_workers=workers)
+        outs.append(bp.process_fileset(files, "colmap_camera").copy())
+        bp.close()
+    assert np.array_equal(outs[0], outs[1])  # float sum keeps file order
+    assert np.array_equal(outs[0], oracle_c.average(shape, origin, vs, fviews))
+
+
 def test_odd_image_sizes(gpu_device):
     for (w, h) in ((33, 17), (64, 64), (65, 31), (1, 1), (129, 3)):
         shape, origin, vs, views = scene(20, 4, "noise", width=w, height=h, fx=0.8 * w, fy=0.8 * w,

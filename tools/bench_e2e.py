@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""End-to-end ``process_fileset`` timing (mask ingest -> device).
+
+Writes the S1 scene's masks as PNG files (what a ``Masks`` fileset holds), then times
+``Backprojection.process_fileset`` from PNG files on disk to the volume in host memory:
+
+  serial   decode_workers=1, views_per_launch=1 + a synchronize per view: the reference's
+           schedule (read -> upload -> launch -> queue.finish per view, cl.py:282-303,226)
+  default  decode-ahead threads + deferred fused carve (what the drop-in does)
+
+Both are checked equal.  Prints one JSON line.  Not the headline metric (that is bench.py).
+"""
+import argparse, json, os, sys, tempfile, time
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class PngFile:
+    """Duck-type of a plantdb File whose pixels are decoded from disk on every read."""
+
+    def __init__(self, fid, path, md):
+        self.id, self.path, self._md = fid, path, md
+
+    def get_metadata(self, key=None, default=None):
+        return self._md if key is None else self._md.get(key, default)
+
+    def read_image(self):
+        from PIL import Image
+        with Image.open(self.path) as im:
+            return np.array(im)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--views", type=int, default=72)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    from PIL import Image
+    from plant3dvision_amd import scenes
+    from plant3dvision_amd.cl import Backprojection
+
+    shape, origin, vs, views = scenes.make_scene(a.n, a.views, "plant")
+    tmp = tempfile.mkdtemp(prefix="sc_e2e_")
+    files = []
+    for q, (K, R, t, m) in enumerate(views):
+        path = os.path.join(tmp, f"{q:05d}_mask.png")
+        Image.fromarray(m).save(path, compress_level=1)
+        files.append(PngFile(f"{q:05d}_mask", path, {"colmap_camera": scenes.camera_dict(K, R, t)}))
+    t0 = time.perf_counter()
+    for f in files:
+        f.read_image()
+    t_decode = time.perf_counter() - t0
+
+    class SerialBackprojection(Backprojection):
+        def _submit_view(self, *args, **kw):
+            super()._submit_view(*args, **kw)
+            self.synchronize()  # queue.finish() after every view, cl.py:226
+
+    res = {}
+    vols = {}
+    for name, cls, kw in (("serial", SerialBackprojection, dict(decode_workers=1, views_per_launch=1)),
+                          ("default", Backprojection, dict())):
+        best = None
+        for _ in range(a.reps):
+            bp = cls(shape, origin, vs, **kw)
+            t0 = time.perf_counter()
+            vol = bp.process_fileset(files, "colmap_camera")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            vols[name] = vol.copy()
+            bp.close()
+        res[name] = best
+    assert np.array_equal(vols["serial"], vols["default"])
+    n_vv = int(np.prod(shape)) * len(views)
+    print(json.dumps({"workload": f"{a.n}^3 x {len(views)} PNG masks {views[0][3].shape[1]}x{views[0][3].shape[0]} -> volume in host memory",
+                      "decode_only_s": t_decode, "serial_s": res["serial"], "default_s": res["default"],
+                      "speedup": res["serial"] / res["default"],
+                      "default_Mvoxel_views_per_s": n_vv / res["default"] / 1e6,
+                      "serial_Mvoxel_views_per_s": n_vv / res["serial"] / 1e6,
+                      "host_threads": os.cpu_count()}))
+    for f in files:
+        os.remove(f.path)
+    os.rmdir(tmp)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,16 +27,13 @@ def run(kind, n, V, opts=(), reps=5, vpl=0, label=""):
     e.dev_free(ptr); e.close()
 
 if __name__ == "__main__":
-    run("empty", 512, 6, label="empty masks (all culled)")
-    run("empty", 512, 6, opts=[(10, 0)], label="empty masks, cull off")
+    run("empty", 512, 6, label="empty masks: 1 dense view")
     run("plant", 512, 6, label="plant 6 views")
-    run("plant", 512, 6, opts=[(10, 0)], label="plant 6 views cull off")
     run("plant", 512, 6, opts=[(5, 0)], label="plant 6 views no compaction")
-    run("plant", 512, 2, label="plant 2 views (dense only)")
     run("plant", 512, 1, vpl=1, label="plant 1 view stream fresh")
     run("plant", 512, 72, label="plant 72")
+    run("plant", 512, 72, opts=[(6, 1), (7, 1)], label="plant 72 dense=1 (overflow?)")
     run("solid", 512, 6, label="solid 6 (overflow->resume)")
-    # fill kernel
     shape, origin, vs, _ = scenes.make_scene(512, 1, "empty")
     e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
     e.set_option(nat.SC_OPT_TIME_KERNELS, 1)
