@@ -450,3 +450,59 @@ def test_full_size_512_cubed_72_views_properties(gpu_device):
     assert np.array_equal(fused[ijk[:, 0], ijk[:, 1], ijk[:, 2]], want)
     h = histogram3(fused)
     assert h[2] > 0 and h[0] > 100 * h[2]
+
+
+# -- seeded random geometry ---------------------------------------------------------------------
+def _random_case(rng):
+    """Random grid, free (rolled / tilted / off-centre) cameras, random image size and masks."""
+    shape = [int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 300))]
+    vs = float(rng.choice([0.25, 0.5, 1.0, 1.7]))
+    origin = [float(x) for x in rng.uniform(-50, 50, 3)]
+    centre = np.array(origin) + (np.array(shape) - 1) * vs / 2
+    extent = max(shape) * vs
+    W, H = int(rng.integers(8, 400)), int(rng.integers(8, 300))
+    views = []
+    for _ in range(int(rng.integers(1, 11))):
+        # random camera position on a shell around (or inside) the grid, random roll
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        C = centre + d * extent * rng.uniform(0.2, 3.0)
+        fwd = centre + rng.normal(size=3) * extent * 0.2 - C
+        fwd /= np.linalg.norm(fwd)
+        up = rng.normal(size=3)
+        right = np.cross(up, fwd)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd])
+        t = -R @ C
+        f = rng.uniform(0.3, 3.0) * W
+        K = np.array([f, f * rng.uniform(0.8, 1.25), W * rng.uniform(0.2, 0.8), H * rng.uniform(0.2, 0.8)])
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            m = (rng.random((H, W)) < rng.uniform(0.05, 0.95)).astype(np.uint8) * 255
+        elif kind == 1:  # blobs: coherent regions
+            yy, xx = np.mgrid[0:H, 0:W]
+            m = np.zeros((H, W), dtype=np.uint8)
+            for _ in range(4):
+                cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(2, max(W, H) / 2)
+                m[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = rng.integers(1, 256)
+        else:
+            m = np.full((H, W), 255, dtype=np.uint8)
+        views.append((K.astype(np.float32), R.reshape(9).astype(np.float32), t.astype(np.float32), m))
+    return shape, origin, vs, views
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometry_carve_and_average(gpu_device, seed):
+    rng = np.random.default_rng(1000 + seed)
+    shape, origin, vs, views = _random_case(rng)
+    dv = int(rng.choice([0, 0, 0, 1, -1, 5]))
+    want = oracle_c.carve(shape, origin, vs, views, dv)
+    for vpl, compact in ((0, 1), (0, 0), (1, 1), (2, 1)):
+        got = hip_carve(shape, origin, vs, views, default_value=dv, views_per_launch=vpl, compact=compact)
+        assert np.array_equal(got, want), (seed, vpl, compact, shape, histogram3(want))
+    fviews = [(K, R, t, rng.random(m.shape, dtype=np.float32) - 0.5) for K, R, t, m in views]
+    wantf = oracle_c.average(shape, origin, vs, fviews, default_value=0.5)
+    for vpl in (0, 1):
+        gotf = hip_average(shape, origin, vs, fviews, default_value=0.5, views_per_launch=vpl)
+        assert np.array_equal(gotf.view(np.uint32), wantf.view(np.uint32)), (seed, vpl, shape)
