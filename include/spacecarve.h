@@ -51,6 +51,9 @@ extern "C" {
                               cl.py:300-301 done on the device: foreground = (value != 255)   */
 #define SC_MASK_BOOL_INV 4 /* carve: bool mask (bytes 0/1) to be inverted first (logical not):
                               foreground = (value == 0)                                       */
+#define SC_MASK_U8_LUT 5   /* average: the ORIGINAL uint8 mask; the value added is table[byte],
+                              the table (sc_set_lut) being what the host conversion of
+                              cl.py:205-208 (img_as_float32, log) makes of each byte value      */
 
 /* sc_set_option keys */
 #define SC_OPT_VIEWS_PER_LAUNCH 1 /* 0 (default): defer views, fuse all pending views into one
@@ -112,6 +115,10 @@ void sc_destroy(sc_engine *e);
 int sc_clear(sc_engine *e);
 
 int sc_set_option(sc_engine *e, int key, int64_t value);
+
+/* Averaging engines: the 256-entry float32 table used by SC_MASK_U8_LUT views enqueued
+ * afterwards (views already enqueued are flushed with the previous table). */
+int sc_set_lut(sc_engine *e, const float *lut256);
 
 /* Run the engine's work on an existing hipStream_t (e.g. torch's current stream);
  * NULL restores the engine's own stream. */

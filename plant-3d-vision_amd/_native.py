@@ -21,6 +21,7 @@ SC_OK = 0
 SC_ERR_INVALID, SC_ERR_DEVICE, SC_ERR_NOMEM, SC_ERR_STATE = -1, -2, -3, -4
 SC_MODE_CARVE, SC_MODE_AVERAGE = 0, 1
 SC_MASK_U8, SC_MASK_I32, SC_MASK_F32, SC_MASK_U8_INV, SC_MASK_BOOL_INV = 0, 1, 2, 3, 4
+SC_MASK_U8_LUT = 5
 SC_OPT_VIEWS_PER_LAUNCH, SC_OPT_VIEW_ORDER, SC_OPT_TIME_KERNELS, SC_OPT_MAX_PENDING = 1, 2, 3, 4
 SC_OPT_COMPACT, SC_OPT_DENSE_VIEWS, SC_OPT_STAGE1_VIEWS, SC_OPT_LIST_BLOCKS = 5, 6, 7, 8
 SC_OPT_VIEW_GROUP = 9
@@ -37,6 +38,7 @@ _SIGNATURES = {
     "sc_clear": ("i", ["p"]),
     "sc_set_option": ("i", ["p", "i", "q"]),
     "sc_set_stream": ("i", ["p", "p"]),
+    "sc_set_lut": ("i", ["p", "p"]),
     "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views_device": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i"]),
@@ -222,6 +224,12 @@ class Engine:
     # -- options ----------------------------------------------------------------------
     def set_option(self, key, value):
         self._call("sc_set_option", int(key), int(value))
+
+    def set_lut(self, lut):
+        lut = np.ascontiguousarray(np.asarray(lut, dtype=np.float32).reshape(-1))
+        if lut.size != 256:
+            raise ValueError("the table has 256 entries")
+        self._call("sc_set_lut", addr(lut))
 
     def set_stream(self, stream_ptr):
         self._call("sc_set_stream", int(stream_ptr or 0))

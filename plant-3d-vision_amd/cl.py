@@ -144,6 +144,7 @@ class Backprojection(object):
             self._engine.close()
         self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
                                   default_value=float(self.default_value), device=self.device)
+        self._lut = None
         if self.views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(self.views_per_launch))
         self.values_h = np.ascontiguousarray(
@@ -171,6 +172,20 @@ class Backprojection(object):
         fold = invert and self.dtype == np.int32 and mask.dtype in (np.uint8, np.bool_)
         if invert and not fold:
             mask = np.invert(mask)
+        if self.dtype == np.float32 and mask.dtype == np.uint8:
+            # averaging of a uint8 mask: ship the bytes and let the device look the float up in
+            # a 256-entry table built by the SAME host operations on the 256 byte values (the
+            # conversions are elementwise, so table[mask] == convert(mask) bit for bit)
+            if self._lut is None:
+                lut = img_as_float32(np.arange(256, dtype=np.uint8))  # cl.py:205-206
+                if self.log:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        lut = np.log(EPS + lut)  # cl.py:207-208
+                self._lut = np.ascontiguousarray(lut, dtype=np.float32)
+                self._engine.set_lut(self._lut)
+            self._engine.process_view(intrinsics, rot, tvec, np.ascontiguousarray(mask),
+                                      nat.SC_MASK_U8_LUT)
+            return
         if self.dtype == np.float32 and mask.dtype != np.float32:
             mask = img_as_float32(mask)  # cl.py:205-206
         if self.log and self.dtype == np.float32:

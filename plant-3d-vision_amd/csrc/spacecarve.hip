@@ -499,11 +499,23 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
 }
 
 // average (backprojection.c:36-55): value += mask[v][u] for every in-image view, in the
-// order given (float32 sum, order matters).
+// order given (float32 sum, order matters).  Two mask forms (ViewDesc::pad):
+//   0  float32 [H][W] row-major, the value itself (what cl.py:205-215 hands the kernel);
+//   1  the ORIGINAL uint8 mask in 16x8-pixel tiles (one 128-byte line per tile) plus a
+//      256-entry float table: table[b] is what the host conversion (img_as_float32, log)
+//      makes of byte b, so table[mask] is the same float32 the reference would upload, at
+//      a quarter of the bytes and with tile-coherent gathers.  The table sits in LDS.
+constexpr int kATileW = 16, kATileH = 8;
+
 template <bool FRESH, bool VEC>
 __device__ __forceinline__ void average_body(float *__restrict__ values, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
-                                             float init) {
+                                             float init, const float *__restrict__ lut) {
+    __shared__ float lut_s[256];
+    if (lut != nullptr) {  // block-uniform
+        lut_s[threadIdx.x] = lut[threadIdx.x];  // kBlock == 256
+        __syncthreads();
+    }
     uint32_t lb = spread_block(blockIdx.x, gridDim.x);
     uint64_t grp = (uint64_t)lb * kBlock + threadIdx.x;
     if (grp >= g.ngroups) return;
@@ -530,15 +542,29 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
         float ax = d.R[0] * vx.x + d.R[1] * vx.y;
         float ay = d.R[3] * vx.x + d.R[4] * vx.y;
         float az = d.R[6] * vx.x + d.R[7] * vx.y;
-        const float *m = static_cast<const float *>(d.mask);
         bool ok[4];
         float add[4];
+        if (d.pad == 1) {  // wave-uniform
+            const uint8_t *m = static_cast<const uint8_t *>(d.mask);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int u, v;
-            ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
-            add[e] = 0.0f;
-            if (ok[e]) add[e] = m[(int64_t)v * d.W + u];  // nearest texel
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
+                uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
+                               (uint32_t)((v & 7) * 16 + (u & 15));
+                uint32_t b = 0;
+                if (ok[e]) b = m[off];
+                add[e] = lut_s[b];
+            }
+        } else {
+            const float *m = static_cast<const float *>(d.mask);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
+                add[e] = 0.0f;
+                if (ok[e]) add[e] = m[(int64_t)v * d.W + u];  // nearest texel
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -556,14 +582,40 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
 template <bool FRESH, bool VEC>
 __global__ __launch_bounds__(kBlock) void average_kernel(float *__restrict__ values, GridDesc g,
                                                          const ViewDesc *__restrict__ views,
-                                                         int nviews, float init) {
-    average_body<FRESH, VEC>(values, g, views, nviews, init);
+                                                         int nviews, float init,
+                                                         const float *__restrict__ lut) {
+    average_body<FRESH, VEC>(values, g, views, nviews, init, lut);
 }
 
 template <bool FRESH, bool VEC>
 __global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ values, GridDesc g,
-                                                           ViewDesc view, float init) {
-    average_body<FRESH, VEC>(values, g, &view, 1, init);
+                                                           ViewDesc view, float init,
+                                                           const float *__restrict__ lut) {
+    average_body<FRESH, VEC>(values, g, &view, 1, init, lut);
+}
+
+// uint8 [V][H][W] row-major -> 16x8-pixel tiles (128 B each) for the averaging gather.
+// Fast form: W % 16 == 0 and 16-byte aligned rows -- every lane moves one 16-byte run.
+__global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict__ raw,
+                                                       int64_t row_stride, int64_t view_stride, int W,
+                                                       int H, int nviews, int tiles_x, int tiles_y,
+                                                       uint8_t *__restrict__ out, int fast) {
+    int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int chunks = (W + 15) >> 4;
+    int64_t total = (int64_t)nviews * H * chunks;
+    if (idx >= total) return;
+    int c = (int)(idx % chunks);
+    int64_t r = idx / chunks;
+    int v = (int)(r % H);
+    int view = (int)(r / H);
+    const uint8_t *src = raw + view * view_stride + (int64_t)v * row_stride + c * 16;
+    uint8_t *dst = out + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
+    if (fast) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    } else {
+        int n = min(16, W - c * 16);
+        for (int k = 0; k < n; ++k) dst[k] = src[k];
+    }
 }
 
 // Self-test of the shared-reciprocal division against the compiler's IEEE division.
@@ -756,6 +808,8 @@ struct sc_engine {
     // mask storage for pending views
     std::vector<Chunk> chunks;
 
+    float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
+
     // survivor lists of the fused carve
     uint32_t *lists = nullptr;  // 2 x (kSub * subcap) entries
     ListCtl *ctl = nullptr;
@@ -909,7 +963,8 @@ int ensure_slots(sc_engine *e, size_t bytes) {
 }
 
 size_t elem_size(int dtype) {
-    return (dtype == SC_MASK_U8 || dtype == SC_MASK_U8_INV || dtype == SC_MASK_BOOL_INV) ? 1 : 4;
+    return (dtype == SC_MASK_U8 || dtype == SC_MASK_U8_INV || dtype == SC_MASK_BOOL_INV ||
+            dtype == SC_MASK_U8_LUT) ? 1 : 4;
 }
 
 int check_dtype(const sc_engine *e, int dtype) {
@@ -917,6 +972,10 @@ int check_dtype(const sc_engine *e, int dtype) {
                                      dtype == SC_MASK_U8_INV || dtype == SC_MASK_BOOL_INV))
         return SC_OK;
     if (e->mode == SC_MODE_AVERAGE && dtype == SC_MASK_F32) return SC_OK;
+    if (e->mode == SC_MODE_AVERAGE && dtype == SC_MASK_U8_LUT) {
+        if (!e->lut_dev) return fail(SC_ERR_STATE, "SC_MASK_U8_LUT needs sc_set_lut first");
+        return SC_OK;
+    }
     return fail(SC_ERR_INVALID, "mask dtype %d does not fit engine mode %d", dtype, e->mode);
 }
 
@@ -989,6 +1048,38 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
         ViewDesc d;
         fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
                   static_cast<uint32_t *>(packed) + (size_t)q * words, H, W);
+        e->pending.push_back(d);
+    }
+    return SC_OK;
+}
+
+// averaging, uint8 + table form: raw device bytes [V][H][W] -> 16x8 tiles; appends V pending views
+int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const float *t,
+                  const void *raw_dev, int H, int W, int64_t row_stride, int64_t view_stride) {
+    int tiles_x = (W + kATileW - 1) / kATileW, tiles_y = (H + kATileH - 1) / kATileH;
+    size_t per_view = (size_t)tiles_x * tiles_y * 128;
+    void *tiled = nullptr;
+    int rc = arena_alloc(e, per_view * (size_t)V, &tiled);
+    if (rc) return rc;
+    int fast = (W % 16) == 0 && (row_stride % 16) == 0 && (view_stride % 16) == 0 &&
+               (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
+    int64_t total = (int64_t)V * H * ((W + 15) / 16);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+    LaunchTimer lt{e, SC_KERNEL_PACK};
+    rc = lt.begin();
+    if (rc) return rc;
+    hipLaunchKernelGGL(tile8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                       static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V, tiles_x,
+                       tiles_y, static_cast<uint8_t *>(tiled), fast);
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    for (int q = 0; q < V; ++q) {
+        ViewDesc d;
+        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W);
+        d.tiles_x = tiles_x;
+        d.pad = 1;
         e->pending.push_back(d);
     }
     return SC_OK;
@@ -1158,10 +1249,10 @@ int flush(sc_engine *e, size_t count = 0) {
     do {                                                                                         \
         if (nv == 1)                                                                             \
             hipLaunchKernelGGL((average_kernel_1<F, V>), grid, block, 0, e->stream, st, g, one,  \
-                               e->default_value);                                                \
+                               e->default_value, e->lut_dev);                                    \
         else                                                                                     \
             hipLaunchKernelGGL((average_kernel<F, V>), grid, block, 0, e->stream, st, g, vd,     \
-                               (int)nv, e->default_value);                                       \
+                               (int)nv, e->default_value, e->lut_dev);                           \
     } while (0)
         if (e->fresh) {
             if (vec) LAUNCH_AVG(true, true); else LAUNCH_AVG(true, false);
@@ -1301,6 +1392,7 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl) (void)hipFree(e->ctl);
     if (e->state) (void)hipFree(e->state);
@@ -1360,6 +1452,19 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
     }
 }
 
+int sc_set_lut(sc_engine *e, const float *lut256) {
+    if (!e || !lut256) return fail(SC_ERR_INVALID, "null argument");
+    if (e->mode != SC_MODE_AVERAGE) return fail(SC_ERR_STATE, "the table belongs to averaging engines");
+    int rc = use_device(e);
+    if (rc) return rc;
+    rc = flush(e);  // views already enqueued keep the old table
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->lut_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lut_dev), 256 * sizeof(float)));
+    HIP_TRY(hipMemcpy(e->lut_dev, lut256, 256 * sizeof(float), hipMemcpyHostToDevice));
+    return SC_OK;
+}
+
 int sc_set_stream(sc_engine *e, void *hip_stream) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     int rc = use_device(e);
@@ -1406,6 +1511,12 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
         e->slot_armed[s] = true;
         rc = enqueue_pack(e, 1, K, R, t, e->raw[s], H, W, mask_dtype, (int64_t)row, (int64_t)bytes);
         if (rc) return rc;
+    } else if (mask_dtype == SC_MASK_U8_LUT) {
+        HIP_TRY(hipMemcpyAsync(e->raw[s], e->pin[s], bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->slot_ev[s], e->stream));
+        e->slot_armed[s] = true;
+        rc = enqueue_tile8(e, 1, K, R, t, e->raw[s], H, W, (int64_t)row, (int64_t)bytes);
+        if (rc) return rc;
     } else {
         void *dst = nullptr;
         rc = arena_alloc(e, bytes, &dst);
@@ -1448,6 +1559,11 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
     if (e->mode == SC_MODE_CARVE) {
         // one pack launch for the whole batch, then carve launches per views_per_launch
         rc = enqueue_pack(e, V, K, R, t, masks_dev, H, W, mask_dtype, row, view);
+        if (rc) return rc;
+        return after_enqueue(e);
+    }
+    if (mask_dtype == SC_MASK_U8_LUT) {
+        rc = enqueue_tile8(e, V, K, R, t, masks_dev, H, W, row, view);
         if (rc) return rc;
         return after_enqueue(e);
     }

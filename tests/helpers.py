@@ -36,7 +36,12 @@ class OracleEngine:
     def clear(self):
         self._vol.clear()
 
+    def set_lut(self, lut):
+        self._lut = np.asarray(lut, dtype=np.float32)
+
     def process_view(self, K, R, t, mask, mask_dtype):
+        if mask_dtype == nat.SC_MASK_U8_LUT:
+            mask = self._lut[np.asarray(mask, dtype=np.uint8)]
         if mask_dtype == nat.SC_MASK_U8_INV:      # what the device folds into its bit packing
             mask = np.invert(np.asarray(mask, dtype=np.uint8))
         elif mask_dtype == nat.SC_MASK_BOOL_INV:
@@ -73,6 +78,7 @@ class OracleBackprojection(Backprojection):
     def init_buffers(self):
         self._engine = OracleEngine(self.shape, self.origin, self.voxel_size, self._mode,
                                     default_value=float(self.default_value))
+        self._lut = None
         self.values_h = np.ascontiguousarray(
             self.default_value * np.ones(self.shape, dtype=self.dtype), dtype=self.dtype)
 

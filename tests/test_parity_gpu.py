@@ -280,6 +280,40 @@ def test_average_log_path_uint8_masks(gpu_device):
     assert np.array_equal(vol, oracle_c.average(shape, origin, vs, fviews))
 
 
+@pytest.mark.parametrize("w,h", [(160, 96), (37, 21), (896, 896)])
+@pytest.mark.parametrize("log", [False, True])
+def test_average_uint8_masks_table_path(gpu_device, w, h, log):
+    """uint8 masks in averaging mode travel as bytes + a 256-entry table (SC_MASK_U8_LUT); the
+    result must equal the reference's full-array conversion (img_as_float32, log) bit for bit,
+    for tile-aligned and ragged image sizes, fused and per-view."""
+    n = 20 if w < 800 else 40
+    shape, origin, vs, views = scene(n, 5, "noise", width=w, height=h, fx=0.8 * w, fy=0.8 * w,
+                                     cx=w / 2.0, cy=h / 2.0)
+    rng = np.random.default_rng(w + h)
+    grey = [(K, R, t, rng.integers(0, 256, m.shape, dtype=np.uint8)) for K, R, t, m in views]
+    conv = (lambda m: np.log(EPS + img_as_float32(m))) if log else img_as_float32
+    with np.errstate(divide="ignore"):
+        want = oracle_c.average(shape, origin, vs, [(K, R, t, conv(m)) for K, R, t, m in grey])
+    for vpl in (0, 1):
+        bp = Backprojection(shape, origin, vs, type="averaging", log=log, views_per_launch=vpl)
+        for K, R, t, m in grey:
+            bp.process_view(K, R, t, m)
+        assert np.array_equal(bp.get_values().view(np.uint32), want.view(np.uint32)), (vpl,)
+        bp.close()
+
+
+def test_average_mixed_uint8_and_float_views(gpu_device):
+    shape, origin, vs, views = scene(18, 6, "noise", width=64, height=48, fx=50.0, fy=50.0, cx=32.0, cy=24.0)
+    rng = np.random.default_rng(4)
+    mixed = [(K, R, t, rng.integers(0, 256, m.shape, dtype=np.uint8) if q % 2 else rng.random(m.shape, dtype=np.float32))
+             for q, (K, R, t, m) in enumerate(views)]
+    want = oracle_c.average(shape, origin, vs, [(K, R, t, img_as_float32(m)) for K, R, t, m in mixed])
+    bp = Backprojection(shape, origin, vs, type="averaging", log=False)
+    for K, R, t, m in mixed:
+        bp.process_view(K, R, t, m)
+    assert np.array_equal(bp.get_values(), want)
+
+
 def test_process_fileset_with_labels(gpu_device):
     shape, origin, vs, views = scene(16, 3, "plant")
     stem = files_from_views(views, "camera", channel="stem")
