@@ -176,6 +176,23 @@ int sc_reset_kernel_stats(sc_engine *e);
 int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                          uint64_t *mismatches, uint64_t *fast_pairs);
 
+/*
+ * The carve's immediate consumer: plant3dvision/proc3d.py::vol2pcd (:490-570, called by
+ * tasks/proc3d.py:134) on the GPU.  volume: host pointer, or device pointer on `device` when
+ * on_device != 0 (e.g. sc_values_device_ptr: the volume then never crosses PCIe); dtype 0 int32,
+ * 1 float32, 2 float64, 3 uint8; C-order [nx][ny][nz].  gauss_w: the 5 distinct weights of
+ * scipy's radius-4 Gaussian kernel (centre first), computed by the host as scipy does.
+ * Returns malloc'ed float64 arrays [count][3] (release with sc_free_host): points in world
+ * coordinates and unit normals, in C-order of the shell voxels; voxels whose gradient is zero
+ * carry NaNs (the reference drops them afterwards, proc3d.py:559-561).
+ */
+int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t ny, int64_t nz,
+               const double origin[3], double voxel_size, double level_set_value,
+               const double gauss_w[5], int device, double **points_out, double **normals_out,
+               int64_t *count);
+const char *sc_vol2pcd_last_error(void);
+void sc_free_host(void *p);
+
 /* Device-memory helpers so that hosts without a HIP binding can stage inputs in HBM
  * (bench.py, tests): plain hipMalloc / hipMemcpy / hipFree on the engine's device. */
 int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr);

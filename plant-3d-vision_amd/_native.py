@@ -50,6 +50,9 @@ _SIGNATURES = {
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
+    "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
+    "sc_vol2pcd_last_error": ("s", []),
+    "sc_free_host": ("v", ["p"]),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
     "sc_dev_free": ("i", ["p", "p"]),
     "sc_dev_upload": ("i", ["p", "p", "p", "q"]),
@@ -58,9 +61,9 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float,
-       "I": ctypes.c_uint32,
+       "I": ctypes.c_uint32, "d": ctypes.c_double,
        "s": ctypes.c_char_p, "v": None}
-_CDEF = {"p": "void *", "i": "int", "q": "int64_t", "f": "float", "s": "const char *", "I": "uint32_t",
+_CDEF = {"p": "void *", "i": "int", "q": "int64_t", "f": "float", "s": "const char *", "I": "uint32_t", "d": "double",
          "v": "void"}
 
 

@@ -13,3 +13,96 @@ def point2index(points, origin, voxel_size):
     """Nxd points -> Nxd integer indices, rounded to nearest (proc3d.py:48-65)."""
     return np.array(np.round((np.asarray(points) - np.asarray(origin)[np.newaxis, :]) / voxel_size),
                     dtype=int)
+
+
+class PointCloud:
+    """What ``vol2pcd`` returns where open3d is absent: ``points`` and ``normals`` as float64
+    ``[n, 3]`` arrays (the two attributes the reference's callers read from the open3d object)."""
+
+    def __init__(self, points, normals):
+        self.points = points
+        self.normals = normals
+
+    def __len__(self):
+        return len(self.points)
+
+
+def gaussian_weights(sigma=1.0, truncate=4.0):
+    """The weights ``scipy.ndimage.gaussian_filter`` uses (``_gaussian_kernel1d``): radius
+    ``int(truncate*sigma + 0.5)``, ``exp(-0.5/sigma^2 * x^2)`` normalised by its sum.  Returns
+    the distinct half, centre first."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:], dtype=np.float64)
+
+
+def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=True):
+    """Converts a volume into a point-cloud with normals, on the GPU
+    (``plant3dvision/proc3d.py:490-570``; same signature, ``device`` / ``as_open3d`` added).
+
+    ``volume`` may be a NumPy array (int32 / float32 / float64 / uint8, C-order) or a
+    ``Backprojection`` whose device-resident volume is used in place -- the 4N-byte grid then
+    never crosses PCIe, only the shell's points and normals come back.
+    Returns an ``open3d.geometry.PointCloud`` when open3d is importable (and ``as_open3d``),
+    else a :class:`PointCloud` with the same ``points`` / ``normals``.
+    """
+    import ctypes
+
+    from . import _native as nat
+
+    b = nat.backend()
+    codes = {np.dtype(np.int32): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.uint8): 3}
+    keep = None
+    if hasattr(volume, "_engine") and hasattr(volume, "shape"):  # a Backprojection: use its state in place
+        bp = volume
+        ptr = bp._engine.values_device_ptr()
+        bp._engine.synchronize()
+        shape = [int(s) for s in bp.shape]
+        code, on_device, device = codes[np.dtype(bp.dtype)], 1, bp.device
+    else:
+        vol = np.asarray(volume)
+        if vol.ndim != 3:
+            raise ValueError("volume must be 3-D")
+        if vol.dtype == np.bool_:
+            vol = vol.view(np.uint8)
+        if vol.dtype not in codes:
+            vol = vol.astype(np.float64)
+        keep = np.ascontiguousarray(vol)
+        ptr, shape, code, on_device = nat.addr(keep), list(keep.shape), codes[keep.dtype], 0
+    origin64 = np.ascontiguousarray(np.asarray(origin, dtype=np.float64).reshape(3))
+    gw = gaussian_weights(1.0)
+    assert gw.size == 5
+    out = np.zeros(2, dtype=np.uintp)
+    cnt = np.zeros(1, dtype=np.int64)
+    rc = b.call("sc_vol2pcd", ptr, on_device, code, shape[0], shape[1], shape[2], nat.addr(origin64),
+                float(voxel_size), float(level_set_value), nat.addr(gw), int(device), nat.addr(out),
+                nat.addr(out) + 8, nat.addr(cnt))
+    if rc != 0:
+        msg = b.string(b.call("sc_vol2pcd_last_error"))
+        if rc == nat.SC_ERR_INVALID:
+            raise ValueError(f"sc_vol2pcd: {msg}")
+        raise nat.SpaceCarveError(f"sc_vol2pcd: {msg} (code {rc})")
+    n = int(cnt[0])
+    if n:
+        pts = np.ctypeslib.as_array((ctypes.c_double * (3 * n)).from_address(int(out[0]))).reshape(n, 3).copy()
+        nrm = np.ctypeslib.as_array((ctypes.c_double * (3 * n)).from_address(int(out[1]))).reshape(n, 3).copy()
+        b.call("sc_free_host", int(out[0]))
+        b.call("sc_free_host", int(out[1]))
+    else:
+        pts = np.zeros((0, 3))
+        nrm = np.zeros((0, 3))
+    ok = ~np.isnan(nrm).any(axis=1)  # proc3d.py:559-561: keep points with a positive gradient norm
+    pts, nrm = pts[ok], nrm[ok]
+    if as_open3d:
+        try:
+            import open3d as o3d  # type: ignore
+        except ImportError:
+            o3d = None
+        if o3d is not None:
+            pcd = o3d.geometry.PointCloud()
+            pcd.points = o3d.utility.Vector3dVector(pts)
+            pcd.normals = o3d.utility.Vector3dVector(nrm)
+            return pcd
+    return PointCloud(pts, nrm)

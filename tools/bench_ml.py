@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BASELINE cfg 5 in outline: stand-in segmentation network (PyTorch-ROCm) -> per-label masks ->
+512^3 volume, everything on one MI355X, masks never leaving HBM.  Prints one JSON line.
+The network is a seeded stand-in (romiseg and its weights are not vendored): the number that
+matters is the mask -> volume part."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--views", type=int, default=72)
+    ap.add_argument("--size", type=int, default=896)
+    ap.add_argument("--type", default="averaging")
+    a = ap.parse_args()
+    import torch
+    from plant3dvision_amd import masks2d, scenes
+    labels = ["background", "flower", "fruit", "leaf", "pedicel", "stem"]
+    S = a.size
+    shape, origin, vs, views = scenes.make_scene(a.n, a.views, "solid", width=S, height=S, fx=0.8 * S, fy=0.8 * S, cx=S / 2, cy=S / 2)
+    cams = [scenes.camera_dict(K, R, t) for K, R, t, _ in views]
+    torch.manual_seed(0)
+    coarse = torch.rand(a.views, 3, 14, 14, device="cuda")
+    images = torch.nn.functional.interpolate(coarse, size=(S, S), mode="bilinear", align_corners=False)
+    net = masks2d.StandInSegmenter(labels, seed=1)
+    def sync(): torch.cuda.synchronize()
+    res = {}
+    for it in range(2):  # first pass warms up
+        sync(); t0 = time.perf_counter()
+        pred = torch.cat([net(images[i:i + 8]) for i in range(0, a.views, 8)])
+        sync(); t1 = time.perf_counter()
+        thr = 0.3
+        masks = masks2d.masks_from_predictions(pred, labels, labels=["background"], threshold=thr, dilation=1)
+        sync(); t2 = time.perf_counter()
+        vols = masks2d.voxels_from_masks(masks, cams, shape, origin, vs, type=a.type, log=False)
+        t3 = time.perf_counter()
+        res = {"network_s": t1 - t0, "masks_s": t2 - t1, "volume_incl_readback_s": t3 - t2}
+    v = vols["background"]
+    nvv = int(np.prod(shape)) * a.views
+    res.update({"workload": f"{a.views} images {S}x{S} -> stand-in net (6 labels) -> label 'background' -> {a.n}^3 {a.type} volume in host memory",
+                "mask_to_volume_Mvoxel_views_per_s": nvv / res["volume_incl_readback_s"] / 1e6,
+                "volume_min_max": [float(v.min()), float(v.max())]})
+    print(json.dumps(res))
+
+if __name__ == "__main__":
+    main()
