@@ -193,6 +193,18 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
 const char *sc_vol2pcd_last_error(void);
 void sc_free_host(void *p);
 
+/*
+ * SegmentedPointCloud's scoring loop (plant3dvision/tasks/proc3d.py:203-232 over
+ * proc3d.py::backproject_points :655-659) on the GPU: P float64 points, V views (K[V][4] =
+ * fx,fy,cx,cy, R[V][9], t[V][3], float64), L label images per view, masks uint8 [L][V][H][W]
+ * (host, or device when masks_on_device != 0).  Writes scores_out [L][P] (float64 sums of mask
+ * values at int(pixel + 0.5)) and labels_out [P] = arg-max over labels (first maximum).
+ */
+int sc_label_points(const double *points, int64_t P, int L, int V, const double *K, const double *R,
+                    const double *t, const void *masks, int masks_on_device, int H, int W, int device,
+                    double *scores_out, int32_t *labels_out);
+const char *sc_label_points_last_error(void);
+
 /* Device-memory helpers so that hosts without a HIP binding can stage inputs in HBM
  * (bench.py, tests): plain hipMalloc / hipMemcpy / hipFree on the engine's device. */
 int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr);

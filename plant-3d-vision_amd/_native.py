@@ -53,6 +53,8 @@ _SIGNATURES = {
     "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_vol2pcd_last_error": ("s", []),
     "sc_free_host": ("v", ["p"]),
+    "sc_label_points": ("i", ["p", "q", "i", "i", "p", "p", "p", "p", "i", "i", "i", "i", "p", "p"]),
+    "sc_label_points_last_error": ("s", []),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
     "sc_dev_free": ("i", ["p", "p"]),
     "sc_dev_upload": ("i", ["p", "p", "p", "q"]),

@@ -106,3 +106,57 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
             pcd.normals = o3d.utility.Vector3dVector(nrm)
             return pcd
     return PointCloud(pts, nrm)
+
+
+def backproject_points(points, K, rot, tvec):
+    """``plant3dvision/proc3d.py:655-659`` (host, NumPy): pixel coordinates of 3-D points."""
+    x = rot @ points.transpose() + tvec[:, np.newaxis]
+    x = K @ x
+    x = x / x[2, :][np.newaxis, :]
+    return x[:2, :].transpose()
+
+
+def label_points(points, cameras, masks, device=0):
+    """The scoring loop of ``SegmentedPointCloud.run`` (``tasks/proc3d.py:203-232``) on the GPU.
+
+    points  : ``[P, 3]`` float64 (``np.asarray(pcd.points)``)
+    cameras : list of V camera dicts (``colmap_camera`` / ``camera`` metadata schema)
+    masks   : uint8 ``[L, V, H, W]`` -- NumPy array, or a CUDA torch tensor (e.g. stacked
+              ``masks2d.masks_from_predictions`` output) used in place
+    Returns ``(labels int32 [P], scores float64 [L, P])``; ``labels[i]`` indexes the L labels in
+    the order given (the reference iterates a Python ``set``; fix the order yourself).
+    """
+    from . import _native as nat
+
+    b = nat.backend()
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    P = pts.shape[0]
+    V = len(cameras)
+    K = np.ascontiguousarray(np.array([c["camera_model"]["params"][0:4] for c in cameras], dtype=np.float64).reshape(V, 4))
+    R = np.ascontiguousarray(np.array([c["rotmat"] for c in cameras], dtype=np.float64).reshape(V, 9))
+    t = np.ascontiguousarray(np.array([c["tvec"] for c in cameras], dtype=np.float64).reshape(V, 3))
+    if hasattr(masks, "data_ptr"):  # torch tensor on the device
+        import torch
+        if masks.dtype != torch.uint8 or masks.dim() != 4 or not masks.is_contiguous() or not masks.is_cuda:
+            raise ValueError("device masks must be a contiguous uint8 CUDA tensor [L, V, H, W]")
+        torch.cuda.current_stream(masks.device.index).synchronize()
+        L, Vm, H, W = (int(s) for s in masks.shape)
+        mptr, on_dev, device = masks.data_ptr(), 1, masks.device.index
+    else:
+        m = np.ascontiguousarray(np.asarray(masks))
+        if m.dtype != np.uint8 or m.ndim != 4:
+            raise ValueError("masks must be uint8 [L, V, H, W]")
+        L, Vm, H, W = m.shape
+        mptr, on_dev = nat.addr(m), 0
+    if Vm != V:
+        raise ValueError("one camera per view")
+    scores = np.zeros((L, P), dtype=np.float64)
+    labels = np.zeros(P, dtype=np.int32)
+    rc = b.call("sc_label_points", nat.addr(pts), P, L, V, nat.addr(K), nat.addr(R), nat.addr(t), mptr, on_dev,
+                H, W, int(device), nat.addr(scores), nat.addr(labels))
+    if rc != 0:
+        msg = b.string(b.call("sc_label_points_last_error"))
+        if rc == nat.SC_ERR_INVALID:
+            raise ValueError(f"sc_label_points: {msg}")
+        raise nat.SpaceCarveError(f"sc_label_points: {msg} (code {rc})")
+    return labels, scores
