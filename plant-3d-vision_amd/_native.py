@@ -7,8 +7,10 @@ type.  There is no CPU fallback: if the library is missing or no gfx950 device i
 visible, calls raise.
 """
 import ctypes
+import importlib.util
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -130,6 +132,28 @@ class _CffiBackend:
 _backend = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own ``libamdhip64.so`` (same SONAME as
+    /opt/rocm's); whichever is loaded first serves everybody, and torch fails if that is not its
+    own.  So when torch is installed but not imported yet, load ITS runtime before our library:
+    device pointers, streams and RCCL then work across torch and the engine in either import
+    order.  Without torch the system ROCm runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(lib):
+        try:
+            ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def backend():
     """Load the library once.  Raises ``SpaceCarveError`` if it is not built."""
     global _backend
@@ -139,6 +163,7 @@ def backend():
         raise SpaceCarveError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C plant-3d-vision_amd/csrc` (needs hipcc, gfx950)")
+    _preload_hip_runtime()
     want = os.environ.get("SPACECARVE_FFI", "").lower()
     if want not in ("", "cffi", "ctypes"):
         raise ValueError("SPACECARVE_FFI must be 'cffi' or 'ctypes'")

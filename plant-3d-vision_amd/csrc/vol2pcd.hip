@@ -34,8 +34,26 @@ namespace {
 
 constexpr int kB = 256;
 constexpr uint32_t kFar = 0xffffu;
+constexpr int kBlk = 8;  // activity is tracked per 8x8x8 block of voxels
 
-int fail_v(int code, const char *msg);  // defined below (thread-local message via spacecarve.hip)
+int fail_v(int code, const char *msg);  // defined below
+
+// Geometry shared by the per-voxel kernels: one thread per voxel, threads along z,
+// blockIdx.y = y, blockIdx.z = x (no divisions), plus the block-activity map.
+struct Vol {
+    int nx, ny, nz;
+    int nby, nbz;            // blocks along y and z
+    const uint8_t *active;   // [nbx][nby][nbz], 1 = within reach of the surface
+};
+
+__device__ __forceinline__ bool voxel(const Vol &v, int &x, int &y, int &z, int64_t &i) {
+    x = blockIdx.z;
+    y = blockIdx.y;
+    z = blockIdx.x * kB + threadIdx.x;
+    if (z >= v.nz) return false;
+    i = ((int64_t)x * v.ny + y) * v.nz + z;
+    return v.active[((int64_t)(x / kBlk) * v.nby + (y / kBlk)) * v.nbz + (z / kBlk)] != 0;
+}
 
 template <typename T>
 __global__ __launch_bounds__(kB) void occ_kernel(const T *__restrict__ vol, uint8_t *__restrict__ occ,
@@ -44,33 +62,79 @@ __global__ __launch_bounds__(kB) void occ_kernel(const T *__restrict__ vol, uint
     if (i < n) occ[i] = (double)vol[i] > 0.5 ? 1 : 0;  // proc3d.py:515
 }
 
+// per 8^3 block: bit 0 = holds a foreground voxel, bit 1 = holds a background voxel
+__global__ __launch_bounds__(kB) void block_class_kernel(const uint8_t *__restrict__ occ, int nx, int ny,
+                                                         int nz, int nbx, int nby, int nbz,
+                                                         uint8_t *__restrict__ cls) {
+    int64_t b = (int64_t)blockIdx.x * kB + threadIdx.x;
+    if (b >= (int64_t)nbx * nby * nbz) return;
+    int bz = (int)(b % nbz), by = (int)((b / nbz) % nby), bx = (int)(b / ((int64_t)nbz * nby));
+    uint32_t fg = 0, bg = 0;
+    for (int dx = 0; dx < kBlk; ++dx) {
+        int x = bx * kBlk + dx;
+        if (x >= nx) break;
+        for (int dy = 0; dy < kBlk; ++dy) {
+            int y = by * kBlk + dy;
+            if (y >= ny) break;
+            const uint8_t *row = occ + ((int64_t)x * ny + y) * nz;
+            for (int dz = 0; dz < kBlk; ++dz) {
+                int z = bz * kBlk + dz;
+                if (z >= nz) break;
+                uint8_t o = row[z];
+                fg |= o;
+                bg |= (uint8_t)(o ^ 1);
+            }
+        }
+    }
+    cls[b] = (uint8_t)(fg | (bg << 1));
+}
+
+// A voxel can matter only if a voxel of the other class lies within R of it.  Block-level,
+// conservative: the block holds class c and some block within rb = ceil(R/8) blocks holds the
+// other class.
+__global__ __launch_bounds__(kB) void block_active_kernel(const uint8_t *__restrict__ cls, int nbx, int nby,
+                                                          int nbz, int rb, uint8_t *__restrict__ active) {
+    int64_t b = (int64_t)blockIdx.x * kB + threadIdx.x;
+    if (b >= (int64_t)nbx * nby * nbz) return;
+    int bz = (int)(b % nbz), by = (int)((b / nbz) % nby), bx = (int)(b / ((int64_t)nbz * nby));
+    uint32_t near = 0;
+    for (int x = max(0, bx - rb); x <= min(nbx - 1, bx + rb); ++x)
+        for (int y = max(0, by - rb); y <= min(nby - 1, by + rb); ++y)
+            for (int z = max(0, bz - rb); z <= min(nbz - 1, bz + rb); ++z)
+                near |= cls[((int64_t)x * nby + y) * nbz + z];
+    uint32_t own = cls[b];
+    // own has fg and a bg block is near, or own has bg and an fg block is near
+    active[b] = (uint8_t)((((own & 1u) && (near & 2u)) || ((own & 2u) && (near & 1u))) ? 1 : 0);
+}
+
 // EDT pass along z (the contiguous axis).  Two channels per voxel, packed lo/hi 16 bits:
 // A = squared distance to the nearest BACKGROUND voxel of the line, B = to the nearest FOREGROUND
 // voxel; a voxel's own class gives 0 in the other channel.  Exact up to R, kFar beyond.
+// Inactive voxels keep the (far, far) the buffers are pre-filled with: no active voxel of the
+// other class lies within R of them, so they are never anybody's nearest site.
 __global__ __launch_bounds__(kB) void edt_z_kernel(const uint8_t *__restrict__ occ,
-                                                   uint32_t *__restrict__ g, int64_t n, int nz, int R) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i >= n) return;
-    int k = (int)(i % nz);
+                                                   uint32_t *__restrict__ g, Vol v, int R) {
+    int x, y, k;
+    int64_t i;
+    if (!voxel(v, x, y, k, i)) return;
     uint8_t c = occ[i];
     uint32_t best = kFar;
     for (int d = 1; d <= R; ++d) {
-        bool hit = (k - d >= 0 && occ[i - d] != c) || (k + d < nz && occ[i + d] != c);
+        bool hit = (k - d >= 0 && occ[i - d] != c) || (k + d < v.nz && occ[i + d] != c);
         if (hit) { best = (uint32_t)(d * d); break; }
     }
-    g[i] = c ? (best | 0u << 16) : (0u | best << 16);  // fg: A=best,B=0 ; bg: A=0,B=best
+    g[i] = c ? best : (best << 16);  // fg: A=best,B=0 ; bg: A=0,B=best
 }
 
-// EDT pass along an axis of stride `stride` and length `len`: both channels,
-// H(p) = min_j ( j^2 + G(p + j*stride) ), |j| <= R.
-__global__ __launch_bounds__(kB) void edt_axis_kernel(const uint32_t *__restrict__ g,
-                                                      uint32_t *__restrict__ h, int64_t n,
-                                                      int64_t stride, int len, int R) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i >= n) return;
-    int p = (int)((i / stride) % len);
-    uint32_t v = g[i];
-    uint32_t a = v & 0xffffu, b = v >> 16;
+// EDT pass along y: both channels,  H(p) = min_j ( j^2 + G(p + j*stride) ), |j| <= R.
+__global__ __launch_bounds__(kB) void edt_y_kernel(const uint32_t *__restrict__ g,
+                                                   uint32_t *__restrict__ h, Vol v, int R) {
+    int x, p, z;
+    int64_t i;
+    if (!voxel(v, x, p, z, i)) return;
+    const int64_t stride = v.nz;
+    uint32_t w0 = g[i];
+    uint32_t a = w0 & 0xffffu, b = w0 >> 16;
     for (int j = 1; j <= R; ++j) {
         uint32_t jj = (uint32_t)(j * j);
         if (jj >= a && jj >= b) break;  // nothing farther can improve either channel
@@ -79,7 +143,7 @@ __global__ __launch_bounds__(kB) void edt_axis_kernel(const uint32_t *__restrict
             a = min(a, (w & 0xffffu) + jj);
             b = min(b, (w >> 16) + jj);
         }
-        if (p + j < len) {
+        if (p + j < v.ny) {
             uint32_t w = g[i + j * stride];
             a = min(a, (w & 0xffffu) + jj);
             b = min(b, (w >> 16) + jj);
@@ -90,13 +154,13 @@ __global__ __launch_bounds__(kB) void edt_axis_kernel(const uint32_t *__restrict
 
 // last EDT pass (along x) fused with the signed distance of proc3d.py:518-522:
 //   dist = where(dist > 0.5, dist - 0.5, -mdist + 0.5)
-__global__ __launch_bounds__(kB) void edt_final_kernel(const uint32_t *__restrict__ g,
-                                                       const uint8_t *__restrict__ occ,
-                                                       double *__restrict__ sd, int64_t n,
-                                                       int64_t stride, int len, int R) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i >= n) return;
-    int p = (int)((i / stride) % len);
+__global__ __launch_bounds__(kB) void edt_x_kernel(const uint32_t *__restrict__ g,
+                                                   const uint8_t *__restrict__ occ,
+                                                   double *__restrict__ sd, Vol v, int R) {
+    int p, y, z;
+    int64_t i;
+    if (!voxel(v, p, y, z, i)) return;
+    const int64_t stride = (int64_t)v.ny * v.nz;
     bool fg = occ[i] != 0;
     int sh = fg ? 0 : 16;
     uint32_t a = (g[i] >> sh) & 0xffffu;
@@ -104,19 +168,22 @@ __global__ __launch_bounds__(kB) void edt_final_kernel(const uint32_t *__restric
         uint32_t jj = (uint32_t)(j * j);
         if (jj >= a) break;
         if (p - j >= 0) a = min(a, ((g[i - j * stride] >> sh) & 0xffffu) + jj);
-        if (p + j < len) a = min(a, ((g[i + j * stride] >> sh) & 0xffffu) + jj);
+        if (p + j < v.nx) a = min(a, ((g[i + j * stride] >> sh) & 0xffffu) + jj);
     }
     double d = sqrt((double)a);  // exact integer in, correctly rounded sqrt
     sd[i] = fg ? d - 0.5 : -d + 0.5;
 }
 
 // np.gradient along one axis (unit spacing, edge_order 1)
+template <int AXIS>
 __global__ __launch_bounds__(kB) void gradient_kernel(const double *__restrict__ f,
-                                                      double *__restrict__ out, int64_t n,
-                                                      int64_t stride, int len) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i >= n) return;
-    int p = (int)((i / stride) % len);
+                                                      double *__restrict__ out, Vol v) {
+    int x, y, z;
+    int64_t i;
+    if (!voxel(v, x, y, z, i)) return;
+    const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
+    const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
+    const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
     double r;
     if (p == 0) r = f[i + stride] - f[i];
     else if (p == len - 1) r = f[i] - f[i - stride];
@@ -134,11 +201,15 @@ __device__ __forceinline__ int reflect_index(int q, int len) {  // scipy "reflec
 struct GaussW { double w[5]; };  // w[0] centre .. w[4] farthest
 
 // scipy.ndimage.correlate1d, symmetric branch, radius 4, along one axis
+template <int AXIS>
 __global__ __launch_bounds__(kB) void gauss_kernel(const double *__restrict__ f, double *__restrict__ out,
-                                                   int64_t n, int64_t stride, int len, GaussW gw) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i >= n) return;
-    int p = (int)((i / stride) % len);
+                                                   Vol v, GaussW gw) {
+    int x, y, z;
+    int64_t i;
+    if (!voxel(v, x, y, z, i)) return;
+    const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
+    const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
+    const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
     int64_t base = i - (int64_t)p * stride;
     double tmp = f[i] * gw.w[0];
     if (p >= 4 && p + 4 < len) {
@@ -262,6 +333,7 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     if (!volume || !origin || !gauss_w || !points_out || !normals_out || !count)
         return fail_v(SC_ERR_INVALID, "null argument");
     if (nx < 2 || ny < 2 || nz < 2) return fail_v(SC_ERR_INVALID, "np.gradient needs at least 2 voxels per axis");
+    if (nx > 65535 || ny > 65535) return fail_v(SC_ERR_INVALID, "x and y are limited to 65535 voxels");
     if (dtype < 0 || dtype > 3) return fail_v(SC_ERR_INVALID, "volume dtype: 0 int32, 1 float32, 2 float64, 3 uint8");
     if (!(std::fabs(level_set_value) < 200.0)) return fail_v(SC_ERR_INVALID, "level_set_value out of range");
     *points_out = *normals_out = nullptr;
@@ -270,24 +342,53 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 4 : dtype == 2 ? 8 : 1;
     // what can reach a shell voxel: |d| <= |lsv| + sqrt(3) there, gradient 1 + Gaussian 4 per axis
     const int R = (int)std::ceil(std::fabs(level_set_value) + 1.7321 + 5.0 * 1.7321 + 3.0);
+    const int rb = (R + kBlk - 1) / kBlk;
+    const int nbx = (int)((nx + kBlk - 1) / kBlk), nby = (int)((ny + kBlk - 1) / kBlk),
+              nbz = (int)((nz + kBlk - 1) / kBlk);
+    const int64_t nb = (int64_t)nbx * nby * nbz;
+    const uint32_t nchunks = (uint32_t)((n + kChunk - 1) / kChunk);
+    const double lo = -level_set_value, hi = -level_set_value + std::sqrt(3.0);
     int rc = SC_OK;
     void *vol_d = nullptr;
-    uint8_t *occ = nullptr;
-    uint32_t *g0 = nullptr, *g1 = nullptr, *counts = nullptr;
-    uint64_t *offs_d = nullptr;
-    double *sd = nullptr, *ga = nullptr, *gb = nullptr, *gx = nullptr, *gy = nullptr, *gz = nullptr;
+    char *scratch = nullptr;
     double *pts_d = nullptr, *nrm_d = nullptr;
     std::vector<uint32_t> hc;
     std::vector<uint64_t> ho;
-    const uint32_t nchunks = (uint32_t)((n + kChunk - 1) / kChunk);
-    const double lo = -level_set_value, hi = -level_set_value + std::sqrt(3.0);
     GaussW gw;
     memcpy(gw.w, gauss_w, sizeof gw.w);
     uint64_t total = 0;
     hipStream_t st = nullptr;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // one scratch allocation: occ | cls | active | counts | offsets | sd | A (g0,g1 then ga) | gb | gx | gy | gz
+    const size_t o_occ = 0, o_cls = o_occ + al((size_t)n), o_act = o_cls + al((size_t)nb),
+                 o_cnt = o_act + al((size_t)nb), o_off = o_cnt + al((size_t)nchunks * 4),
+                 o_sd = o_off + al((size_t)nchunks * 8), o_a = o_sd + al((size_t)n * 8),
+                 o_b = o_a + al((size_t)n * 8), o_gx = o_b + al((size_t)n * 8),
+                 o_gy = o_gx + al((size_t)n * 8), o_gz = o_gy + al((size_t)n * 8),
+                 bytes = o_gz + al((size_t)n * 8);
+    uint8_t *occ, *cls, *act;
+    uint32_t *counts, *g0, *g1;
+    uint64_t *offs_d;
+    double *sd, *ga, *gb, *gx, *gy, *gz;
+    Vol v;
+    dim3 grid((uint32_t)((nz + kB - 1) / kB), (uint32_t)ny, (uint32_t)nx), block(kB);
 
     V_TRY(hipSetDevice(device));
-    V_TRY(hipMalloc(&occ, (size_t)n));
+    V_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), bytes));
+    occ = reinterpret_cast<uint8_t *>(scratch + o_occ);
+    cls = reinterpret_cast<uint8_t *>(scratch + o_cls);
+    act = reinterpret_cast<uint8_t *>(scratch + o_act);
+    counts = reinterpret_cast<uint32_t *>(scratch + o_cnt);
+    offs_d = reinterpret_cast<uint64_t *>(scratch + o_off);
+    sd = reinterpret_cast<double *>(scratch + o_sd);
+    ga = reinterpret_cast<double *>(scratch + o_a);
+    g0 = reinterpret_cast<uint32_t *>(scratch + o_a);
+    g1 = g0 + n;
+    gb = reinterpret_cast<double *>(scratch + o_b);
+    gx = reinterpret_cast<double *>(scratch + o_gx);
+    gy = reinterpret_cast<double *>(scratch + o_gy);
+    gz = reinterpret_cast<double *>(scratch + o_gz);
+    v = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act};
     if (on_device) {
         vol_d = const_cast<void *>(volume);
     } else {
@@ -295,55 +396,45 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
         V_TRY(hipMemcpy(vol_d, volume, (size_t)n * esz, hipMemcpyHostToDevice));
     }
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(occ_kernel<int32_t>, dim3(blocks_for(n)), dim3(kB), 0, st, (const int32_t *)vol_d, occ, n); break;
-        case 1: hipLaunchKernelGGL(occ_kernel<float>, dim3(blocks_for(n)), dim3(kB), 0, st, (const float *)vol_d, occ, n); break;
-        case 2: hipLaunchKernelGGL(occ_kernel<double>, dim3(blocks_for(n)), dim3(kB), 0, st, (const double *)vol_d, occ, n); break;
-        default: hipLaunchKernelGGL(occ_kernel<uint8_t>, dim3(blocks_for(n)), dim3(kB), 0, st, (const uint8_t *)vol_d, occ, n); break;
+        case 0: hipLaunchKernelGGL(occ_kernel<int32_t>, dim3(blocks_for(n)), block, 0, st, (const int32_t *)vol_d, occ, n); break;
+        case 1: hipLaunchKernelGGL(occ_kernel<float>, dim3(blocks_for(n)), block, 0, st, (const float *)vol_d, occ, n); break;
+        case 2: hipLaunchKernelGGL(occ_kernel<double>, dim3(blocks_for(n)), block, 0, st, (const double *)vol_d, occ, n); break;
+        default: hipLaunchKernelGGL(occ_kernel<uint8_t>, dim3(blocks_for(n)), block, 0, st, (const uint8_t *)vol_d, occ, n); break;
     }
+    hipLaunchKernelGGL(block_class_kernel, dim3(blocks_for(nb)), block, 0, st, occ, (int)nx, (int)ny, (int)nz, nbx, nby, nbz, cls);
+    hipLaunchKernelGGL(block_active_kernel, dim3(blocks_for(nb)), block, 0, st, cls, nbx, nby, nbz, rb, act);
+    // inactive voxels: (far, far) in both EDT buffers, NaN signed distance (never on the shell)
+    V_TRY(hipMemsetAsync(g0, 0xff, (size_t)n * 8, st));
+    V_TRY(hipMemsetAsync(sd, 0xff, (size_t)n * 8, st));
+    hipLaunchKernelGGL(edt_z_kernel, grid, block, 0, st, occ, g0, v, R);
+    hipLaunchKernelGGL(edt_y_kernel, grid, block, 0, st, g0, g1, v, R);
+    hipLaunchKernelGGL(edt_x_kernel, grid, block, 0, st, g1, occ, sd, v, R);
     V_TRY(hipGetLastError());
-    V_TRY(hipMalloc(&g0, (size_t)n * 4));
-    V_TRY(hipMalloc(&g1, (size_t)n * 4));
-    V_TRY(hipMalloc(&sd, (size_t)n * 8));
-    hipLaunchKernelGGL(edt_z_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, occ, g0, n, (int)nz, R);
-    hipLaunchKernelGGL(edt_axis_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, g0, g1, n, (int64_t)nz, (int)ny, R);
-    hipLaunchKernelGGL(edt_final_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, g1, occ, sd, n, (int64_t)ny * nz, (int)nx, R);
+    // gradient along each axis, then gaussian_filter: axes 0, 1, 2 in turn (proc3d.py:525-531)
+    hipLaunchKernelGGL(gradient_kernel<0>, grid, block, 0, st, sd, ga, v);
+    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gx, v, gw);
+    hipLaunchKernelGGL(gradient_kernel<1>, grid, block, 0, st, sd, ga, v);
+    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gy, v, gw);
+    hipLaunchKernelGGL(gradient_kernel<2>, grid, block, 0, st, sd, ga, v);
+    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
+    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gz, v, gw);
     V_TRY(hipGetLastError());
-    V_TRY(hipStreamSynchronize(st));
-    (void)hipFree(g0); g0 = nullptr;
-    (void)hipFree(g1); g1 = nullptr;
-    if (!on_device) { (void)hipFree(vol_d); vol_d = nullptr; }
-
-    V_TRY(hipMalloc(&ga, (size_t)n * 8));
-    V_TRY(hipMalloc(&gb, (size_t)n * 8));
-    V_TRY(hipMalloc(&gx, (size_t)n * 8));
-    V_TRY(hipMalloc(&gy, (size_t)n * 8));
-    V_TRY(hipMalloc(&gz, (size_t)n * 8));
-    {
-        const int64_t strides[3] = {ny * nz, nz, 1};
-        const int lens[3] = {(int)nx, (int)ny, (int)nz};
-        double *outs[3] = {gx, gy, gz};
-        for (int ax = 0; ax < 3; ++ax) {
-            // gradient along `ax`, then gaussian_filter: axes 0, 1, 2 in turn (proc3d.py:525-531)
-            hipLaunchKernelGGL(gradient_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, sd, ga, n, strides[ax], lens[ax]);
-            hipLaunchKernelGGL(gauss_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, ga, gb, n, strides[0], lens[0], gw);
-            hipLaunchKernelGGL(gauss_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, gb, ga, n, strides[1], lens[1], gw);
-            hipLaunchKernelGGL(gauss_kernel, dim3(blocks_for(n)), dim3(kB), 0, st, ga, outs[ax], n, strides[2], lens[2], gw);
-        }
-    }
-    V_TRY(hipGetLastError());
-    V_TRY(hipMalloc(&counts, (size_t)nchunks * 4));
-    hipLaunchKernelGGL(shell_count_kernel, dim3(nchunks), dim3(kB), 0, st, sd, n, lo, hi, counts);
+    hipLaunchKernelGGL(shell_count_kernel, dim3(nchunks), block, 0, st, sd, n, lo, hi, counts);
     V_TRY(hipGetLastError());
     hc.resize(nchunks);
     V_TRY(hipMemcpy(hc.data(), counts, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
     ho.resize(nchunks);
     for (uint32_t c = 0; c < nchunks; ++c) { ho[c] = total; total += hc[c]; }
     if (total > 0) {
-        V_TRY(hipMalloc(&offs_d, (size_t)nchunks * 8));
         V_TRY(hipMemcpy(offs_d, ho.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
-        V_TRY(hipMalloc(&pts_d, (size_t)total * 24));
-        V_TRY(hipMalloc(&nrm_d, (size_t)total * 24));
-        hipLaunchKernelGGL(shell_points_kernel, dim3(nchunks), dim3(kB), 0, st, sd, gx, gy, gz, n, (int)ny,
+        V_TRY(hipMalloc(reinterpret_cast<void **>(&pts_d), (size_t)total * 48));
+        nrm_d = pts_d + total * 3;
+        hipLaunchKernelGGL(shell_points_kernel, dim3(nchunks), block, 0, st, sd, gx, gy, gz, n, (int)ny,
                            (int)nz, lo, hi, level_set_value, origin[0], origin[1], origin[2], voxel_size,
                            offs_d, pts_d, nrm_d);
         V_TRY(hipGetLastError());
@@ -363,9 +454,8 @@ done:
     }
     (void)hipDeviceSynchronize();
     if (!on_device && vol_d) (void)hipFree(vol_d);
-    void *bufs[] = {occ, g0, g1, counts, offs_d, sd, ga, gb, gx, gy, gz, pts_d, nrm_d};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
+    if (scratch) (void)hipFree(scratch);
+    if (pts_d) (void)hipFree(pts_d);
     return rc;
 }
 
