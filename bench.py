@@ -8,8 +8,9 @@ the 72 uint8 masks that are ALREADY RESIDENT IN HBM, pack them to bit tiles and 
 whole slab (the ``Backprojection.process_fileset`` work after ingest).  The result stays in HBM.
 
 Workload (config.workload): BASELINE cfg 3, 512^3 voxels x 72 views, scene S1 "plant"
-(SURVEY.md 8d).  N GPUs: weak scaling -- every rank carves one X-slab of 512^3 voxels of a
-grid N times as large (N=8 is BASELINE cfg 4, 1024^3), no data-path collective (voxels are
+(SURVEY.md 8d).  N GPUs: weak scaling -- a near-cubic grid of about N x 512^3 voxels (N=8 is
+BASELINE cfg 4, 1024^3) whose x-planes are dealt round-robin over the ranks, so every rank
+carves ~512^3 voxels holding the same share of the object; no data-path collective (voxels are
 independent).  ``--gather`` times the optional grid assembly AFTER the timed region
 and reports it next to the headline; it is never part of ``value``.
 
@@ -35,7 +36,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}  # multiples of n per axis
+# Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
+# x-planes dealt round-robin over the ranks.  Shapes for n = 512 (nx divisible by N, nz by 4):
+GRIDS_512 = {1: (512, 512, 512), 2: (640, 648, 648), 4: (812, 812, 816), 8: (1024, 1024, 1024)}
 
 
 def parse():
@@ -60,10 +63,13 @@ def parse():
 
 
 def global_shape(n, gpus):
-    if gpus in GRIDS:
-        m = GRIDS[gpus]
-        return [n * m[0], n * m[1], n * m[2]]
-    return [n * gpus, n, n]
+    if n == 512 and gpus in GRIDS_512:
+        return list(GRIDS_512[gpus])
+    # general case: a cube of about gpus * n^3 voxels, nx a multiple of gpus, ny, nz multiples of 4
+    edge = (gpus * n ** 3) ** (1.0 / 3.0)
+    nx = max(gpus, int(round(edge / gpus)) * gpus)
+    ny = nz = max(4, int(round(edge / 4)) * 4)
+    return [nx, ny, nz]
 
 
 def run_steps(engine, nat, K, R, t, masks_dev, V, H, W, steps, vpl):
@@ -282,7 +288,7 @@ def main():
             "config": {"workload": f"BASELINE cfg 3: {a.n}^3 voxels x {V} views per GPU, scene S1 "
                                    f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
                        "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
-                       "parallelism": f"x-slab x{world}, no data-path collective",
+                       "parallelism": f"x-planes cyclic over {world} rank(s), no data-path collective",
                        "path": a.path, "views_per_launch": V if a.path == "fused" else 1},
             "roofline": roof(a.path, stats, traffic_for(a.path)),
             "kernels": stats,

@@ -109,6 +109,16 @@ int sc_create_slab(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t 
                    const float origin[3], float voxel_size, int mode, float default_value,
                    int device);
 
+/*
+ * Same, but the engine owns the x-planes  first, first + stride, first + 2*stride, ...  of the
+ * global grid (plane-cyclic sharding: rank r of W takes first = r, stride = W).  An object in
+ * the middle of the grid then loads every rank alike, which contiguous slabs do not.  State /
+ * sc_get_values are [planes][ny][nz] in that order.
+ */
+int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride,
+                     const float origin[3], float voxel_size, int mode, float default_value,
+                     int device);
+
 void sc_destroy(sc_engine *e);
 
 /* Backprojection.clear (cl.py:307-311): reset state to default_value, drop pending views. */

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "sc_device_count": ("i", ["p"]),
     "sc_create": ("i", ["p", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_create_slab": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
+    "sc_create_cyclic": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_destroy": ("v", ["p"]),
     "sc_clear": ("i", ["p"]),
     "sc_set_option": ("i", ["p", "i", "q"]),
@@ -209,13 +210,26 @@ def device_count():
 class Engine:
     """Owning handle of one ``sc_engine`` (whole grid or an X-slab of it)."""
 
-    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None):
+    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None,
+                 cyclic=None):
+        """slab=(i0, i1): the engine owns x-planes [i0, i1); cyclic=(first, stride): planes
+        first, first+stride, ... ; neither: the whole grid."""
         self._b = backend()
         self._h = 0
         nx, ny, nz = (int(s) for s in shape)
         origin32 = np.ascontiguousarray(np.asarray(origin, dtype=np.float32).reshape(3))
         out = np.zeros(1, dtype=np.uintp)
-        if slab is None:
+        self.planes = None
+        if slab is not None and cyclic is not None:
+            raise ValueError("slab and cyclic are exclusive")
+        if cyclic is not None:
+            first, stride = int(cyclic[0]), int(cyclic[1])
+            rc = self._b.call("sc_create_cyclic", addr(out), nx, ny, nz, first, stride, addr(origin32),
+                              float(np.float32(voxel_size)), int(mode), float(default_value),
+                              int(device))
+            self.planes = range(first, nx, stride)
+            self.slab = (first, nx)
+        elif slab is None:
             rc = self._b.call("sc_create", addr(out), nx, ny, nz, addr(origin32),
                               float(np.float32(voxel_size)), int(mode), float(default_value),
                               int(device))
@@ -230,7 +244,9 @@ class Engine:
         self._h = int(out[0])
         self.mode = int(mode)
         self.shape = (nx, ny, nz)
-        self.slab_shape = (self.slab[1] - self.slab[0], ny, nz)
+        if self.planes is None:
+            self.planes = range(self.slab[0], self.slab[1])
+        self.slab_shape = (len(self.planes), ny, nz)
         self.dtype = np.int32 if mode == SC_MODE_CARVE else np.float32
         self.device = int(device)
 

@@ -64,9 +64,11 @@ static_assert(sizeof(ViewDesc) == 96, "ViewDesc layout");
 struct GridDesc {
     float ox, oy, oz, vs;
     uint32_t ny, nz;
-    uint32_t i0;        // first global x index of the slab
+    uint32_t i0;        // global x index of the engine's first plane
     uint32_t gpc;       // 4-voxel groups per column = ceil(nz / 4)
-    uint64_t ngroups;   // columns in slab * gpc
+    uint64_t ngroups;   // columns owned * gpc
+    uint32_t istride;   // global x step between the engine's planes (1: slab, W: plane-cyclic)
+    uint32_t pad_;
 };
 
 constexpr int kBlock = 256;
@@ -200,8 +202,8 @@ __device__ __forceinline__ void decode_group(const GridDesc &g, uint64_t grp, Vo
     vx.k0 = kq * 4u;
     vx.nvalid = min(4u, g.nz - vx.k0);
     vx.elem = (uint64_t)col * g.nz + vx.k0;
-    // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index
-    vx.x = g.ox + (float)(int)(il + g.i0) * g.vs;
+    // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index of the plane
+    vx.x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     vx.y = g.oy + (float)(int)j * g.vs;
 }
 
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
     if (grp >= g.ngroups) return;
     int4 pre = make_int4(0, 0, 0, 0);
     if (!FRESH && VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
-    ap.sub = (lb / kXcdRun) % kSub;  // neighbouring blocks feed one sub-list: coherent chunks
+    ap.sub = (lb * 0x9E3779B1u) >> 24;  // kSub == 256: hashed, so a dense region loads every sub-list alike
     carve_group<FRESH, VEC>(labels, g, views, nviews, init, grp, pre, ap);
 }
 
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
             uint32_t k = idx - col * g.nz;
             uint32_t il = col / g.ny;
             uint32_t j = col - il * g.ny;
-            float x = g.ox + (float)(int)(il + g.i0) * g.vs;  // backprojection.c:71-73
+            float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
             float y = g.oy + (float)(int)j * g.vs;
             float z = g.oz + (float)(int)k * g.vs;
             for (int vi = v0; vi < v1; vi += 2) {
@@ -790,7 +792,7 @@ constexpr int kNumKernels = 5;
 struct sc_engine {
     int device = 0;
     int mode = SC_MODE_CARVE;
-    int64_t nx = 0, ny = 0, nz = 0, i0 = 0, i1 = 0, n = 0;
+    int64_t nx = 0, ny = 0, nz = 0, i0 = 0, istride = 1, planes = 0, n = 0;
     float origin[3] = {0, 0, 0};
     float vs = 1.0f;
     float default_value = 0.0f;
@@ -887,8 +889,10 @@ GridDesc grid_desc(const sc_engine *e) {
     g.ny = (uint32_t)e->ny;
     g.nz = (uint32_t)e->nz;
     g.i0 = (uint32_t)e->i0;
+    g.istride = (uint32_t)e->istride;
+    g.pad_ = 0;
     g.gpc = (uint32_t)((e->nz + 3) / 4);
-    g.ngroups = (uint64_t)(e->i1 - e->i0) * (uint64_t)e->ny * g.gpc;
+    g.ngroups = (uint64_t)e->planes * (uint64_t)e->ny * g.gpc;
     return g;
 }
 
@@ -1119,7 +1123,7 @@ constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
 
 int ensure_lists(sc_engine *e) {
     if (e->lists) return SC_OK;
-    uint64_t total = std::max<uint64_t>((uint64_t)e->n / 8, (uint64_t)kSub * 1024);
+    uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4, (uint64_t)kSub * 1024);
     e->subcap = (uint32_t)((total + kSub - 1) / kSub);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lists), (size_t)2 * kSub * e->subcap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->ctl), sizeof(ListCtl)));
@@ -1166,10 +1170,10 @@ int flush(sc_engine *e, size_t count = 0) {
     if (e->mode == SC_MODE_CARVE) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
-        // fused carve with survivor compaction: dense for kDenseViews, then lists
-        const int kDenseViews = (int)e->dense_views, kStage1Views = (int)e->stage1_views;
-        const uint32_t kListBlocks = (uint32_t)e->list_blocks;
-        bool compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)kDenseViews &&
+        // fused carve with survivor compaction: dense for the first `ndense` views, then lists
+        const int ndense = (int)e->dense_views, nstage1 = (int)e->stage1_views;
+        const uint32_t list_blocks = (uint32_t)e->list_blocks;
+        bool compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)ndense &&
                        (uint64_t)e->n < 0x80000000ull;
         Append ap{nullptr, nullptr, 0u, 0u};
         int dense_views = (int)nv;
@@ -1180,7 +1184,7 @@ int flush(sc_engine *e, size_t count = 0) {
             ap.list = e->lists;
             ap.ctl = e->ctl;
             ap.subcap = e->subcap;
-            dense_views = kDenseViews;
+            dense_views = ndense;
         }
         LaunchTimer lt{e, SC_KERNEL_CARVE};
         rc = lt.begin();
@@ -1212,7 +1216,7 @@ int flush(sc_engine *e, size_t count = 0) {
         rc = lt.end();
         if (rc) return rc;
         if (compact) {
-            int s1 = (int)std::min<size_t>(nv, (size_t)kDenseViews + kStage1Views);
+            int s1 = (int)std::min<size_t>(nv, (size_t)ndense + nstage1);
             uint32_t *l0 = e->lists, *l1 = e->lists + (size_t)kSub * e->subcap;
             LaunchTimer lt2{e, SC_KERNEL_LIST};
             rc = lt2.begin();
@@ -1220,22 +1224,22 @@ int flush(sc_engine *e, size_t count = 0) {
             bool two = (size_t)s1 < nv;
             int vg = (int)e->view_group;
             if (two) {
-                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(kListBlocks), block, 0, e->stream, st,
-                                   g, vd + kDenseViews, s1 - kDenseViews, l0, l1, e->ctl, 0, e->subcap, vg);
-                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(kListBlocks), block, 0, e->stream, st,
+                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream, st,
+                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, e->subcap, vg);
+                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream, st,
                                    g, vd + s1, (int)nv - s1, l1, static_cast<uint32_t *>(nullptr), e->ctl,
                                    1, e->subcap, vg);
             } else {
-                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(kListBlocks), block, 0, e->stream, st,
-                                   g, vd + kDenseViews, s1 - kDenseViews, l0,
+                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream, st,
+                                   g, vd + ndense, s1 - ndense, l0,
                                    static_cast<uint32_t *>(nullptr), e->ctl, 0, e->subcap, vg);
             }
             if (vec)
-                hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(kListBlocks), block, 0, e->stream,
-                                   st, g, vd + kDenseViews, (int)nv - kDenseViews, e->ctl);
+                hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl);
             else
-                hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(kListBlocks), block, 0, e->stream,
-                                   st, g, vd + kDenseViews, (int)nv - kDenseViews, e->ctl);
+                hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(list_blocks), block, 0, e->stream,
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl);
             HIP_TRY(hipGetLastError());
             rc = lt2.end();
             if (rc) return rc;
@@ -1291,8 +1295,9 @@ int check_view_args(const sc_engine *e, const float *K, const float *R, const fl
     return SC_OK;
 }
 
-int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t i1,
-           const float *origin, float vs, int mode, float default_value, int device) {
+// The engine owns the x-planes  i0, i0 + istride, ...  (`planes` of them) of the global grid.
+int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t istride,
+           int64_t planes, const float *origin, float vs, int mode, float default_value, int device) {
     if (!out) return fail(SC_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if (!origin) return fail(SC_ERR_INVALID, "null origin");
@@ -1300,7 +1305,9 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
     // int -> float of an index must be exact
     if (nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24))
         return fail(SC_ERR_INVALID, "axis longer than 2^24 voxels");
-    if (i0 < 0 || i1 > nx || i0 >= i1) return fail(SC_ERR_INVALID, "bad slab [%lld, %lld)", (long long)i0, (long long)i1);
+    if (i0 < 0 || istride < 1 || planes < 1 || i0 + (planes - 1) * istride >= nx)
+        return fail(SC_ERR_INVALID, "bad slab / plane set (first %lld, stride %lld, planes %lld of %lld)",
+                    (long long)i0, (long long)istride, (long long)planes, (long long)nx);
     if (mode != SC_MODE_CARVE && mode != SC_MODE_AVERAGE)
         return fail(SC_ERR_INVALID, "unknown mode %d", mode);
     int ndev = 0;
@@ -1312,8 +1319,8 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
     if (!e) return fail(SC_ERR_NOMEM, "host allocation failed");
     e->device = device;
     e->mode = mode;
-    e->nx = nx; e->ny = ny; e->nz = nz; e->i0 = i0; e->i1 = i1;
-    e->n = (i1 - i0) * ny * nz;
+    e->nx = nx; e->ny = ny; e->nz = nz; e->i0 = i0; e->istride = istride; e->planes = planes;
+    e->n = planes * ny * nz;
     memcpy(e->origin, origin, sizeof e->origin);
     e->vs = vs;
     e->default_value = default_value;
@@ -1365,13 +1372,23 @@ int sc_device_count(int *count) {
 
 int sc_create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],
               float voxel_size, int mode, float default_value, int device) {
-    return create(out, nx, ny, nz, 0, nx, origin, voxel_size, mode, default_value, device);
+    return create(out, nx, ny, nz, 0, 1, nx, origin, voxel_size, mode, default_value, device);
 }
 
 int sc_create_slab(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t i1,
                    const float origin[3], float voxel_size, int mode, float default_value,
                    int device) {
-    return create(out, nx, ny, nz, i0, i1, origin, voxel_size, mode, default_value, device);
+    if (i0 < 0 || i1 > nx || i0 >= i1) return fail(SC_ERR_INVALID, "bad slab [%lld, %lld)", (long long)i0, (long long)i1);
+    return create(out, nx, ny, nz, i0, 1, i1 - i0, origin, voxel_size, mode, default_value, device);
+}
+
+int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride,
+                     const float origin[3], float voxel_size, int mode, float default_value,
+                     int device) {
+    if (stride < 1 || first < 0 || first >= stride || first >= nx)
+        return fail(SC_ERR_INVALID, "bad plane set (first %lld, stride %lld)", (long long)first, (long long)stride);
+    int64_t planes = (nx - first + stride - 1) / stride;
+    return create(out, nx, ny, nz, first, stride, planes, origin, voxel_size, mode, default_value, device);
 }
 
 void sc_destroy(sc_engine *e) {

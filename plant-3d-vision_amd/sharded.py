@@ -1,12 +1,17 @@
-"""Multi-GPU space carving: one process per GPU, the grid sharded into contiguous X-slabs.
+"""Multi-GPU space carving: one process per GPU, the grid sharded by X-planes.
 
 The reference is single-device (one module-global OpenCL queue, ``plant3dvision/cl.py:29-30``);
 this module is the MI355X-native addition.  Voxels are independent
 (``kernels/backprojection.c:64-84``: one owner per voxel), so:
 
-* rank r owns ``i in [nx*r//W, nx*(r+1)//W)`` of the C-order ``[nx][ny][nz]`` grid -- a
-  contiguous block of the output, computed from GLOBAL indices (``sc_create_slab``), hence
-  bit-identical to the single-GPU result;
+* rank r owns a set of x-planes of the C-order ``[nx][ny][nz]`` grid, computed from GLOBAL
+  indices, hence bit-identical to the single-GPU result.  Two partitions:
+  ``"cyclic"`` (default): planes ``r, r+W, r+2W, ...`` (``sc_create_cyclic``).  The object sits
+  in the middle of the grid, so contiguous slabs give the middle ranks all the surviving voxels
+  (measured at 1024^3 / 8 ranks: 6.3 ms on ranks 3-4 against 0.34 ms on the others); dealing the
+  planes round-robin gives every rank the same mix.
+  ``"slab"``: ``i in [nx*r//W, nx*(r+1)//W)`` (``sc_create_slab``), a contiguous block of the
+  output, for consumers that want one;
 * every rank applies every view to its slab: the data path needs NO collective;
 * assembling the full grid is a separate, optional step: ``gather_to_host`` (what a
   ``Voxels`` run needs: the volume in host memory of one process), ``all_gather`` (RCCL
@@ -20,6 +25,20 @@ gloo in tests; the default is the HIP engine and there is no CPU fallback.
 import numpy as np
 
 from . import _native as nat
+
+
+def rank_planes(nx, world_size, rank, partition="cyclic"):
+    """The global x indices rank ``rank`` owns, as a ``range``."""
+    if partition == "cyclic":
+        if not 0 <= rank < world_size:
+            raise ValueError("rank out of range")
+        if world_size > nx:
+            raise ValueError(f"cannot shard {nx} planes over {world_size} ranks")
+        return range(rank, nx, world_size)
+    if partition == "slab":
+        i0, i1 = slab_bounds(nx, world_size, rank)
+        return range(i0, i1)
+    raise ValueError("partition must be 'cyclic' or 'slab'")
 
 
 def slab_bounds(nx, world_size, rank):
@@ -43,7 +62,8 @@ class ShardedBackprojection:
     """Slab-sharded ``Backprojection``: same per-view interface, one slab per rank."""
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, rank=None,
-                 world_size=None, device=None, engine_factory=None, views_per_launch=0):
+                 world_size=None, device=None, engine_factory=None, views_per_launch=0,
+                 partition="cyclic"):
         if rank is None or world_size is None:
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_initialized() else 0
@@ -59,12 +79,18 @@ class ShardedBackprojection:
             self.dtype, self._mode = np.float32, nat.SC_MODE_AVERAGE
         else:
             raise ValueError(f"Unknown kernel type {type}, valid values are 'averaging' or 'carving'!")
-        self.slab = slab_bounds(self.shape[0], self.world_size, self.rank)
+        self.partition = partition
+        self.planes = rank_planes(self.shape[0], self.world_size, self.rank, partition)
         self.device = self.rank if device is None else int(device)
         factory = engine_factory or nat.Engine
-        self._engine = factory(self.shape, origin, voxel_size, self._mode,
-                               default_value=float(default_value), device=self.device,
-                               slab=self.slab)
+        if partition == "cyclic":
+            self._engine = factory(self.shape, origin, voxel_size, self._mode,
+                                   default_value=float(default_value), device=self.device,
+                                   cyclic=(self.rank, self.world_size))
+        else:
+            self._engine = factory(self.shape, origin, voxel_size, self._mode,
+                                   default_value=float(default_value), device=self.device,
+                                   slab=(self.planes.start, self.planes.stop))
         if views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(views_per_launch))
         self._on_gpu = engine_factory is None
@@ -75,7 +101,7 @@ class ShardedBackprojection:
 
     @property
     def slab_shape(self):
-        return (self.slab[1] - self.slab[0], self.shape[1], self.shape[2])
+        return (len(self.planes), self.shape[1], self.shape[2])
 
     def process_view(self, intrinsics, rot, tvec, mask, mask_dtype=None):
         mask = np.ascontiguousarray(mask)
@@ -100,7 +126,7 @@ class ShardedBackprojection:
         self._engine.synchronize()
 
     def get_local(self):
-        """This rank's slab as a host array ``[i1-i0, ny, nz]``."""
+        """This rank's planes as a host array ``[len(planes), ny, nz]`` (in ``self.planes`` order)."""
         return self._engine.get_values()
 
     # -- assembling the grid ----------------------------------------------------------------
@@ -115,10 +141,22 @@ class ShardedBackprojection:
         return torch.from_numpy(np.ascontiguousarray(self.get_local()).reshape(-1))
 
     def _max_slab_voxels(self):
-        planes = max(slab_bounds(self.shape[0], self.world_size, r)[1]
-                     - slab_bounds(self.shape[0], self.world_size, r)[0]
+        planes = max(len(rank_planes(self.shape[0], self.world_size, r, self.partition))
                      for r in range(self.world_size))
         return planes * self.shape[1] * self.shape[2]
+
+    def _assemble(self, per_rank):
+        """Full grid (torch tensor ``[nx, ny, nz]``) from one flat, possibly padded, tensor per
+        rank, placing every rank's planes at their global x indices."""
+        import torch
+        plane = self.shape[1] * self.shape[2]
+        first = per_rank[0]
+        full = torch.empty((self.shape[0], self.shape[1], self.shape[2]), dtype=first.dtype,
+                           device=first.device)
+        for r, flat in enumerate(per_rank):
+            pl = rank_planes(self.shape[0], self.world_size, r, self.partition)
+            full[pl.start:pl.stop:pl.step] = flat[: len(pl) * plane].reshape(len(pl), *self.shape[1:])
+        return full
 
     def all_gather(self, compress=False):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
@@ -142,18 +180,10 @@ class ShardedBackprojection:
             send[: local.numel()] = local
         recv = torch.empty(pad * self.world_size, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(recv, send)
-        plane = self.shape[1] * self.shape[2]
-        if self.shape[0] % self.world_size == 0:
-            full = recv
-        else:
-            parts = []
-            for r in range(self.world_size):
-                i0, i1 = slab_bounds(self.shape[0], self.world_size, r)
-                parts.append(recv[r * pad: r * pad + (i1 - i0) * plane])
-            full = torch.cat(parts)
+        full = self._assemble([recv[r * pad:(r + 1) * pad] for r in range(self.world_size)])
         if compress:
             full = full.to(torch.int32)
-        return full.reshape(self.shape)
+        return full
 
     def all_reduce(self):
         """Full grid on every rank by summing zero-padded full-size buffers (the north
@@ -161,12 +191,13 @@ class ShardedBackprojection:
         import torch
         import torch.distributed as dist
         local = self._slab_tensor()
-        plane = self.shape[1] * self.shape[2]
-        full = torch.zeros(self.shape[0] * plane, dtype=local.dtype, device=local.device)
-        full[self.slab[0] * plane: self.slab[1] * plane] = local
+        full = torch.zeros((self.shape[0], self.shape[1], self.shape[2]), dtype=local.dtype,
+                           device=local.device)
+        pl = self.planes
+        full[pl.start:pl.stop:pl.step] = local.reshape(len(pl), *self.shape[1:])
         if self.world_size > 1:
             dist.all_reduce(full, op=dist.ReduceOp.SUM)
-        return full.reshape(self.shape)
+        return full
 
     def gather_to_host(self, dst=0):
         """Full grid as a NumPy array on rank ``dst`` (None elsewhere): each rank copies its
@@ -185,17 +216,16 @@ class ShardedBackprojection:
             dist.gather(send, bufs, dst=dst)
             if self.rank != dst:
                 return None
-            plane = self.shape[1] * self.shape[2]
-            out = np.empty(self.shape, dtype=self.dtype)
-            for r in range(self.world_size):
-                i0, i1 = slab_bounds(self.shape[0], self.world_size, r)
-                out[i0:i1] = bufs[r][: (i1 - i0) * plane].numpy().reshape(i1 - i0, *self.shape[1:])
-            return out
+            return self._assemble(bufs).numpy()
         objs = [None] * self.world_size if self.rank == dst else None
         dist.gather_object(local, objs, dst=dst)
         if self.rank != dst:
             return None
-        return np.concatenate(objs, axis=0)
+        out = np.empty(self.shape, dtype=self.dtype)
+        for r, part in enumerate(objs):
+            pl = rank_planes(self.shape[0], self.world_size, r, self.partition)
+            out[pl.start:pl.stop:pl.step] = part
+        return out
 
     def close(self):
         if self._engine is not None:

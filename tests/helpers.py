@@ -12,10 +12,16 @@ from plant3dvision_amd.cl import Backprojection
 class OracleEngine:
     """Same surface as ``_native.Engine``, computed by the C oracle (whole grid or slab)."""
 
-    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None):
+    def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None,
+                 cyclic=None):
         self.shape = tuple(int(s) for s in shape)
-        self.slab = (0, self.shape[0]) if slab is None else (int(slab[0]), int(slab[1]))
-        self.slab_shape = (self.slab[1] - self.slab[0], self.shape[1], self.shape[2])
+        if cyclic is not None:
+            self.planes = range(int(cyclic[0]), self.shape[0], int(cyclic[1]))
+            self.slab = (0, self.shape[0])  # the oracle updates the whole grid, we return the planes
+        else:
+            self.slab = (0, self.shape[0]) if slab is None else (int(slab[0]), int(slab[1]))
+            self.planes = range(self.slab[0], self.slab[1])
+        self.slab_shape = (len(self.planes), self.shape[1], self.shape[2])
         self.mode = mode
         self.dtype = np.int32 if mode == nat.SC_MODE_CARVE else np.float32
         self.device = device
@@ -56,7 +62,8 @@ class OracleEngine:
         pass
 
     def get_values(self, out=None):
-        vals = self._vol.values[self.slab[0]:self.slab[1]]
+        pl = self.planes
+        vals = self._vol.values[pl.start:pl.stop:pl.step]
         if out is None:
             return vals.copy()
         out[...] = vals.reshape(out.shape)

@@ -444,6 +444,25 @@ def test_slabs_concatenate_to_the_whole_grid(gpu_device):
     assert np.array_equal(np.concatenate(parts, axis=0), want)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_cyclic_planes_interleave_to_the_whole_grid(gpu_device, world):
+    """Plane-cyclic sharding (the default of ShardedBackprojection): rank r owns planes r, r+W, ...
+    computed from GLOBAL indices; interleaved they are the single-engine grid, fused and per view."""
+    shape, origin, vs, views = scene((50, 24, 36), 8, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    for vpl in (0, 1):
+        got = np.empty(shape, dtype=np.int32)
+        for r in range(world):
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, cyclic=(r, world))
+            e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+            for K, R, t, m in views:
+                e.process_view(K, R, t, m, nat.SC_MASK_U8)
+            got[r::world] = e.get_values()
+            assert e.slab_shape[0] == len(range(r, shape[0], world))
+            e.close()
+        assert np.array_equal(got, want), (world, vpl)
+
+
 def test_full_size_512_cubed_72_views_properties(gpu_device):
     """BASELINE cfg 3 at full size: the oracle would take minutes, so check properties the
     domain offers: fused == per-view schedule == permuted order (order independence),

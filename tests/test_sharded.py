@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import oracle_c
-from plant3dvision_amd.sharded import ShardedBackprojection, slab_bounds
+from plant3dvision_amd.sharded import ShardedBackprojection, rank_planes, slab_bounds
 from tests.helpers import OracleEngine, scene
 
 
@@ -32,7 +32,19 @@ def test_slab_bounds_cover_the_axis_exactly():
         slab_bounds(3, 4, 0)
 
 
-def _worker(rank, world, port, shape, mode, q):
+def test_rank_planes_partition_the_axis():
+    for part in ("cyclic", "slab"):
+        for nx, w in ((512, 8), (301, 8), (7, 7), (10, 3)):
+            allp = sorted(i for r in range(w) for i in rank_planes(nx, w, r, part))
+            assert allp == list(range(nx)), (part, nx, w)
+            sizes = [len(rank_planes(nx, w, r, part)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+    assert list(rank_planes(10, 3, 1, "cyclic")) == [1, 4, 7]
+    with pytest.raises(ValueError):
+        rank_planes(10, 3, 0, "blocks")
+
+
+def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,14 +53,15 @@ def _worker(rank, world, port, shape, mode, q):
         if mode == "averaging":
             rng = np.random.default_rng(1)
             views = [(K, R, t, rng.random(m.shape, dtype=np.float32)) for K, R, t, m in views]
-        sb = ShardedBackprojection(shape, origin, vs, type=mode, engine_factory=OracleEngine)
+        sb = ShardedBackprojection(shape, origin, vs, type=mode, engine_factory=OracleEngine,
+                                   partition=partition)
         assert (sb.rank, sb.world_size) == (rank, world)
         for K, R, t, m in views:
             sb.process_view(K, R, t, m)
         full_ag = sb.all_gather().numpy()
         full_ar = sb.all_reduce().numpy()
         host = sb.gather_to_host(dst=0)
-        res = {"rank": rank, "slab": sb.slab, "ag": full_ag, "ar": full_ar, "host": host}
+        res = {"rank": rank, "planes": list(sb.planes), "ag": full_ag, "ar": full_ar, "host": host}
         if mode == "carving":
             res["ag8"] = sb.all_gather(compress=True).numpy()
         q.put(res)
@@ -57,9 +70,11 @@ def _worker(rank, world, port, shape, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,mode", [(2, (16, 10, 12), "carving"), (3, (17, 9, 8), "carving"),
-                                              (2, (9, 8, 12), "averaging")])
-def test_gloo_sharded_equals_single(world, shape, mode):
+@pytest.mark.parametrize("world,shape,mode,partition", [(2, (16, 10, 12), "carving", "cyclic"),
+                                                        (3, (17, 9, 8), "carving", "cyclic"),
+                                                        (3, (17, 9, 8), "carving", "slab"),
+                                                        (2, (9, 8, 12), "averaging", "cyclic")])
+def test_gloo_sharded_equals_single(world, shape, mode, partition):
     _, origin, vs, views = scene(tuple(shape), 5, "plant")
     if mode == "carving":
         want = oracle_c.carve(list(shape), origin, vs, views)
@@ -70,7 +85,7 @@ def test_gloo_sharded_equals_single(world, shape, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, list(shape), mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, list(shape), mode, q, partition)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
