@@ -49,7 +49,7 @@ namespace {
 // device side
 // ------------------------------------------------------------------------------------------
 
-struct ViewDesc {   // 96 bytes, read with scalar loads (the view index is wave-uniform)
+struct ViewDesc {   // 104 bytes, read with scalar loads (the view index is wave-uniform)
     float K[4];     // fx fy cx cy
     float R[9];     // row-major
     float t[3];
@@ -58,8 +58,9 @@ struct ViewDesc {   // 96 bytes, read with scalar loads (the view index is wave-
     int32_t tiles_x;
     int32_t pad;
     float Wf, Hf;
+    const uint8_t *occ;  // carve: one byte per 32x32 tile, non-zero if the tile holds foreground
 };
-static_assert(sizeof(ViewDesc) == 96, "ViewDesc layout");
+static_assert(sizeof(ViewDesc) == 104, "ViewDesc layout");
 
 struct GridDesc {
     float ox, oy, oz, vs;
@@ -340,6 +341,203 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
     if (!FRESH && VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
     ap.sub = (lb * 0x9E3779B1u) >> 24;  // kSub == 256: hashed, so a dense region loads every sub-list alike
     carve_group<FRESH, VEC>(labels, g, views, nviews, init, grp, pre, ap);
+}
+
+// ---- brick form of the dense stage -------------------------------------------------------
+// When ny % 16 == 0 and nz % 64 == 0 a block takes a BRICK of 16 columns (along y) x 64 voxels
+// (along z) instead of 1024 consecutive voxels: wavefront w owns columns 4w..4w+3, lane l the
+// 4-voxel group (l & 15) of column (l >> 4).  A brick projects onto a small image patch, which
+// makes a conservative emptiness test worthwhile: wavefront 0 projects the brick's 32 column
+// end points (one per lane), widens their bounding box by a rigorous bound on the float32
+// rounding of end points AND interior voxels (the image of a straight 3-D segment is the
+// segment between the images of its ends; depth is affine along it), and if that box lies
+// inside the image, in front of the camera, and only over 32x32 tiles that hold no foreground,
+// then the reference would find every voxel of the brick in-image on a zero pixel
+// (backprojection.c:26-31,79): the whole block carves its voxels without projecting them.
+// Any doubt -> no culling.  Measured on the 512^3 plant scene: 72 % of the bricks are culled
+// in the first view.
+constexpr int kBrickY = 16, kBrickZ = 64;
+
+struct BrickBox { float umin, umax, vmin, vmax; bool ok; };
+
+__device__ __forceinline__ float wave_min32(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max32(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// executed by the 64 lanes of wavefront 0; lanes 0..31 carry one end point each:
+// column (lane >> 1) of the brick, z end (lane & 1).  Returns a wave-uniform verdict.
+__device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDesc &g, float x, int j0,
+                                                int k0) {
+    const int lane = (int)__lane_id();
+    const int pt = lane & 31;
+    float y = g.oy + (float)(j0 + (pt >> 1)) * g.vs;                         // backprojection.c:72
+    float z = g.oz + (float)(k0 + ((pt & 1) ? kBrickZ - 1 : 0)) * g.vs;      // :73
+    float rzx = d.R[6] * x, rzy = d.R[7] * y, rzz = d.R[8] * z;
+    float rxx = d.R[0] * x, rxy = d.R[1] * y, rxz = d.R[2] * z;
+    float ryx = d.R[3] * x, ryy = d.R[4] * y, ryz = d.R[5] * z;
+    float pz = ((rzx + rzy) + rzz) + d.t[2];
+    float px = ((rxx + rxy) + rxz) + d.t[0];
+    float py = ((ryx + ryy) + ryz) + d.t[1];
+    // absolute rounding-error bounds of the three dot products (8x the worst case), valid for
+    // every voxel of the brick once maximised over the end points
+    float ez = wave_max32((fabsf(rzx) + fabsf(rzy) + fabsf(rzz) + fabsf(d.t[2])) * 0x1p-19f);
+    float ex = wave_max32((fabsf(rxx) + fabsf(rxy) + fabsf(rxz) + fabsf(d.t[0])) * 0x1p-19f);
+    float ey = wave_max32((fabsf(ryx) + fabsf(ryy) + fabsf(ryz) + fabsf(d.t[1])) * 0x1p-19f);
+    float pzmin = wave_min32(pz);
+    bool front = pzmin > 4.0f * ez;  // depth is affine along every segment: all voxels in front
+    float qx = px / pz, qy = py / pz;
+    float u = qx * d.K[0] + d.K[2], v = qy * d.K[1] + d.K[3];
+    float qxm = wave_max32(fabsf(qx)), qym = wave_max32(fabsf(qy));
+    float umin = wave_min32(u), umax = wave_max32(u), vmin = wave_min32(v), vmax = wave_max32(v);
+    // pixel-space slack: 2 px + propagated dot-product error + relative slack of the final ops
+    float inv = 2.0f / pzmin;
+    float mu = 2.0f + fabsf(d.K[0]) * (ex + qxm * ez) * inv + fmaxf(fabsf(umin), fabsf(umax)) * 0x1p-20f;
+    float mv = 2.0f + fabsf(d.K[1]) * (ey + qym * ez) * inv + fmaxf(fabsf(vmin), fabsf(vmax)) * 0x1p-20f;
+    umin -= mu; umax += mu; vmin -= mv; vmax += mv;
+    // a NaN anywhere makes a comparison false -> no culling
+    bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
+    if (!inside) return false;  // wave-uniform (all inputs were reduced over the wavefront)
+    int tx0 = (int)umin >> 5, tx1 = (int)umax >> 5, ty0 = (int)vmin >> 5, ty1 = (int)vmax >> 5;
+    int ntx = tx1 - tx0 + 1, nty = ty1 - ty0 + 1;
+    int tx, ty;
+    bool use;
+    if (ntx <= 8 && nty <= 8) {
+        tx = tx0 + (lane & 7); ty = ty0 + (lane >> 3); use = ((lane & 7) < ntx) & ((lane >> 3) < nty);
+    } else if (ntx <= 2 && nty <= 32) {
+        tx = tx0 + (lane & 1); ty = ty0 + (lane >> 1); use = ((lane & 1) < ntx) & ((lane >> 1) < nty);
+    } else if (nty <= 2 && ntx <= 32) {
+        ty = ty0 + (lane & 1); tx = tx0 + (lane >> 1); use = ((lane & 1) < nty) & ((lane >> 1) < ntx);
+    } else {
+        return false;
+    }
+    uint32_t o = 0;
+    if (use) o = d.occ[ty * d.tiles_x + tx];
+    return __ballot(o != 0) == 0;
+}
+
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                             const ViewDesc *__restrict__ views,
+                                                             int nviews, int32_t init, Append ap,
+                                                             uint32_t bricks_y, uint32_t bricks_z) {
+    __shared__ int s_cull;
+    const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+    const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nz + k0;
+    int32_t *p = labels + elem;
+    int32_t lab[4], was[4];
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lab[e] = init;
+    } else {
+        int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        was[e] = lab[e];
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
+
+    for (int vi = 0; vi < nviews; ++vi) {
+        // the whole block decides together: culled, or projected voxel by voxel
+        if (wave == 0) {
+            const ViewDesc dc = views[vi];
+            bool c = brick_is_carved(dc, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+            if (lane == 0) s_cull = c ? 1 : 0;
+        }
+        __syncthreads();
+        const bool culled = s_cull != 0;
+        __syncthreads();
+        if (culled) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((alive >> e) & 1u) lab[e] = -1;
+            alive = 0;
+            break;  // block-uniform: everything is carved
+        }
+        if (__ballot(alive != 0) != 0) {  // this wavefront still has live voxels
+            const ViewDesc d = views[vi];
+            float ax = d.R[0] * x + d.R[1] * y;
+            float ay = d.R[3] * x + d.R[4] * y;
+            float az = d.R[6] * x + d.R[7] * y;
+            const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
+            bool ok[4];
+            uint32_t w[4];
+            int sh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                ok[e] = project(ax, ay, az, z[e], d, u, v) & ((alive >> e) & 1u);
+                sh[e] = u & 31;
+                w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u, v, d.tiles_x) : 0u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ok[e]) {
+                    if (((w[e] >> sh[e]) & 1u) == 0) {  // :79
+                        lab[e] = -1;
+                        alive &= ~(1u << e);
+                    } else if (lab[e] == 0) {  // :81
+                        lab[e] = 1;
+                    }
+                }
+            }
+        }
+    }
+
+    bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+    if (changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+
+    if (ap.list != nullptr) {
+        ap.sub = (lb * 0x9E3779B1u) >> 24;
+        unsigned long long b[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = __ballot((alive >> e) & 1u);
+            total += (uint32_t)__popcll(b[e]);
+        }
+        if (total != 0) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ap.ctl->count[0][ap.sub].n, total);
+            base = __shfl(base, 0);
+            if (base + total > ap.subcap) {
+                if (lane == 0) ap.ctl->overflow = 1u;
+            } else {
+                uint32_t *dst = ap.list + (size_t)ap.sub * ap.subcap + base;
+                unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                uint32_t off = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((alive >> e) & 1u) {
+                        uint32_t rank = off + (uint32_t)__popcll(b[e] & below);
+                        dst[rank] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
+                    }
+                    off += (uint32_t)__popcll(b[e]);
+                }
+            }
+        }
+    }
 }
 
 // One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
@@ -672,7 +870,8 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
                                                       int64_t row_stride, int64_t view_stride,
                                                       int W, int H, int nviews, int tiles_x,
                                                       uint32_t *__restrict__ out,
-                                                      int64_t out_view_words, T background) {
+                                                      int64_t out_view_words, T background,
+                                                      uint8_t *__restrict__ occ, int tiles_y) {
     const int lane = threadIdx.x & 63;
     const int segs = (W + 63) >> 6;
     int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -692,10 +891,13 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
     uint32_t *o = out + view * out_view_words;
     uint32_t base = (uint32_t)(v >> 5) * (uint32_t)tiles_x;
     uint32_t rowin = (uint32_t)(v & 31);
+    uint8_t *oc = occ + (int64_t)view * tiles_x * tiles_y;  // zeroed by the host; racing stores all write 1
     if (lane == 0) {
         o[(base + seg * 2) * 32u + rowin] = (uint32_t)vote;
+        if ((uint32_t)vote) oc[base + seg * 2] = 1;
     } else if (lane == 32 && seg * 2 + 1 < tiles_x) {
         o[(base + seg * 2 + 1) * 32u + rowin] = (uint32_t)(vote >> 32);
+        if ((uint32_t)(vote >> 32)) oc[base + seg * 2 + 1] = 1;
     }
 }
 
@@ -716,7 +918,8 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
                                                         int64_t row_stride, int64_t view_stride,
                                                         int W, int H, int nviews, int tiles_x,
                                                         int tiles_y, uint32_t *__restrict__ out,
-                                                        int64_t out_view_words, uint32_t flip) {
+                                                        int64_t out_view_words, uint32_t flip,
+                                                        uint8_t *__restrict__ occ) {
     // flip: 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
     const int lane = threadIdx.x & 63;
     const int txb = (tiles_x + 3) >> 2;                      // panels per tile row
@@ -745,8 +948,12 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
         uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
                         (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
         uint32_t other = __shfl_xor(half, 1);
-        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
-            out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = half | (other << 16);
+        uint32_t word = half | (other << 16);
+        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
+            out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
+            // tile occupancy (zeroed by the host): any wavefront that sees foreground says so
+            if (word) occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + tx] = 1;
+        }
     }
 }
 
@@ -831,6 +1038,7 @@ struct sc_engine {
     int64_t time_kernels = 0;
     int64_t max_pending = 256;
     int64_t compact = 1;
+    int64_t brick = 1;
     int64_t dense_views = 2;     // views applied to every voxel before compaction
     int64_t stage1_views = 8;    // views applied to the first survivor list
     int64_t list_blocks = 2048;  // persistent grid of the list / resume kernels
@@ -984,7 +1192,7 @@ int check_dtype(const sc_engine *e, int dtype) {
 }
 
 void fill_desc(ViewDesc &d, const float *K, const float *R, const float *t, const void *mask,
-               int H, int W) {
+               int H, int W, const uint8_t *occ = nullptr) {
     memcpy(d.K, K, sizeof d.K);
     memcpy(d.R, R, sizeof d.R);
     memcpy(d.t, t, sizeof d.t);
@@ -993,6 +1201,7 @@ void fill_desc(ViewDesc &d, const float *K, const float *R, const float *t, cons
     d.H = H;
     d.tiles_x = (W + kTile - 1) / kTile;
     d.pad = 0;
+    d.occ = occ;
     d.Wf = (float)W;
     d.Hf = (float)H;
 }
@@ -1011,6 +1220,12 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     int rc = arena_alloc(e, words * 4 * (size_t)V, &packed);
     if (rc) return rc;
     int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    size_t occ_bytes = (size_t)tiles_x * tiles_y;
+    void *occ_v = nullptr;
+    rc = arena_alloc(e, occ_bytes * (size_t)V, &occ_v);
+    if (rc) return rc;
+    uint8_t *occ = static_cast<uint8_t *>(occ_v);
+    HIP_TRY(hipMemsetAsync(occ, 0, occ_bytes * (size_t)V, e->stream));
     LaunchTimer lt{e, SC_KERNEL_PACK};
     bool bytes = dtype != SC_MASK_I32;
     uint32_t flip = dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
@@ -1023,7 +1238,7 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
         if (rc) return rc;
         hipLaunchKernelGGL(pack16_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
                            static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,
-                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip);
+                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip, occ);
     } else {
         int segs = (W + 63) / 64;
         int64_t waves = (int64_t)V * H * segs;
@@ -1037,12 +1252,12 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
             hipLaunchKernelGGL(pack_kernel<uint8_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
                                e->stream, static_cast<const uint8_t *>(raw_dev), row_stride,
                                view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
-                               (int64_t)words, bg);
+                               (int64_t)words, bg, occ, tiles_y);
         } else {
             hipLaunchKernelGGL(pack_kernel<int32_t>, dim3((uint32_t)blocks), dim3(kBlock), 0,
                                e->stream, static_cast<const int32_t *>(raw_dev), row_stride,
                                view_stride, W, H, V, tiles_x, static_cast<uint32_t *>(packed),
-                               (int64_t)words, (int32_t)0);
+                               (int64_t)words, (int32_t)0, occ, tiles_y);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1051,7 +1266,7 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
         fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
-                  static_cast<uint32_t *>(packed) + (size_t)q * words, H, W);
+                  static_cast<uint32_t *>(packed) + (size_t)q * words, H, W, occ + (size_t)q * occ_bytes);
         e->pending.push_back(d);
     }
     return SC_OK;
@@ -1202,15 +1417,28 @@ int flush(sc_engine *e, size_t count = 0) {
             }
 #undef LAUNCH_CARVE1
         } else {
+            bool brick = e->brick && (e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0 &&
+                         (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
+            if (brick) {
+                uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
+                dim3 bgrid((uint32_t)((uint64_t)e->planes * bys * bzs));
+                if (e->fresh)
+                    hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
+                                       dense_views, init, ap, bys, bzs);
+                else
+                    hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
+                                       dense_views, init, ap, bys, bzs);
+            } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
                        init, ap)
-            if (e->fresh) {
-                if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
-            } else {
-                if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
-            }
+                if (e->fresh) {
+                    if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
+                } else {
+                    if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
+                }
 #undef LAUNCH_CARVE
+            }
         }
         HIP_TRY(hipGetLastError());
         rc = lt.end();
@@ -1455,6 +1683,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_LIST_BLOCKS:
             if (value < 1 || value > 65536) return fail(SC_ERR_INVALID, "list_blocks must be in [1, 65536]");
             e->list_blocks = value;
+            return SC_OK;
+        case SC_OPT_BRICK:
+            e->brick = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_VIEW_GROUP:
             if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "view_group must be in [1, 4096]");

@@ -118,6 +118,34 @@ def test_tall_columns_close_and_oblique_cameras(gpu_device, shape, kw, kind):
             (vpl, histogram3(want))
 
 
+@pytest.mark.parametrize("shape,kw", [
+    ((5, 16, 128), dict(radius_factor=2.0)),
+    ((5, 16, 128), dict(radius_factor=0.25)),                    # cameras inside the bricks' extent
+    ((3, 32, 192), dict(radius_factor=0.7, tilt_deg=40.0)),      # oblique: bricks cover many tiles
+    ((4, 48, 64), dict(radius_factor=1.0, width=200, height=90, fx=150.0, fy=150.0, cx=100.0, cy=45.0)),
+    ((2, 16, 64), dict(radius_factor=3.0, width=2000, height=1500, fx=3000.0, fy=3000.0, cx=1000.0, cy=750.0)),
+])
+@pytest.mark.parametrize("kind", ["plant", "noise", "empty", "solid"])
+def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
+    """ny % 16 == 0 and nz % 64 == 0: the dense stage works on bricks with a conservative
+    emptiness test.  It must never change a label: compare with the oracle and with the brick
+    form switched off, on geometries that stress its guards (bricks that leave the image, lie
+    behind or around the camera, cover many tiles, or sit over completely empty masks)."""
+    sh, origin, vs, views = scene(shape, 8, kind, **kw)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    for brick in (1, 0):
+        bp = Backprojection(sh, origin, vs)
+        bp._engine.set_option(nat.SC_OPT_BRICK, brick)
+        for K, R, t, m in views:
+            bp.process_view(K, R, t, m)
+        assert np.array_equal(bp.get_values(), want), (brick, histogram3(want))
+        # a second fused launch on the stored (non-fresh) state
+        for K, R, t, m in views:
+            bp.process_view(K, R, t, m)
+        assert np.array_equal(bp.get_values(), want), (brick, "second pass")
+        bp.close()
+
+
 def test_fused_compaction_with_slab_and_default_values(gpu_device):
     shape, origin, vs, views = scene((40, 28, 36), 14, "plant")
     for dv in (0, 3):
