@@ -355,7 +355,8 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
 // then the reference would find every voxel of the brick in-image on a zero pixel
 // (backprojection.c:26-31,79): the whole block carves its voxels without projecting them.
 // Any doubt -> no culling.  Measured on the 512^3 plant scene: 72 % of the bricks are culled
-// in the first view.
+// in the first view.  (One test per wavefront on its own 4 columns, without the barrier, was
+// slower: 0.291 vs 0.240 ms -- four times the test instructions outweigh the waiting.)
 constexpr int kBrickY = 16, kBrickZ = 64;
 
 struct BrickBox { float umin, umax, vmin, vmax; bool ok; };
