@@ -347,56 +347,50 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
 // When ny % 16 == 0 and nz % 64 == 0 a block takes a BRICK of 16 columns (along y) x 64 voxels
 // (along z) instead of 1024 consecutive voxels: wavefront w owns columns 4w..4w+3, lane l the
 // 4-voxel group (l & 15) of column (l >> 4).  A brick projects onto a small image patch, which
-// makes a conservative emptiness test worthwhile: wavefront 0 projects the brick's 32 column
-// end points (one per lane), widens their bounding box by a rigorous bound on the float32
-// rounding of end points AND interior voxels (the image of a straight 3-D segment is the
-// segment between the images of its ends; depth is affine along it), and if that box lies
-// inside the image, in front of the camera, and only over 32x32 tiles that hold no foreground,
-// then the reference would find every voxel of the brick in-image on a zero pixel
+// makes a conservative emptiness test worthwhile (brick_flags_kernel, ahead of the dense
+// kernel): project the brick's four corners, widen their bounding box by a rigorous bound on
+// the float32 rounding of corners AND interior voxels, and if that box lies inside the image,
+// in front of the camera, and only over 32x32 tiles that hold no foreground, then the
+// reference would find every voxel of the brick in-image on a zero pixel
 // (backprojection.c:26-31,79): the whole block carves its voxels without projecting them.
 // Any doubt -> no culling.  Measured on the 512^3 plant scene: 72 % of the bricks are culled
-// in the first view.  (One test per wavefront on its own 4 columns, without the barrier, was
-// slower: 0.291 vs 0.240 ms -- four times the test instructions outweigh the waiting.)
+// in the first view.
 constexpr int kBrickY = 16, kBrickZ = 64;
 
-struct BrickBox { float umin, umax, vmin, vmax; bool ok; };
-
-__device__ __forceinline__ float wave_min32(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_max32(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-// executed by the 64 lanes of wavefront 0; lanes 0..31 carry one end point each:
-// column (lane >> 1) of the brick, z end (lane & 1).  Returns a wave-uniform verdict.
+// One lane per (view, brick).  A brick lies in one x-plane, so it is a planar rectangle: with
+// every corner in front of the camera its image is the convex hull of the images of its four
+// corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
+// corners hold for every voxel of the brick.
 __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDesc &g, float x, int j0,
                                                 int k0) {
-    const int lane = (int)__lane_id();
-    const int pt = lane & 31;
-    float y = g.oy + (float)(j0 + (pt >> 1)) * g.vs;                         // backprojection.c:72
-    float z = g.oz + (float)(k0 + ((pt & 1) ? kBrickZ - 1 : 0)) * g.vs;      // :73
-    float rzx = d.R[6] * x, rzy = d.R[7] * y, rzz = d.R[8] * z;
-    float rxx = d.R[0] * x, rxy = d.R[1] * y, rxz = d.R[2] * z;
-    float ryx = d.R[3] * x, ryy = d.R[4] * y, ryz = d.R[5] * z;
-    float pz = ((rzx + rzy) + rzz) + d.t[2];
-    float px = ((rxx + rxy) + rxz) + d.t[0];
-    float py = ((ryx + ryy) + ryz) + d.t[1];
-    // absolute rounding-error bounds of the three dot products (8x the worst case), valid for
-    // every voxel of the brick once maximised over the end points
-    float ez = wave_max32((fabsf(rzx) + fabsf(rzy) + fabsf(rzz) + fabsf(d.t[2])) * 0x1p-19f);
-    float ex = wave_max32((fabsf(rxx) + fabsf(rxy) + fabsf(rxz) + fabsf(d.t[0])) * 0x1p-19f);
-    float ey = wave_max32((fabsf(ryx) + fabsf(ryy) + fabsf(ryz) + fabsf(d.t[1])) * 0x1p-19f);
-    float pzmin = wave_min32(pz);
-    bool front = pzmin > 4.0f * ez;  // depth is affine along every segment: all voxels in front
-    float qx = px / pz, qy = py / pz;
-    float u = qx * d.K[0] + d.K[2], v = qy * d.K[1] + d.K[3];
-    float qxm = wave_max32(fabsf(qx)), qym = wave_max32(fabsf(qy));
-    float umin = wave_min32(u), umax = wave_max32(u), vmin = wave_min32(v), vmax = wave_max32(v);
+    float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
+    float pzmin = INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float y = g.oy + (float)(j0 + ((c >> 1) ? kBrickY - 1 : 0)) * g.vs;  // backprojection.c:72
+        float z = g.oz + (float)(k0 + ((c & 1) ? kBrickZ - 1 : 0)) * g.vs;   // :73
+        float rzx = d.R[6] * x, rzy = d.R[7] * y, rzz = d.R[8] * z;
+        float rxx = d.R[0] * x, rxy = d.R[1] * y, rxz = d.R[2] * z;
+        float ryx = d.R[3] * x, ryy = d.R[4] * y, ryz = d.R[5] * z;
+        float pz = ((rzx + rzy) + rzz) + d.t[2];
+        float px = ((rxx + rxy) + rxz) + d.t[0];
+        float py = ((ryx + ryy) + ryz) + d.t[1];
+        // absolute rounding-error bounds of the three dot products (8x the worst case)
+        ez = fmaxf(ez, (fabsf(rzx) + fabsf(rzy) + fabsf(rzz) + fabsf(d.t[2])) * 0x1p-19f);
+        ex = fmaxf(ex, (fabsf(rxx) + fabsf(rxy) + fabsf(rxz) + fabsf(d.t[0])) * 0x1p-19f);
+        ey = fmaxf(ey, (fabsf(ryx) + fabsf(ryy) + fabsf(ryz) + fabsf(d.t[1])) * 0x1p-19f);
+        float qx = px / pz, qy = py / pz;
+        float u = qx * d.K[0] + d.K[2], v = qy * d.K[1] + d.K[3];
+        // fminf/fmaxf drop NaN operands: track them explicitly
+        nan |= __builtin_isunordered(u, v) | __builtin_isunordered(pz, pz);
+        pzmin = fminf(pzmin, pz);
+        qxm = fmaxf(qxm, fabsf(qx)); qym = fmaxf(qym, fabsf(qy));
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    if (nan) return false;
+    bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
     // pixel-space slack: 2 px + propagated dot-product error + relative slack of the final ops
     float inv = 2.0f / pzmin;
     float mu = 2.0f + fabsf(d.K[0]) * (ex + qxm * ez) * inv + fmaxf(fabsf(umin), fabsf(umax)) * 0x1p-20f;
@@ -404,31 +398,41 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
     // a NaN anywhere makes a comparison false -> no culling
     bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
-    if (!inside) return false;  // wave-uniform (all inputs were reduced over the wavefront)
+    if (!inside) return false;
     int tx0 = (int)umin >> 5, tx1 = (int)umax >> 5, ty0 = (int)vmin >> 5, ty1 = (int)vmax >> 5;
-    int ntx = tx1 - tx0 + 1, nty = ty1 - ty0 + 1;
-    int tx, ty;
-    bool use;
-    if (ntx <= 8 && nty <= 8) {
-        tx = tx0 + (lane & 7); ty = ty0 + (lane >> 3); use = ((lane & 7) < ntx) & ((lane >> 3) < nty);
-    } else if (ntx <= 2 && nty <= 32) {
-        tx = tx0 + (lane & 1); ty = ty0 + (lane >> 1); use = ((lane & 1) < ntx) & ((lane >> 1) < nty);
-    } else if (nty <= 2 && ntx <= 32) {
-        ty = ty0 + (lane & 1); tx = tx0 + (lane >> 1); use = ((lane & 1) < nty) & ((lane >> 1) < ntx);
-    } else {
-        return false;
-    }
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) return false;
     uint32_t o = 0;
-    if (use) o = d.occ[ty * d.tiles_x + tx];
-    return __ballot(o != 0) == 0;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) o |= d.occ[ty * d.tiles_x + tx];
+    return o == 0;
+}
+
+// The emptiness verdict of every (view, brick) pair ahead of the dense kernel, which then reads
+// one byte per brick and view.  (The first brick kernel had its wavefront 0 run the test on 32
+// column end points while the other three waited behind a barrier: 61 % of its wave cycles.)
+__global__ __launch_bounds__(kBlock) void brick_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
+                                                             int nviews, uint32_t bricks_y,
+                                                             uint32_t bricks_z, uint32_t nbricks,
+                                                             uint8_t *__restrict__ flags) {
+    const uint32_t vi = blockIdx.y;  // block-uniform: the descriptor stays in scalar registers
+    const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
+    if (lb >= nbricks) return;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    const ViewDesc d = views[vi];
+    flags[(size_t)vi * nbricks + lb] =
+        brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ)) ? 1 : 0;
 }
 
 template <bool FRESH>
 __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
-                                                             uint32_t bricks_y, uint32_t bricks_z) {
-    __shared__ int s_cull;
+                                                             uint32_t bricks_y, uint32_t bricks_z,
+                                                             const uint8_t *__restrict__ flags) {
     const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t il = lb / per_plane;
@@ -460,15 +464,8 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
 
     for (int vi = 0; vi < nviews; ++vi) {
-        // the whole block decides together: culled, or projected voxel by voxel
-        if (wave == 0) {
-            const ViewDesc dc = views[vi];
-            bool c = brick_is_carved(dc, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
-            if (lane == 0) s_cull = c ? 1 : 0;
-        }
-        __syncthreads();
-        const bool culled = s_cull != 0;
-        __syncthreads();
+        // the verdict of brick_flags_kernel for this brick and view (block-uniform, scalar load)
+        const bool culled = flags[(size_t)vi * gridDim.x + lb] != 0;
         if (culled) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1018,6 +1015,8 @@ struct sc_engine {
     // mask storage for pending views
     std::vector<Chunk> chunks;
 
+    uint8_t *flags = nullptr;  // fused carve, brick form: [dense views][bricks] emptiness verdicts
+    size_t flags_cap = 0;
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
 
     // survivor lists of the fused carve
@@ -1422,13 +1421,25 @@ int flush(sc_engine *e, size_t count = 0) {
                          (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
             if (brick) {
                 uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
-                dim3 bgrid((uint32_t)((uint64_t)e->planes * bys * bzs));
+                uint32_t nbricks = (uint32_t)((uint64_t)e->planes * bys * bzs);
+                dim3 bgrid(nbricks);
+                size_t need = (size_t)nbricks * (size_t)dense_views;
+                if (need > e->flags_cap) {
+                    HIP_TRY(hipStreamSynchronize(e->stream));
+                    if (e->flags) (void)hipFree(e->flags);
+                    e->flags = nullptr;
+                    e->flags_cap = 0;
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->flags), need));
+                    e->flags_cap = need;
+                }
+                hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + kBlock - 1) / kBlock, (uint32_t)dense_views),
+                                   block, 0, e->stream, g, vd, dense_views, bys, bzs, nbricks, e->flags);
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs);
+                                       dense_views, init, ap, bys, bzs, e->flags);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs);
+                                       dense_views, init, ap, bys, bzs, e->flags);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -1638,6 +1649,7 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->flags) (void)hipFree(e->flags);
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl) (void)hipFree(e->ctl);
