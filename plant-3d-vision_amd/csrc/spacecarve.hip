@@ -87,7 +87,7 @@ struct alignas(128) ListCounter {
     uint32_t pad[31];
 };
 struct ListCtl {
-    ListCounter count[2][kSub];  // entries appended per sub-list, ping-pong between stages
+    ListCounter count[3][kSub];  // entries appended per sub-list, one set per list stage
     uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
     uint32_t pad[31];
 };
@@ -407,14 +407,19 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
     return o == 0;
 }
 
-// The emptiness verdict of every (view, brick) pair ahead of the dense kernel, which then reads
-// one byte per brick and view.  (The first brick kernel had its wavefront 0 run the test on 32
-// column end points while the other three waited behind a barrier: 61 % of its wave cycles.)
+// The emptiness verdict of every brick ahead of the dense kernel: flags[brick] = 1 when ANY view
+// of the batch finds the brick empty (carve is order-independent: one in-image zero pixel in any
+// view carves a voxel, backprojection.c:79, so the views tested here need not be the dense
+// stage's).  Blocks of blockIdx.y take kFlagViews views each, early exit on the first hit; the
+// flags are zeroed beforehand and only ever set, so the racing stores are benign.
+// (The first brick kernel had its wavefront 0 run the test on 32 column end points while the other
+// three waited behind a barrier: 61 % of its wave cycles.)
+constexpr int kFlagViews = 2;
+
 __global__ __launch_bounds__(kBlock) void brick_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
                                                              int nviews, uint32_t bricks_y,
                                                              uint32_t bricks_z, uint32_t nbricks,
                                                              uint8_t *__restrict__ flags) {
-    const uint32_t vi = blockIdx.y;  // block-uniform: the descriptor stays in scalar registers
     const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
     if (lb >= nbricks) return;
     const uint32_t per_plane = bricks_y * bricks_z;
@@ -422,25 +427,27 @@ __global__ __launch_bounds__(kBlock) void brick_flags_kernel(GridDesc g, const V
     const uint32_t rem = lb - il * per_plane;
     const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-    const ViewDesc d = views[vi];
-    flags[(size_t)vi * nbricks + lb] =
-        brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ)) ? 1 : 0;
+    const int v0 = (int)blockIdx.y * kFlagViews;  // block-uniform: descriptors stay in scalar registers
+    const int v1 = min(v0 + kFlagViews, nviews);
+    for (int vi = v0; vi < v1; ++vi) {
+        const ViewDesc d = views[vi];
+        if (brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ))) {
+            flags[lb] = 1;
+            return;
+        }
+    }
 }
 
+// The dense kernel proper.  A block takes a STRIP: the bricks_z bricks of one plane and one
+// 16-column band, i.e. 16 whole columns.  It first stores -1 over every brick the flags kernel
+// found empty (nothing but 16-byte stores back to back -- with one brick per block the chain
+// kernel arguments -> flag -> store was paid per 4 KB and bounded the store rate), then
+// projects the voxels of the remaining bricks.
 template <bool FRESH>
-__global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
-                                                             const ViewDesc *__restrict__ views,
-                                                             int nviews, int32_t init, Append ap,
-                                                             uint32_t bricks_y, uint32_t bricks_z,
-                                                             const uint8_t *__restrict__ flags) {
-    const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
-    const uint32_t per_plane = bricks_y * bricks_z;
-    const uint32_t il = lb / per_plane;
-    const uint32_t rem = lb - il * per_plane;
-    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
-    const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+__device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
+                                             const ViewDesc *__restrict__ views, int nviews,
+                                             int32_t init, Append ap, uint32_t il, uint32_t j,
+                                             uint32_t k0, uint32_t lb, uint32_t lane) {
     const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nz + k0;
     int32_t *p = labels + elem;
     int32_t lab[4], was[4];
@@ -464,15 +471,6 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
 
     for (int vi = 0; vi < nviews; ++vi) {
-        // the verdict of brick_flags_kernel for this brick and view (block-uniform, scalar load)
-        const bool culled = flags[(size_t)vi * gridDim.x + lb] != 0;
-        if (culled) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((alive >> e) & 1u) lab[e] = -1;
-            alive = 0;
-            break;  // block-uniform: everything is carved
-        }
         if (__ballot(alive != 0) != 0) {  // this wavefront still has live voxels
             const ViewDesc d = views[vi];
             float ax = d.R[0] * x + d.R[1] * y;
@@ -538,6 +536,30 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
     }
 }
 
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                             const ViewDesc *__restrict__ views,
+                                                             int nviews, int32_t init, Append ap,
+                                                             uint32_t bricks_y, uint32_t bricks_z,
+                                                             const uint8_t *__restrict__ flags) {
+    const uint32_t strip = spread_block(blockIdx.x, gridDim.x);
+    const uint32_t il = strip / bricks_y;
+    const uint32_t by = strip - il * bricks_y;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const uint32_t lb0 = strip * bricks_z;
+    // bit bz: some view sees brick bz whole, in-image, over background (bricks_z <= 64)
+    const unsigned long long culled = __ballot(lane < bricks_z && flags[lb0 + min(lane, bricks_z - 1)] != 0);
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz + (lane & 15) * 4;
+    for (uint32_t bz = 0; bz < bricks_z; ++bz)
+        if ((culled >> bz) & 1ull)  // live voxels become -1, dead ones are -1 already
+            *reinterpret_cast<int4 *>(col + bz * kBrickZ) = make_int4(-1, -1, -1, -1);
+    for (uint32_t bz = 0; bz < bricks_z; ++bz)
+        if (!((culled >> bz) & 1ull))
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4,
+                                lb0 + bz, lane);
+}
+
 // One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
 // the kernel arguments (no copy, no host-side wait), and each lane walks kStreamGroups
 // 16-byte groups with the next group's state load already in flight -- after the first view
@@ -579,8 +601,8 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
                                                             int nviews,
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
-                                                            ListCtl *ctl, int sin, uint32_t subcap,
-                                                            int vgsize) {
+                                                            ListCtl *ctl, int sin, int sout,
+                                                            uint32_t subcap, int vgsize) {
     __shared__ uint32_t pref[kSub + 1];
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
     const uint32_t tid = threadIdx.x;
@@ -663,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
                     int leader = __ffsll((long long)act) - 1;
                     uint32_t base = 0;
                     if ((int)lane == leader)
-                        base = atomicAdd(&ctl->count[sin ^ 1][s].n, (uint32_t)__popcll(b));
+                        base = atomicAdd(&ctl->count[sout][s].n, (uint32_t)__popcll(b));
                     base = __shfl(base, leader);
                     // survivors of sub-list s never outnumber its entries: no overflow here
                     if (alive) {
@@ -1015,7 +1037,8 @@ struct sc_engine {
     // mask storage for pending views
     std::vector<Chunk> chunks;
 
-    uint8_t *flags = nullptr;  // fused carve, brick form: [dense views][bricks] emptiness verdicts
+    uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick
+    int64_t flag_views = 8;    // views that may veto a brick (0 = all of the batch)
     size_t flags_cap = 0;
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
 
@@ -1041,8 +1064,9 @@ struct sc_engine {
     int64_t brick = 1;
     int64_t dense_views = 2;     // views applied to every voxel before compaction
     int64_t stage1_views = 8;    // views applied to the first survivor list
+    int64_t stage2_views = 0;    // views applied to the second survivor list (0: no such stage)
     int64_t list_blocks = 2048;  // persistent grid of the list / resume kernels
-    int64_t view_group = 8;      // views per work item in the final list stage
+    int64_t view_group = 16;     // views per work item in the final list stage
 
     std::vector<TimedLaunch> timed[kNumKernels];
     std::vector<hipEvent_t> event_pool;
@@ -1418,12 +1442,12 @@ int flush(sc_engine *e, size_t count = 0) {
 #undef LAUNCH_CARVE1
         } else {
             bool brick = e->brick && (e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0 &&
-                         (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
+                         e->nz / kBrickZ <= 64 && (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
             if (brick) {
                 uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
                 uint32_t nbricks = (uint32_t)((uint64_t)e->planes * bys * bzs);
-                dim3 bgrid(nbricks);
-                size_t need = (size_t)nbricks * (size_t)dense_views;
+                dim3 bgrid((uint32_t)((uint64_t)e->planes * bys));  // one block per strip of bzs bricks
+                size_t need = (size_t)nbricks;
                 if (need > e->flags_cap) {
                     HIP_TRY(hipStreamSynchronize(e->stream));
                     if (e->flags) (void)hipFree(e->flags);
@@ -1432,8 +1456,14 @@ int flush(sc_engine *e, size_t count = 0) {
                     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->flags), need));
                     e->flags_cap = need;
                 }
-                hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + kBlock - 1) / kBlock, (uint32_t)dense_views),
-                                   block, 0, e->stream, g, vd, dense_views, bys, bzs, nbricks, e->flags);
+                // every view of the batch may veto a brick, not only the dense stage's
+                int flag_views = (int)nv;
+                if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
+                HIP_TRY(hipMemsetAsync(e->flags, 0, nbricks, e->stream));
+                hipLaunchKernelGGL(brick_flags_kernel,
+                                   dim3((nbricks + kBlock - 1) / kBlock,
+                                        (uint32_t)((flag_views + kFlagViews - 1) / kFlagViews)),
+                                   block, 0, e->stream, g, vd, flag_views, bys, bzs, nbricks, e->flags);
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags);
@@ -1461,18 +1491,25 @@ int flush(sc_engine *e, size_t count = 0) {
             LaunchTimer lt2{e, SC_KERNEL_LIST};
             rc = lt2.begin();
             if (rc) return rc;
-            bool two = (size_t)s1 < nv;
             int vg = (int)e->view_group;
-            if (two) {
-                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, e->subcap, vg);
+            // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
+            int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
+            uint32_t *nolist = nullptr;
+            if ((size_t)s1 >= nv) {
                 hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + s1, (int)nv - s1, l1, static_cast<uint32_t *>(nullptr), e->ctl,
-                                   1, e->subcap, vg);
+                                   g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg);
             } else {
-                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0,
-                                   static_cast<uint32_t *>(nullptr), e->ctl, 0, e->subcap, vg);
+                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream, st,
+                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg);
+                if (s2 > s1 && (size_t)s2 < nv) {
+                    hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream,
+                                       st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg);
+                    hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream,
+                                       st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg);
+                } else {
+                    hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream,
+                                       st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg);
+                }
             }
             if (vec)
                 hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
@@ -1699,6 +1736,14 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_BRICK:
             e->brick = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_STAGE2_VIEWS:
+            if (value < 0 || value > 4096) return fail(SC_ERR_INVALID, "stage2_views must be in [0, 4096]");
+            e->stage2_views = value;
+            return SC_OK;
+        case SC_OPT_FLAG_VIEWS:
+            if (value < 0) return fail(SC_ERR_INVALID, "flag_views must be >= 0");
+            e->flag_views = value;
             return SC_OK;
         case SC_OPT_VIEW_GROUP:
             if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "view_group must be in [1, 4096]");
