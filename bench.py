@@ -37,8 +37,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
-# x-planes dealt round-robin over the ranks.  Shapes for n = 512 (nx divisible by N, nz by 4):
-GRIDS_512 = {1: (512, 512, 512), 2: (640, 648, 648), 4: (812, 812, 816), 8: (1024, 1024, 1024)}
+# x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
+# nz by 64, so the dense stage runs in its brick form (include/spacecarve.h, SC_OPT_BRICK):
+GRIDS_512 = {1: (512, 512, 512), 2: (640, 640, 640), 4: (808, 800, 832), 8: (1024, 1024, 1024)}
 
 
 def parse():
@@ -65,10 +66,11 @@ def parse():
 def global_shape(n, gpus):
     if n == 512 and gpus in GRIDS_512:
         return list(GRIDS_512[gpus])
-    # general case: a cube of about gpus * n^3 voxels, nx a multiple of gpus, ny, nz multiples of 4
+    # general case: a cube of about gpus * n^3 voxels, nx a multiple of gpus, ny of 16, nz of 64
     edge = (gpus * n ** 3) ** (1.0 / 3.0)
     nx = max(gpus, int(round(edge / gpus)) * gpus)
-    ny = nz = max(4, int(round(edge / 4)) * 4)
+    ny = max(16, int(round(edge / 16)) * 16)
+    nz = max(64, int(round(edge / 64)) * 64)
     return [nx, ny, nz]
 
 
@@ -102,7 +104,8 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world):
         dt = float(tt.item())
     stats = {}
     for name, kid in (("carve", nat.SC_KERNEL_CARVE), ("list", nat.SC_KERNEL_LIST),
-                      ("pack", nat.SC_KERNEL_PACK), ("fill", nat.SC_KERNEL_FILL)):
+                      ("pack", nat.SC_KERNEL_PACK), ("fill", nat.SC_KERNEL_FILL),
+                      ("flags", nat.SC_KERNEL_FLAGS)):
         n, ms = engine.kernel_stats(kid)
         stats[name] = {"launches": n, "total_ms": ms, "avg_ms": (ms / n if n else 0.0)}
     engine.set_option(nat.SC_OPT_TIME_KERNELS, 0)
@@ -254,7 +257,9 @@ def main():
             units = n_local
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "carve_kernel",
+             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+             "kernel": ("carve_brick_kernel<true> (dense stage; carve_kernel<true> when the grid has no "
+                        "brick form)" if path == "fused" else "carve_kernel_1<false>"),
              "avg_launch_ms": avg_ms, "launches": st["carve"]["launches"],
              "algorithmic_bytes_per_launch": bytes_launch, "bytes_model": model,
              "voxel_views_per_launch": units}

@@ -79,6 +79,7 @@ extern "C" {
                                      works on 16x64-voxel bricks with a conservative emptiness
                                      test per brick; 0: linear blocks only                       */
 #define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
+#define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */
@@ -87,6 +88,7 @@ extern "C" {
 #define SC_KERNEL_PACK 2
 #define SC_KERNEL_FILL 3
 #define SC_KERNEL_LIST 4 /* survivor-list stages + dense resume of a fused carve */
+#define SC_KERNEL_FLAGS 5 /* brick emptiness verdicts ahead of the dense stage (brick form) */
 
 typedef struct sc_engine sc_engine;
 

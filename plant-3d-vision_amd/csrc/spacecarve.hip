@@ -932,8 +932,11 @@ __device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
     return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
 }
 
-constexpr int kPackRows = 4;  // tile rows per block: that many 16-byte loads in flight per lane
-
+// (Measured: 44-50 us for 72 masks of 1440x1080 whatever ROWS is, and the same for a band form
+// reading whole rows contiguously.  tools/probes/read_probe.hip: a plain read of those 112 MB
+// takes 41 us when they come from HBM -- every step writes 0.5 GB of labels in between, so they
+// do -- and 19 us from the Infinity Cache.  The kernel sits on the cold-read floor.)
+template <int ROWS>  // tile rows per block: that many 16-byte loads in flight per lane
 __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restrict__ raw,
                                                         int64_t row_stride, int64_t view_stride,
                                                         int W, int H, int nviews, int tiles_x,
@@ -941,39 +944,48 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
                                                         int64_t out_view_words, uint32_t flip,
                                                         uint8_t *__restrict__ occ) {
     // flip: 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
+    __shared__ uint32_t occ_s[ROWS * 4];
     const int lane = threadIdx.x & 63;
-    const int txb = (tiles_x + 3) >> 2;                      // panels per tile row
-    const int tyb = (tiles_y + kPackRows - 1) / kPackRows;   // block rows per view
+    const int txb = (tiles_x + 3) >> 2;            // panels per tile row
+    const int tyb = (tiles_y + ROWS - 1) / ROWS;   // block rows per view
     int64_t b = blockIdx.x;
     int bx = (int)(b % txb);
     int64_t r = b / txb;
     int by = (int)(r % tyb);
     int view = (int)(r / tyb);
-    if (view >= nviews) return;
+    if (view >= nviews) return;  // block-uniform
+    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = 0;
     int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
     int c = lane & 7;                                      // 16-pixel chunk inside the panel
     int u0 = bx * 128 + c * 16;
     int tx = bx * 4 + (c >> 1);
-    uint4 q[kPackRows];
+    uint4 q[ROWS];
 #pragma unroll
-    for (int k = 0; k < kPackRows; ++k) {
-        int v = (by * kPackRows + k) * 32 + row;
+    for (int k = 0; k < ROWS; ++k) {
+        int v = (by * ROWS + k) * 32 + row;
         q[k] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
         if (v < H && u0 < W)  // W % 16 == 0: a 16-pixel run is inside the row or outside it
             q[k] = *reinterpret_cast<const uint4 *>(raw + view * view_stride + (int64_t)v * row_stride + u0);
     }
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kPackRows; ++k) {
-        int ty = by * kPackRows + k;
+    for (int k = 0; k < ROWS; ++k) {
+        int ty = by * ROWS + k;
         uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
                         (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
         uint32_t other = __shfl_xor(half, 1);
         uint32_t word = half | (other << 16);
         if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
             out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
-            // tile occupancy (zeroed by the host): any wavefront that sees foreground says so
-            if (word) occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + tx] = 1;
+            if (word) occ_s[k * 4 + (c >> 1)] = 1;  // racing stores of the same value
         }
+    }
+    __syncthreads();
+    // tile occupancy: every byte written here (0 or 1), nothing for the host to clear
+    if (threadIdx.x < ROWS * 4) {
+        int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
+        if (ty < tiles_y && txo < tiles_x)
+            occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] = occ_s[threadIdx.x] ? 1 : 0;
     }
 }
 
@@ -1012,7 +1024,7 @@ struct TimedLaunch {
 };
 
 constexpr int kSlots = 4;
-constexpr int kNumKernels = 5;
+constexpr int kNumKernels = 6;
 
 }  // namespace
 
@@ -1037,9 +1049,9 @@ struct sc_engine {
     // mask storage for pending views
     std::vector<Chunk> chunks;
 
-    uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick
+    uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick (inside ctl's allocation)
+    int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
     int64_t flag_views = 8;    // views that may veto a brick (0 = all of the batch)
-    size_t flags_cap = 0;
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
 
     // survivor lists of the fused carve
@@ -1249,21 +1261,29 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     rc = arena_alloc(e, occ_bytes * (size_t)V, &occ_v);
     if (rc) return rc;
     uint8_t *occ = static_cast<uint8_t *>(occ_v);
-    HIP_TRY(hipMemsetAsync(occ, 0, occ_bytes * (size_t)V, e->stream));
     LaunchTimer lt{e, SC_KERNEL_PACK};
     bool bytes = dtype != SC_MASK_I32;
     uint32_t flip = dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
     bool fast = bytes && (W % 16) == 0 && (row_stride % 16) == 0 &&
                 (view_stride % 16) == 0 && (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
     if (fast) {
-        int64_t blocks = (int64_t)V * ((tiles_y + kPackRows - 1) / kPackRows) * ((tiles_x + 3) / 4);
+        const int rows = (int)e->pack_rows;
+        int64_t blocks = (int64_t)V * ((tiles_y + rows - 1) / rows) * ((tiles_x + 3) / 4);
         if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
         rc = lt.begin();
         if (rc) return rc;
-        hipLaunchKernelGGL(pack16_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
-                           static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,
-                           tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip, occ);
+#define LAUNCH_PACK16(ROWS)                                                                      \
+    hipLaunchKernelGGL(pack16_kernel<ROWS>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,   \
+                       static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,   \
+                       tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip, occ)
+        if (rows == 1) LAUNCH_PACK16(1);
+        else if (rows == 2) LAUNCH_PACK16(2);
+        else if (rows == 8) LAUNCH_PACK16(8);
+        else LAUNCH_PACK16(4);
+#undef LAUNCH_PACK16
     } else {
+        // the slow forms only ever set occupancy bytes
+        HIP_TRY(hipMemsetAsync(occ, 0, occ_bytes * (size_t)V, e->stream));
         int segs = (W + 63) / 64;
         int64_t waves = (int64_t)V * H * segs;
         int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
@@ -1365,7 +1385,19 @@ int ensure_lists(sc_engine *e) {
     uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4, (uint64_t)kSub * 1024);
     e->subcap = (uint32_t)((total + kSub - 1) / kSub);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lists), (size_t)2 * kSub * e->subcap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->ctl), sizeof(ListCtl)));
+    return SC_OK;
+}
+
+// List counters and brick verdicts share one allocation: one memset clears both per fused launch.
+int ensure_ctl(sc_engine *e) {
+    if (e->ctl) return SC_OK;
+    size_t nbricks = 0;
+    if ((e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0)
+        nbricks = (size_t)e->planes * (size_t)(e->ny / kBrickY) * (size_t)(e->nz / kBrickZ);
+    char *base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), sizeof(ListCtl) + nbricks + 16));
+    e->ctl = reinterpret_cast<ListCtl *>(base);
+    e->flags = reinterpret_cast<uint8_t *>(base + sizeof(ListCtl));
     return SC_OK;
 }
 
@@ -1416,18 +1448,30 @@ int flush(sc_engine *e, size_t count = 0) {
                        (uint64_t)e->n < 0x80000000ull;
         Append ap{nullptr, nullptr, 0u, 0u};
         int dense_views = (int)nv;
+        bool brick = nv > 1 && e->brick && (e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0 &&
+                     e->nz / kBrickZ <= 64 && (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
+        const uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
+        const uint32_t nbricks = brick ? (uint32_t)((uint64_t)e->planes * bys * bzs) : 0u;
+        if (compact || brick) {
+            rc = ensure_ctl(e);
+            if (rc) return rc;
+            // counters (when lists are used) and brick verdicts (when bricks are) in one fill
+            size_t lo = compact ? 0 : sizeof(ListCtl), hi = sizeof(ListCtl) + nbricks;
+            if (hi > lo) HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(e->ctl) + lo, 0, hi - lo, e->stream));
+        }
         if (compact) {
             rc = ensure_lists(e);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
             ap.list = e->lists;
             ap.ctl = e->ctl;
             ap.subcap = e->subcap;
             dense_views = ndense;
         }
         LaunchTimer lt{e, SC_KERNEL_CARVE};
-        rc = lt.begin();
-        if (rc) return rc;
+        if (!brick) {  // the brick form starts the timer after its flags kernel
+            rc = lt.begin();
+            if (rc) return rc;
+        }
         if (nv == 1) {
             // kStreamGroups groups per lane when the state is streamed through (see kernel)
             uint32_t per_block = (!e->fresh && vec) ? kBlock * kStreamGroups : kBlock;
@@ -1441,29 +1485,22 @@ int flush(sc_engine *e, size_t count = 0) {
             }
 #undef LAUNCH_CARVE1
         } else {
-            bool brick = e->brick && (e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0 &&
-                         e->nz / kBrickZ <= 64 && (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
             if (brick) {
-                uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
-                uint32_t nbricks = (uint32_t)((uint64_t)e->planes * bys * bzs);
                 dim3 bgrid((uint32_t)((uint64_t)e->planes * bys));  // one block per strip of bzs bricks
-                size_t need = (size_t)nbricks;
-                if (need > e->flags_cap) {
-                    HIP_TRY(hipStreamSynchronize(e->stream));
-                    if (e->flags) (void)hipFree(e->flags);
-                    e->flags = nullptr;
-                    e->flags_cap = 0;
-                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->flags), need));
-                    e->flags_cap = need;
-                }
                 // every view of the batch may veto a brick, not only the dense stage's
                 int flag_views = (int)nv;
                 if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
-                HIP_TRY(hipMemsetAsync(e->flags, 0, nbricks, e->stream));
+                LaunchTimer ltf{e, SC_KERNEL_FLAGS};
+                rc = ltf.begin();
+                if (rc) return rc;
                 hipLaunchKernelGGL(brick_flags_kernel,
                                    dim3((nbricks + kBlock - 1) / kBlock,
                                         (uint32_t)((flag_views + kFlagViews - 1) / kFlagViews)),
                                    block, 0, e->stream, g, vd, flag_views, bys, bzs, nbricks, e->flags);
+                rc = ltf.end();
+                if (rc) return rc;
+                rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
+                if (rc) return rc;
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags);
@@ -1686,7 +1723,6 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
-    if (e->flags) (void)hipFree(e->flags);
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl) (void)hipFree(e->ctl);
@@ -1740,6 +1776,11 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_STAGE2_VIEWS:
             if (value < 0 || value > 4096) return fail(SC_ERR_INVALID, "stage2_views must be in [0, 4096]");
             e->stage2_views = value;
+            return SC_OK;
+        case SC_OPT_PACK_ROWS:
+            if (value != 1 && value != 2 && value != 4 && value != 8)
+                return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
+            e->pack_rows = value;
             return SC_OK;
         case SC_OPT_FLAG_VIEWS:
             if (value < 0) return fail(SC_ERR_INVALID, "flag_views must be >= 0");

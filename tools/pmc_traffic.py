@@ -37,6 +37,7 @@ def mean_counter(tag, which):
 
 def short(name):
     for key in ("carve_kernel_1<false", "carve_kernel_1<true", "carve_kernel<true", "carve_kernel<false",
+                "carve_brick_kernel<true", "carve_brick_kernel<false", "brick_flags_kernel",
                 "carve_list_kernel<true", "carve_list_kernel<false", "carve_resume_kernel<true",
                 "carve_resume_kernel<false", "average_kernel", "pack_kernel", "pack16_kernel", "fill_kernel"):
         if key in name:
@@ -75,7 +76,9 @@ def main():
     json.dump(per_kernel, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc.json"), "w"), indent=1, sort_keys=True)
     traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-    for path, key in (("stream", "carve_kernel_1<false>"), ("fused", "carve_kernel<true>")):
+    # the fused path's dominant kernel is the dense stage: brick form when the grid allows it
+    fused_key = "carve_brick_kernel<true>" if "carve_brick_kernel<true>" in per_kernel else "carve_kernel<true>"
+    for path, key in (("stream", "carve_kernel_1<false>"), ("fused", fused_key)):
         for s, ent in per_kernel.items():
             if s.startswith(key[:-1]) and "hbm_bytes_per_launch" in ent:
                 traffic[f"{path}_{a.scene}_{a.n}_{a.views}"] = {
