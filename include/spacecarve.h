@@ -64,7 +64,10 @@ extern "C" {
                                      order-independent). average always keeps
                                      the given order (float sum).                             */
 #define SC_OPT_TIME_KERNELS 3     /* 1: bracket every kernel launch with HIP events on the
-                                     engine's stream; read with sc_kernel_stats              */
+                                     engine's stream; read with sc_kernel_stats.  2: only the
+                                     carve / average kernel of a per-view launch and one pair
+                                     around each fused batch, SC_KERNEL_STEP (an event pair costs
+                                     a few microseconds of stream time)                       */
 #define SC_OPT_MAX_PENDING 4      /* deferred views that force a flush (default 256)          */
 #define SC_OPT_COMPACT 5          /* carve only. 1 (default): a fused launch of >= 6 views is dense
                                      for its first two views, then finishes the survivors from
@@ -80,6 +83,10 @@ extern "C" {
                                      test per brick; 0: linear blocks only                       */
 #define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
 #define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
+#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1536): the -1 fill of bricks found empty is done by
+                                     store blocks running beside n persistent blocks of the final
+                                     survivor stage; 0: by the dense stage                          */
+#define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */
@@ -89,6 +96,7 @@ extern "C" {
 #define SC_KERNEL_FILL 3
 #define SC_KERNEL_LIST 4 /* survivor-list stages + dense resume of a fused carve */
 #define SC_KERNEL_FLAGS 5 /* brick emptiness verdicts ahead of the dense stage (brick form) */
+#define SC_KERNEL_STEP 6  /* a whole fused batch: mask packing + every kernel of its launch     */
 
 typedef struct sc_engine sc_engine;
 

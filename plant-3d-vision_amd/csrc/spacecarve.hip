@@ -92,6 +92,12 @@ struct ListCtl {
     uint32_t pad[31];
 };
 
+// Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
+struct CullStores {
+    const uint8_t *flags;  // null: nothing deferred
+    uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
+};
+
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
 // kXcdRun consecutive logical blocks (neighbouring columns, which project onto the same mask
 // lines) stay on one XCD's L2.  Which XCD takes which run of a group of 8 rotates from group
@@ -536,13 +542,40 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     }
 }
 
+// -1 over every brick of a strip that the flags kernel found empty: live voxels become -1,
+// dead ones are -1 already.  One 16-byte store per lane and brick, nothing else.
+__device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
+                                                    const uint8_t *__restrict__ flags, uint32_t strip,
+                                                    uint32_t bricks_y, uint32_t bricks_z) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const unsigned long long culled =
+        __ballot(lane < bricks_z && flags[strip * bricks_z + min(lane, bricks_z - 1)] != 0);
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz + (lane & 15) * 4;
+    for (uint32_t bz = 0; bz < bricks_z; ++bz)
+        if ((culled >> bz) & 1ull)
+            *reinterpret_cast<int4 *>(col + bz * kBrickZ) = make_int4(-1, -1, -1, -1);
+}
+
+// Blocks [0, nstrips) project the voxels of the bricks of their strip that are not empty;
+// blocks [nstrips, nstrips + nstore) fill the empty bricks of strips [0, nstore) (the final list
+// stage fills the others, see carve_list_kernel).  The voxel blocks are dispatched first: the
+// ones with work stay (they wait on mask gathers and list atomics), the rest leave at once, and
+// the store blocks stream through the free slots -- arithmetic and HBM writes side by side.
+// (With both roles in one block the kernel took the sum of the two: 106 us = 48 + 58.)
 template <bool FRESH>
 __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
                                                              uint32_t bricks_y, uint32_t bricks_z,
-                                                             const uint8_t *__restrict__ flags) {
-    const uint32_t strip = spread_block(blockIdx.x, gridDim.x);
+                                                             const uint8_t *__restrict__ flags,
+                                                             uint32_t nstrips) {
+    if (blockIdx.x >= nstrips) {
+        store_culled_bricks(labels, g, flags, blockIdx.x - nstrips, bricks_y, bricks_z);
+        return;
+    }
+    const uint32_t strip = spread_block(blockIdx.x, nstrips);
     const uint32_t il = strip / bricks_y;
     const uint32_t by = strip - il * bricks_y;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -550,10 +583,6 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
     const uint32_t lb0 = strip * bricks_z;
     // bit bz: some view sees brick bz whole, in-image, over background (bricks_z <= 64)
     const unsigned long long culled = __ballot(lane < bricks_z && flags[lb0 + min(lane, bricks_z - 1)] != 0);
-    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz + (lane & 15) * 4;
-    for (uint32_t bz = 0; bz < bricks_z; ++bz)
-        if ((culled >> bz) & 1ull)  // live voxels become -1, dead ones are -1 already
-            *reinterpret_cast<int4 *>(col + bz * kBrickZ) = make_int4(-1, -1, -1, -1);
     for (uint32_t bz = 0; bz < bricks_z; ++bz)
         if (!((culled >> bz) & 1ull))
             brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4,
@@ -602,10 +631,21 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
                                                             ListCtl *ctl, int sin, int sout,
-                                                            uint32_t subcap, int vgsize) {
+                                                            uint32_t subcap, int vgsize, CullStores cs) {
     __shared__ uint32_t pref[kSub + 1];
-    if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
     const uint32_t tid = threadIdx.x;
+    // A final stage with deferred stores has cs.nstrips STORE blocks behind its persistent list
+    // blocks: this stage is bound by projection arithmetic and the -1 fill of the bricks the flags
+    // kernel found empty by HBM writes, so the two run side by side instead of one after the
+    // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
+    const bool split = FINAL && cs.flags != nullptr;
+    const uint32_t nbid = split ? gridDim.x - (cs.nstrips - cs.first) : gridDim.x;
+    if (split && blockIdx.x >= nbid) {
+        store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z);
+        return;
+    }
+    if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
+    const uint32_t bid = blockIdx.x;
     {
         uint32_t c = (min(ctl->count[sin][tid].n, subcap) + 63u) / 64u;  // kSub == kBlock
         if (tid == 0) pref[0] = 0;
@@ -623,11 +663,11 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
     const uint32_t vgroups = FINAL ? (uint32_t)((nviews + vgsize - 1) / vgsize) : 1u;
     const uint64_t items = (uint64_t)chunks * vgroups;
     const uint32_t lane = tid & 63u;
-    const uint64_t nworkers = (uint64_t)gridDim.x * (kBlock / 64);
+    const uint64_t nworkers = (uint64_t)nbid * (kBlock / 64);
     // the wavefront index must be a scalar for the compiler, or everything derived from the
     // item (view range, descriptors) is treated as divergent and fetched with vector loads
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (uint64_t item = (uint64_t)blockIdx.x * (kBlock / 64) + wave; item < items;
+    for (uint64_t item = (uint64_t)bid * (kBlock / 64) + wave; item < items;
          item += nworkers) {
         // neighbouring wavefronts take neighbouring chunks of the same view group
         const uint32_t vgi = (uint32_t)(item / chunks);
@@ -1024,7 +1064,7 @@ struct TimedLaunch {
 };
 
 constexpr int kSlots = 4;
-constexpr int kNumKernels = 6;
+constexpr int kNumKernels = 7;
 
 }  // namespace
 
@@ -1050,6 +1090,8 @@ struct sc_engine {
     std::vector<Chunk> chunks;
 
     uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick (inside ctl's allocation)
+    int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
+    int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
     int64_t flag_views = 8;    // views that may veto a brick (0 = all of the batch)
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
@@ -1081,6 +1123,8 @@ struct sc_engine {
     int64_t view_group = 16;     // views per work item in the final list stage
 
     std::vector<TimedLaunch> timed[kNumKernels];
+    hipEvent_t step_start = nullptr;
+    bool step_open = false;
     std::vector<hipEvent_t> event_pool;
 };
 
@@ -1101,6 +1145,33 @@ int get_event(sc_engine *e, hipEvent_t *ev) {
     return SC_OK;
 }
 
+// SC_KERNEL_STEP: one event pair around everything a fused batch puts on the stream, from the
+// packing of its masks to its last kernel.
+int step_begin(sc_engine *e) {
+    if (!e->time_kernels || e->step_open || e->views_per_launch == 1) return SC_OK;
+    int rc = get_event(e, &e->step_start);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->step_start, e->stream));
+    e->step_open = true;
+    return SC_OK;
+}
+
+int step_end(sc_engine *e, bool fused) {
+    if (!e->step_open) return SC_OK;
+    e->step_open = false;
+    if (!fused) {
+        e->event_pool.push_back(e->step_start);
+        return SC_OK;
+    }
+    TimedLaunch tl{};
+    tl.start = e->step_start;
+    int rc = get_event(e, &tl.stop);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(tl.stop, e->stream));
+    e->timed[SC_KERNEL_STEP].push_back(tl);
+    return SC_OK;
+}
+
 struct LaunchTimer {
     sc_engine *e;
     int kid;
@@ -1108,6 +1179,8 @@ struct LaunchTimer {
     bool on = false;
     int begin() {
         if (!e->time_kernels) return SC_OK;
+        if (e->time_kernels == 2 && kid != SC_KERNEL_CARVE && kid != SC_KERNEL_AVERAGE) return SC_OK;
+        if (e->time_kernels == 2 && kid == SC_KERNEL_CARVE && e->step_open) return SC_OK;  // SC_KERNEL_STEP covers it
         int rc = get_event(e, &tl.start);
         if (rc) return rc;
         rc = get_event(e, &tl.stop);
@@ -1261,6 +1334,8 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     rc = arena_alloc(e, occ_bytes * (size_t)V, &occ_v);
     if (rc) return rc;
     uint8_t *occ = static_cast<uint8_t *>(occ_v);
+    rc = step_begin(e);
+    if (rc) return rc;
     LaunchTimer lt{e, SC_KERNEL_PACK};
     bool bytes = dtype != SC_MASK_I32;
     uint32_t flip = dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
@@ -1412,6 +1487,10 @@ int flush(sc_engine *e, size_t count = 0) {
     dim3 grid((uint32_t)blocks), block(kBlock);
     const ViewDesc *vd = nullptr;
     if (nv > 1) {
+        int rcs = step_begin(e);
+        if (rcs) return rcs;
+    }
+    if (nv > 1) {
         if (e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
             order_views(e->pending);
         // descriptor ring: slots are reused only after a wrap, which waits for the stream
@@ -1452,6 +1531,14 @@ int flush(sc_engine *e, size_t count = 0) {
                      e->nz / kBrickZ <= 64 && (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
         const uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
         const uint32_t nbricks = brick ? (uint32_t)((uint64_t)e->planes * bys * bzs) : 0u;
+        // the -1 fill of empty bricks rides along with the final list stage when there is one
+        const uint32_t nstrips = brick ? (uint32_t)((uint64_t)e->planes * bys) : 0u;
+        // strips [0, dense_store_strips) are filled by the dense kernel's store blocks, the others
+        // by the final list stage's (defer_share sixteenths of them, when there is such a stage)
+        uint32_t dense_store_strips = nstrips;
+        if (brick && compact && e->defer_stores > 0 && e->defer_share > 0)
+            dense_store_strips = (uint32_t)((uint64_t)nstrips * (uint64_t)(16 - e->defer_share) / 16u);
+        const bool defer_stores = dense_store_strips < nstrips;
         if (compact || brick) {
             rc = ensure_ctl(e);
             if (rc) return rc;
@@ -1486,7 +1573,7 @@ int flush(sc_engine *e, size_t count = 0) {
 #undef LAUNCH_CARVE1
         } else {
             if (brick) {
-                dim3 bgrid((uint32_t)((uint64_t)e->planes * bys));  // one block per strip of bzs bricks
+                dim3 bgrid(nstrips + dense_store_strips);  // voxel blocks, then store blocks
                 // every view of the batch may veto a brick, not only the dense stage's
                 int flag_views = (int)nv;
                 if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
@@ -1503,10 +1590,10 @@ int flush(sc_engine *e, size_t count = 0) {
                 if (rc) return rc;
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags);
+                                       dense_views, init, ap, bys, bzs, e->flags, nstrips);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags);
+                                       dense_views, init, ap, bys, bzs, e->flags, nstrips);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -1529,23 +1616,31 @@ int flush(sc_engine *e, size_t count = 0) {
             rc = lt2.begin();
             if (rc) return rc;
             int vg = (int)e->view_group;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u}, cs = none;
+            // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
+            // wavefront slots free) and one short store block per strip behind them
+            dim3 fgrid(list_blocks);
+            if (defer_stores) {
+                cs = CullStores{e->flags, bys, bzs, nstrips, dense_store_strips};
+                fgrid = dim3((uint32_t)e->defer_stores + (nstrips - dense_store_strips));
+            }
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
             int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
             uint32_t *nolist = nullptr;
             if ((size_t)s1 >= nv) {
-                hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg);
+                hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream, st,
+                                   g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs);
             } else {
                 hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg);
+                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, none);
                 if (s2 > s1 && (size_t)s2 < nv) {
                     hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream,
-                                       st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg);
-                    hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                                       st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg);
+                                       st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none);
+                    hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream,
+                                       st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs);
                 } else {
-                    hipLaunchKernelGGL(carve_list_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                                       st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg);
+                    hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream,
+                                       st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs);
                 }
             }
             if (vec)
@@ -1582,6 +1677,8 @@ int flush(sc_engine *e, size_t count = 0) {
         rc = lt.end();
         if (rc) return rc;
     }
+    rc = step_end(e, nv > 1);
+    if (rc) return rc;
     e->fresh = false;
     e->pending.erase(e->pending.begin(), e->pending.begin() + (ptrdiff_t)nv);
     if (e->pending.empty()) arena_reset(e);  // masks of launched views are dead in stream order
@@ -1714,6 +1811,7 @@ void sc_destroy(sc_engine *e) {
             (void)hipEventDestroy(tl.start);
             (void)hipEventDestroy(tl.stop);
         }
+    if (e->step_open) (void)hipEventDestroy(e->step_start);
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     for (auto &c : e->chunks) (void)hipFree(c.base);
     for (int s = 0; s < kSlots; ++s) {
@@ -1753,7 +1851,7 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             e->view_order = value;
             return SC_OK;
         case SC_OPT_TIME_KERNELS:
-            e->time_kernels = value ? 1 : 0;
+            e->time_kernels = value == 2 ? 2 : (value ? 1 : 0);
             return SC_OK;
         case SC_OPT_COMPACT:
             e->compact = value ? 1 : 0;
@@ -1776,6 +1874,14 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_STAGE2_VIEWS:
             if (value < 0 || value > 4096) return fail(SC_ERR_INVALID, "stage2_views must be in [0, 4096]");
             e->stage2_views = value;
+            return SC_OK;
+        case SC_OPT_DEFER_SHARE:
+            if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "defer_share must be in [0, 16]");
+            e->defer_share = value;
+            return SC_OK;
+        case SC_OPT_DEFER_STORES:
+            if (value < 0 || value > 65536) return fail(SC_ERR_INVALID, "defer_stores must be in [0, 65536]");
+            e->defer_stores = value;
             return SC_OK;
         case SC_OPT_PACK_ROWS:
             if (value != 1 && value != 2 && value != 4 && value != 8)
