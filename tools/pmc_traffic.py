@@ -39,7 +39,7 @@ def short(name):
     for key in ("carve_kernel_1<false", "carve_kernel_1<true", "carve_kernel<true", "carve_kernel<false",
                 "carve_brick_kernel<true", "carve_brick_kernel<false", "brick_flags_kernel",
                 "carve_list_kernel<true", "carve_list_kernel<false", "carve_resume_kernel<true",
-                "carve_resume_kernel<false", "average_kernel", "pack_kernel", "pack16_kernel", "fill_kernel"):
+                "carve_resume_kernel<false", "average_kernel", "pack16_kernel", "pack_kernel", "fill_kernel"):
         if key in name:
             return key + (">" if "<" in key else "")
     return name[:40]
@@ -76,14 +76,21 @@ def main():
     json.dump(per_kernel, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc.json"), "w"), indent=1, sort_keys=True)
     traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-    # the fused path's dominant kernel is the dense stage: brick form when the grid allows it
-    fused_key = "carve_brick_kernel<true>" if "carve_brick_kernel<true>" in per_kernel else "carve_kernel<true>"
-    for path, key in (("stream", "carve_kernel_1<false>"), ("fused", fused_key)):
-        for s, ent in per_kernel.items():
-            if s.startswith(key[:-1]) and "hbm_bytes_per_launch" in ent:
-                traffic[f"{path}_{a.scene}_{a.n}_{a.views}"] = {
-                    "hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": f"profiles/{a.tag}_pmc.json",
-                    "kernel": ent["kernel"], "read_correction": ent["read_correction"]}
+    # stream: the per-view kernel.  fused: one batch = one launch of each kernel of the sequence.
+    key = f"stream_{a.scene}_{a.n}_{a.views}"
+    for s, ent in per_kernel.items():
+        if s.startswith("carve_kernel_1<false") and "hbm_bytes_per_launch" in ent:
+            traffic[key] = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": f"profiles/{a.tag}_pmc.json",
+                            "kernel": ent["kernel"], "read_correction": ent["read_correction"]}
+    seq = ("pack16_kernel", "brick_flags_kernel", "carve_brick_kernel<true>", "carve_kernel<true>",
+           "carve_list_kernel<false>", "carve_list_kernel<true>", "carve_resume_kernel<true>")
+    parts = {s: per_kernel[s]["hbm_bytes_per_launch"] for s in seq
+             if s in per_kernel and "hbm_bytes_per_launch" in per_kernel[s]}
+    if parts:
+        traffic[f"fused_{a.scene}_{a.n}_{a.views}"] = {
+            "hbm_bytes_per_launch": sum(parts.values()), "source": f"profiles/{a.tag}_pmc.json",
+            "kernel": "fused batch = one launch each of: " + ", ".join(parts), "per_kernel": parts,
+            "read_correction": 1.0}
     json.dump(traffic, open(traffic_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(per_kernel, indent=1))
 
