@@ -89,7 +89,8 @@ struct alignas(128) ListCounter {
 struct ListCtl {
     ListCounter count[3][kSub];  // entries appended per sub-list, one set per list stage
     uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
-    uint32_t pad[31];
+    uint32_t nlive;              // brick form: bricks no view found empty (entries of the live list)
+    uint32_t pad[30];
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
@@ -413,42 +414,58 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
     return o == 0;
 }
 
-// The emptiness verdict of every brick ahead of the dense kernel: flags[brick] = 1 when ANY view
-// of the batch finds the brick empty (carve is order-independent: one in-image zero pixel in any
-// view carves a voxel, backprojection.c:79, so the views tested here need not be the dense
-// stage's).  Blocks of blockIdx.y take kFlagViews views each, early exit on the first hit; the
-// flags are zeroed beforehand and only ever set, so the racing stores are benign.
-// (The first brick kernel had its wavefront 0 run the test on 32 column end points while the other
-// three waited behind a barrier: 61 % of its wave cycles.)
-constexpr int kFlagViews = 2;
+// The emptiness verdict of every brick ahead of the dense kernel: flags[brick] = 1 when ANY of the
+// first `nviews` views of the batch finds the brick empty (carve is order-independent: one
+// in-image zero pixel in any view carves a voxel, backprojection.c:79, so the views tested here
+// need not be the dense stage's).  The bricks no view found empty are appended to the LIVE list:
+// the dense kernel walks that list (a few per cent of the bricks on a plant), the -1 fill of the
+// others needs the flags only.
+// (History: a first brick kernel had its wavefront 0 run the test on 32 column end points while
+// the other three waited behind a barrier, 61 % of its wave cycles; a second one started one
+// block per strip of bricks and most of those found nothing to do, ~3 us each, 8 rounds deep.)
+// A block is 8 wavefronts over the same 64 bricks: wavefront w tests views w, w + 8, ... (a
+// wave-uniform view, so its descriptor stays in scalar registers), the verdicts meet in LDS.
+constexpr int kFlagWaves = 8;
 
-__global__ __launch_bounds__(kBlock) void brick_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
-                                                             int nviews, uint32_t bricks_y,
-                                                             uint32_t bricks_z, uint32_t nbricks,
-                                                             uint8_t *__restrict__ flags) {
-    const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
-    if (lb >= nbricks) return;
-    const uint32_t per_plane = bricks_y * bricks_z;
-    const uint32_t il = lb / per_plane;
-    const uint32_t rem = lb - il * per_plane;
-    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-    const int v0 = (int)blockIdx.y * kFlagViews;  // block-uniform: descriptors stay in scalar registers
-    const int v1 = min(v0 + kFlagViews, nviews);
-    for (int vi = v0; vi < v1; ++vi) {
-        const ViewDesc d = views[vi];
-        if (brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ))) {
-            flags[lb] = 1;
-            return;
+__global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
+    GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
+    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl) {
+    __shared__ unsigned long long s_mask[kFlagWaves];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t lb = blockIdx.x * 64u + lane;
+    bool culled = false;
+    if (lb < nbricks) {
+        const uint32_t per_plane = bricks_y * bricks_z;
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+        for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
+            const ViewDesc d = views[vi];
+            culled |= brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
         }
+    }
+    const unsigned long long mine = __ballot(culled);
+    if (lane == 0) s_mask[wave] = mine;
+    __syncthreads();
+    if (wave != 0) return;
+    unsigned long long any = 0;
+#pragma unroll
+    for (int w = 0; w < kFlagWaves; ++w) any |= s_mask[w];
+    const bool valid = lb < nbricks, dead = (any >> lane) & 1ull;
+    if (valid) flags[lb] = dead ? 1 : 0;
+    // the bricks left go on the live list, one atomic per block
+    const bool alive = valid && !dead;
+    const unsigned long long m = __ballot(alive);
+    if (m != 0) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->nlive, (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (alive) live[base + (uint32_t)__popcll(m & below)] = lb;
     }
 }
 
-// The dense kernel proper.  A block takes a STRIP: the bricks_z bricks of one plane and one
-// 16-column band, i.e. 16 whole columns.  It first stores -1 over every brick the flags kernel
-// found empty (nothing but 16-byte stores back to back -- with one brick per block the chain
-// kernel arguments -> flag -> store was paid per 4 KB and bounded the store rate), then
-// projects the voxels of the remaining bricks.
 template <bool FRESH>
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
@@ -476,32 +493,48 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
 
-    for (int vi = 0; vi < nviews; ++vi) {
-        if (__ballot(alive != 0) != 0) {  // this wavefront still has live voxels
-            const ViewDesc d = views[vi];
-            float ax = d.R[0] * x + d.R[1] * y;
-            float ay = d.R[3] * x + d.R[4] * y;
-            float az = d.R[6] * x + d.R[7] * y;
-            const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
-            bool ok[4];
-            uint32_t w[4];
-            int sh[4];
+    // two views per iteration: both projections first, then the eight gathers of a lane in one
+    // flight (the kernel waits on memory, not on arithmetic), then backprojection.c:79-83 for
+    // the first view and, for what it left alive, for the second
+    for (int vi = 0; vi < nviews; vi += 2) {
+        if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
+        const bool two = vi + 1 < nviews;      // wave-uniform
+        const ViewDesc da = views[vi];
+        const ViewDesc db = views[two ? vi + 1 : vi];
+        const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
+        const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
+        const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
+        const uint32_t *bitb = static_cast<const uint32_t *>(db.mask);
+        bool oka[4], okb[4];
+        uint32_t wa[4], wb[4];
+        int sha[4], shb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int u, v;
-                ok[e] = project(ax, ay, az, z[e], d, u, v) & ((alive >> e) & 1u);
-                sh[e] = u & 31;
-                w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u, v, d.tiles_x) : 0u);
+        for (int e = 0; e < 4; ++e) {
+            int u, v;
+            const bool live = (alive >> e) & 1u;
+            oka[e] = project(aax, aay, aaz, z[e], da, u, v) & live;
+            sha[e] = u & 31;
+            wa[e] = load_mask_word(bita, oka[e] ? mask_word_index(u, v, da.tiles_x) : 0u);
+            okb[e] = project(bax, bay, baz, z[e], db, u, v) & live & two;
+            shb[e] = u & 31;
+            wb[e] = load_mask_word(bitb, okb[e] ? mask_word_index(u, v, db.tiles_x) : 0u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (oka[e]) {
+                if (((wa[e] >> sha[e]) & 1u) == 0) {  // :79
+                    lab[e] = -1;
+                    alive &= ~(1u << e);
+                } else if (lab[e] == 0) {  // :81
+                    lab[e] = 1;
+                }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ok[e]) {
-                    if (((w[e] >> sh[e]) & 1u) == 0) {  // :79
-                        lab[e] = -1;
-                        alive &= ~(1u << e);
-                    } else if (lab[e] == 0) {  // :81
-                        lab[e] = 1;
-                    }
+            if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
+                if (((wb[e] >> shb[e]) & 1u) == 0) {
+                    lab[e] = -1;
+                    alive &= ~(1u << e);
+                } else if (lab[e] == 0) {
+                    lab[e] = 1;
                 }
             }
         }
@@ -558,35 +591,39 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
             *reinterpret_cast<int4 *>(col + bz * kBrickZ) = make_int4(-1, -1, -1, -1);
 }
 
-// Blocks [0, nstrips) project the voxels of the bricks of their strip that are not empty;
-// blocks [nstrips, nstrips + nstore) fill the empty bricks of strips [0, nstore) (the final list
-// stage fills the others, see carve_list_kernel).  The voxel blocks are dispatched first: the
-// ones with work stay (they wait on mask gathers and list atomics), the rest leave at once, and
-// the store blocks stream through the free slots -- arithmetic and HBM writes side by side.
-// (With both roles in one block the kernel took the sum of the two: 106 us = 48 + 58.)
+// The dense kernel proper: a persistent grid walks the live list, one brick per block and turn
+// (wavefront w owns columns 4w..4w+3 of the brick); runs of kXcdRun consecutive entries
+// (neighbouring bricks, which project onto the same mask lines) stay on one XCD.  Blocks behind
+// the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
+// stage fills the others, see carve_list_kernel).
 template <bool FRESH>
 __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
                                                              uint32_t bricks_y, uint32_t bricks_z,
                                                              const uint8_t *__restrict__ flags,
-                                                             uint32_t nstrips) {
-    if (blockIdx.x >= nstrips) {
-        store_culled_bricks(labels, g, flags, blockIdx.x - nstrips, bricks_y, bricks_z);
+                                                             const uint32_t *__restrict__ live,
+                                                             const ListCtl *ctl, uint32_t nwalkers) {
+    if (blockIdx.x >= nwalkers) {
+        store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z);
         return;
     }
-    const uint32_t strip = spread_block(blockIdx.x, nstrips);
-    const uint32_t il = strip / bricks_y;
-    const uint32_t by = strip - il * bricks_y;
+    const uint32_t nlive = ctl->nlive;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
-    const uint32_t lb0 = strip * bricks_z;
-    // bit bz: some view sees brick bz whole, in-image, over background (bricks_z <= 64)
-    const unsigned long long culled = __ballot(lane < bricks_z && flags[lb0 + min(lane, bricks_z - 1)] != 0);
-    for (uint32_t bz = 0; bz < bricks_z; ++bz)
-        if (!((culled >> bz) & 1ull))
-            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4,
-                                lb0 + bz, lane);
+    const uint32_t per_plane = bricks_y * bricks_z;
+    // block b of XCD (b & 7) takes entries  run * kXcdRun + i  of the runs dealt to that XCD
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3, per_xcd = nwalkers >> 3;
+    for (uint32_t t = seq; ; t += per_xcd) {
+        const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
+        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
+        if (entry >= nlive) continue;
+        const uint32_t lb = live[entry];
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+        brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4, lb, lane);
+    }
 }
 
 // One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
@@ -694,25 +731,35 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
             float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
             float y = g.oy + (float)(int)j * g.vs;
             float z = g.oz + (float)(int)k * g.vs;
-            for (int vi = v0; vi < v1; vi += 2) {
+            // U views per iteration: U independent projection chains and U gathers in flight per
+            // lane.  The final stage is bound by arithmetic (U = 2); the stages before it wait on
+            // memory and most of their voxels die within a few views (U = 4).
+            constexpr int U = FINAL ? 2 : 4;
+            for (int vi = v0; vi < v1; vi += U) {
                 if (__ballot(alive) == 0) break;
-                const bool two = vi + 1 < v1;  // wave-uniform
-                const ViewDesc da = views[vi];
-                const ViewDesc db = views[two ? vi + 1 : vi];
-                int ua, va, ub, vb;
-                bool oka = project(da.R[0] * x + da.R[1] * y, da.R[3] * x + da.R[4] * y,
-                                   da.R[6] * x + da.R[7] * y, z, da, ua, va) & alive;
-                bool okb = project(db.R[0] * x + db.R[1] * y, db.R[3] * x + db.R[4] * y,
-                                   db.R[6] * x + db.R[7] * y, z, db, ub, vb) & alive & two;
-                uint32_t wa = 0, wb = 0;
-                if (oka) wa = load_mask_word(da.mask, mask_word_index(ua, va, da.tiles_x));
-                if (okb) wb = load_mask_word(db.mask, mask_word_index(ub, vb, db.tiles_x));
-                bool fga = ((wa >> (ua & 31)) & 1u) != 0, fgb = ((wb >> (ub & 31)) & 1u) != 0;
-                // two applications of backprojection.c:79-83; a zero pixel in either view wins
-                if ((oka & !fga) | (okb & !fgb)) {
+                bool ok[U], fg[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const bool have = vi + q < v1;  // wave-uniform
+                    const ViewDesc d = views[have ? vi + q : vi];
+                    int uu, vv;
+                    ok[q] = project(d.R[0] * x + d.R[1] * y, d.R[3] * x + d.R[4] * y,
+                                    d.R[6] * x + d.R[7] * y, z, d, uu, vv) & alive & have;
+                    uint32_t w = 0;
+                    if (ok[q]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
+                    fg[q] = ((w >> (uu & 31)) & 1u) != 0;
+                }
+                // U applications of backprojection.c:79-83; a zero pixel in any of the views wins
+                bool carve = false, keep = false;
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    carve |= ok[q] & !fg[q];
+                    keep |= ok[q] & fg[q];
+                }
+                if (carve) {
                     alive = false;
                     labels[idx] = -1;
-                } else if (zero & ((oka & fga) | (okb & fgb))) {
+                } else if (zero & keep) {
                     zero = false;
                     if (FINAL) atomicCAS(&labels[idx], 0, 1); else flipped = true;
                 }
@@ -1090,6 +1137,7 @@ struct sc_engine {
     std::vector<Chunk> chunks;
 
     uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick (inside ctl's allocation)
+    uint32_t *live = nullptr;  // ... and the bricks no view found empty (count in ctl->nlive)
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
@@ -1463,16 +1511,19 @@ int ensure_lists(sc_engine *e) {
     return SC_OK;
 }
 
-// List counters and brick verdicts share one allocation: one memset clears both per fused launch.
+// List counters, brick verdicts and the live-brick list share one allocation; one memset of the
+// counters per fused launch.
 int ensure_ctl(sc_engine *e) {
     if (e->ctl) return SC_OK;
     size_t nbricks = 0;
     if ((e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0)
         nbricks = (size_t)e->planes * (size_t)(e->ny / kBrickY) * (size_t)(e->nz / kBrickZ);
     char *base = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), sizeof(ListCtl) + nbricks + 16));
+    size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), sizeof(ListCtl) + flag_bytes + nbricks * sizeof(uint32_t) + 16));
     e->ctl = reinterpret_cast<ListCtl *>(base);
     e->flags = reinterpret_cast<uint8_t *>(base + sizeof(ListCtl));
+    e->live = reinterpret_cast<uint32_t *>(base + sizeof(ListCtl) + flag_bytes);
     return SC_OK;
 }
 
@@ -1542,9 +1593,8 @@ int flush(sc_engine *e, size_t count = 0) {
         if (compact || brick) {
             rc = ensure_ctl(e);
             if (rc) return rc;
-            // counters (when lists are used) and brick verdicts (when bricks are) in one fill
-            size_t lo = compact ? 0 : sizeof(ListCtl), hi = sizeof(ListCtl) + nbricks;
-            if (hi > lo) HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(e->ctl) + lo, 0, hi - lo, e->stream));
+            // list counters, overflow flag, live-brick count (the flags kernel writes every verdict)
+            HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
         }
         if (compact) {
             rc = ensure_lists(e);
@@ -1573,27 +1623,26 @@ int flush(sc_engine *e, size_t count = 0) {
 #undef LAUNCH_CARVE1
         } else {
             if (brick) {
-                dim3 bgrid(nstrips + dense_store_strips);  // voxel blocks, then store blocks
+                const uint32_t nwalkers = ((uint32_t)e->list_blocks + 7u) & ~7u;  // whole groups of 8 XCDs
+                dim3 bgrid(nwalkers + dense_store_strips);  // live-list walkers, then store blocks
                 // every view of the batch may veto a brick, not only the dense stage's
                 int flag_views = (int)nv;
                 if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
-                hipLaunchKernelGGL(brick_flags_kernel,
-                                   dim3((nbricks + kBlock - 1) / kBlock,
-                                        (uint32_t)((flag_views + kFlagViews - 1) / kFlagViews)),
-                                   block, 0, e->stream, g, vd, flag_views, bys, bzs, nbricks, e->flags);
+                hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
+                                   e->stream, g, vd, flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl);
                 rc = ltf.end();
                 if (rc) return rc;
                 rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
                 if (rc) return rc;
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, nstrips);
+                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, nstrips);
+                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
