@@ -219,6 +219,10 @@ def main():
     bsteps = max(2, min(a.steps, 5))
     dtb, breakdown = timed(eng, nat, torch, dist, call, bsteps, vpl[a.path], world, time_kernels=1)
     breakdown["ms_per_step_with_all_events"] = dtb / bsteps * 1e3
+    if a.path == "fused":
+        live, s0, s1n, ovf = eng.fused_counts()
+        breakdown["fused_counts"] = {"live_bricks": live, "alive_after_dense_stage": s0,
+                                     "alive_after_first_list_stage": s1n, "list_overflow": ovf}
     res_other = None
     if not a.skip_other_path:
         osteps = max(2, a.steps // 4) if other == "stream" else a.steps

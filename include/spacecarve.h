@@ -194,6 +194,11 @@ int64_t sc_num_voxels(const sc_engine *e);
 int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *total_ms);
 int sc_reset_kernel_stats(sc_engine *e);
 
+/* Diagnostics of the last fused carve launch (waits for the stream): out[0] bricks no view found
+ * empty (brick form, else 0), out[1] voxels alive after the dense stage, out[2] after the first
+ * survivor stage, out[3] 1 if a survivor list overflowed (the dense resume kernel took over). */
+int sc_fused_counts(sc_engine *e, int64_t out[4]);
+
 /* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on
  * `count` pseudo-random operand triples (mode 0: raw bit patterns, 1: projection-like
  * magnitudes) and reports how many quotients differ bit-for-bit (must be 0) and how many

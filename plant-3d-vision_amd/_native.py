@@ -54,6 +54,7 @@ _SIGNATURES = {
     "sc_num_voxels": ("q", ["p"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
+    "sc_fused_counts": ("i", ["p", "p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
     "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_vol2pcd_last_error": ("s", []),
@@ -343,6 +344,13 @@ class Engine:
 
     def reset_kernel_stats(self):
         self._call("sc_reset_kernel_stats")
+
+    def fused_counts(self):
+        """(live bricks, voxels alive after the dense stage, after the first list stage, overflow)
+        of the last fused carve launch."""
+        out = np.zeros(4, dtype=np.int64)
+        self._call("sc_fused_counts", addr(out))
+        return tuple(int(x) for x in out)
 
     def selftest_division(self, count, seed=1, mode=1):
         """(mismatches, fast_pairs) of the shared-reciprocal division vs hipcc's IEEE division."""

@@ -2149,6 +2149,24 @@ int sc_reset_kernel_stats(sc_engine *e) {
     return SC_OK;
 }
 
+int sc_fused_counts(sc_engine *e, int64_t out[4]) {
+    if (!e || !out) return fail(SC_ERR_INVALID, "bad argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->ctl) return SC_OK;  // no fused carve launched yet
+    std::vector<ListCtl> host(1);
+    HIP_TRY(hipMemcpy(host.data(), e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
+    out[0] = host[0].nlive;
+    for (int s = 0; s < kSub; ++s) {
+        out[1] += host[0].count[0][s].n;
+        out[2] += host[0].count[1][s].n;
+    }
+    out[3] = host[0].overflow;
+    return SC_OK;
+}
+
 int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                          uint64_t *mismatches, uint64_t *fast_pairs) {
     if (!e || !mismatches || !fast_pairs || count < 0) return fail(SC_ERR_INVALID, "bad argument");

@@ -146,6 +146,53 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
         bp.close()
 
 
+@pytest.mark.parametrize("opts", [
+    {},                                                                   # defaults
+    {"SC_OPT_FLAG_VIEWS": 0},                                             # every view may veto a brick
+    {"SC_OPT_FLAG_VIEWS": 1, "SC_OPT_DENSE_VIEWS": 1},
+    {"SC_OPT_FLAG_VIEWS": 11, "SC_OPT_DENSE_VIEWS": 3, "SC_OPT_STAGE1_VIEWS": 3},
+    {"SC_OPT_DEFER_STORES": 0},                                           # dense stage fills empty bricks
+    {"SC_OPT_DEFER_SHARE": 0},
+    {"SC_OPT_DEFER_SHARE": 7, "SC_OPT_DEFER_STORES": 24},                 # fill split between the two
+    {"SC_OPT_LIST_BLOCKS": 8, "SC_OPT_DEFER_STORES": 8},                  # tiny persistent grids
+    {"SC_OPT_STAGE1_VIEWS": 64},                                          # single (final) list stage
+    {"SC_OPT_STAGE1_VIEWS": 2, "SC_OPT_STAGE2_VIEWS": 3, "SC_OPT_VIEW_GROUP": 2},
+    {"SC_OPT_VIEW_GROUP": 5, "SC_OPT_PACK_ROWS": 1},
+    {"SC_OPT_COMPACT": 0},                                                # bricks without survivor lists
+    {"SC_OPT_VIEW_ORDER": 0},
+])
+@pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192))])
+def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape):
+    """The fused carve is a pipeline (bit packing, brick verdicts + live list, dense stage on live
+    bricks, survivor stages, -1 fill of empty bricks riding with the final stage).  Every knob
+    that moves work between its kernels must leave the volume bit-identical to the oracle, on
+    a fresh volume and on a second batch over the stored one, through host and device masks."""
+    sh, origin, vs, views = scene(shape, 12, kind)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+    for k, v in opts.items():
+        e.set_option(getattr(nat, k), v)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    V, H, W = stack.shape
+    e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), want), ("device masks, fresh", opts, histogram3(want))
+    live, s0, s1, overflow = e.fused_counts()
+    nbricks = sh[0] * (sh[1] // 16) * (sh[2] // 64)
+    assert 0 <= live <= nbricks
+    assert overflow or s1 <= s0
+    e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), want), ("device masks, stored state", opts)
+    e.clear()
+    for Kq, Rq, tq, m in views:
+        e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), want), ("host masks", opts)
+    e.dev_free(ptr)
+    e.close()
+
+
 def test_fused_compaction_with_slab_and_default_values(gpu_device):
     shape, origin, vs, views = scene((40, 28, 36), 14, "plant")
     for dv in (0, 3):
