@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
 # x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
-# nz by 64, so the dense stage runs in its brick form (include/spacecarve.h, SC_OPT_BRICK):
+# nz by 64 (whole bricks of the dense stage, include/spacecarve.h SC_OPT_BRICK; not required):
 GRIDS_512 = {1: (512, 512, 512), 2: (640, 640, 640), 4: (808, 800, 832), 8: (1024, 1024, 1024)}
 
 

@@ -78,7 +78,7 @@ extern "C" {
 #define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
 #define SC_OPT_LIST_BLOCKS 8      /* persistent grid of the list / resume kernels (2048)      */
 #define SC_OPT_VIEW_GROUP 9       /* views per work item in the final survivor stage (16)     */
-#define SC_OPT_BRICK 10           /* 1 (default): when ny % 16 == 0 and nz % 64 == 0 the dense stage
+#define SC_OPT_BRICK 10           /* 1 (default): for grids with nz <= 4096 and < 2^31 voxels the dense stage
                                      works on 16x64-voxel bricks with a conservative emptiness
                                      test per brick; 0: linear blocks only                       */
 #define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */

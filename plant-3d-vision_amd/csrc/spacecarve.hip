@@ -351,8 +351,8 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
 }
 
 // ---- brick form of the dense stage -------------------------------------------------------
-// When ny % 16 == 0 and nz % 64 == 0 a block takes a BRICK of 16 columns (along y) x 64 voxels
-// (along z) instead of 1024 consecutive voxels: wavefront w owns columns 4w..4w+3, lane l the
+// A block takes a BRICK of 16 columns (along y) x 64 voxels (along z) instead of 1024 consecutive
+// voxels (bricks at the far y / z faces may stick out of the grid; any ny, nz with nz <= 4096): wavefront w owns columns 4w..4w+3, lane l the
 // 4-voxel group (l & 15) of column (l >> 4).  A brick projects onto a small image patch, which
 // makes a conservative emptiness test worthwhile (brick_flags_kernel, ahead of the dense
 // kernel): project the brick's four corners, widen their bounding box by a rigorous bound on
@@ -471,15 +471,30 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
                                              uint32_t k0, uint32_t lb, uint32_t lane) {
+    // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
+    // nothing (they still take part in the wave-wide ballots), a group at the end of a column
+    // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const bool vec = (g.nz & 3u) == 0;  // grid-uniform
     const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nz + k0;
     int32_t *p = labels + elem;
     int32_t lab[4], was[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lab[e] = -1;  // what a lane does not own counts as carved
     if (FRESH) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lab[e] = init;
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = init;
+    } else if (vec) {
+        if (inside) {
+            int4 q = *reinterpret_cast<const int4 *>(p);
+            lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+        }
     } else {
-        int4 q = *reinterpret_cast<const int4 *>(p);
-        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = p[e];
     }
     uint32_t alive = 0;
 #pragma unroll
@@ -540,8 +555,14 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         }
     }
 
-    bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
-    if (changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    if (vec) {
+        bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
+    }
 
     if (ap.list != nullptr) {
         ap.sub = (lb * 0x9E3779B1u) >> 24;
@@ -585,10 +606,20 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
     const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
     const unsigned long long culled =
         __ballot(lane < bricks_z && flags[strip * bricks_z + min(lane, bricks_z - 1)] != 0);
-    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz + (lane & 15) * 4;
-    for (uint32_t bz = 0; bz < bricks_z; ++bz)
-        if ((culled >> bz) & 1ull)
-            *reinterpret_cast<int4 *>(col + bz * kBrickZ) = make_int4(-1, -1, -1, -1);
+    if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
+    const bool vec = (g.nz & 3u) == 0;
+    for (uint32_t bz = 0; bz < bricks_z; ++bz) {
+        if (!((culled >> bz) & 1ull)) continue;
+        const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+        if (k0 >= g.nz) continue;
+        if (vec) {
+            *reinterpret_cast<int4 *>(col + k0) = make_int4(-1, -1, -1, -1);
+        } else {
+            const uint32_t n = min(4u, g.nz - k0);
+            for (uint32_t e = 0; e < n; ++e) col[k0 + e] = -1;
+        }
+    }
 }
 
 // The dense kernel proper: a persistent grid walks the live list, one brick per block and turn
@@ -1516,8 +1547,8 @@ int ensure_lists(sc_engine *e) {
 int ensure_ctl(sc_engine *e) {
     if (e->ctl) return SC_OK;
     size_t nbricks = 0;
-    if ((e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0)
-        nbricks = (size_t)e->planes * (size_t)(e->ny / kBrickY) * (size_t)(e->nz / kBrickZ);
+    if ((e->nz + kBrickZ - 1) / kBrickZ <= 64)
+        nbricks = (size_t)e->planes * (size_t)((e->ny + kBrickY - 1) / kBrickY) * (size_t)((e->nz + kBrickZ - 1) / kBrickZ);
     char *base = nullptr;
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), sizeof(ListCtl) + flag_bytes + nbricks * sizeof(uint32_t) + 16));
@@ -1578,9 +1609,9 @@ int flush(sc_engine *e, size_t count = 0) {
                        (uint64_t)e->n < 0x80000000ull;
         Append ap{nullptr, nullptr, 0u, 0u};
         int dense_views = (int)nv;
-        bool brick = nv > 1 && e->brick && (e->ny % kBrickY) == 0 && (e->nz % kBrickZ) == 0 &&
-                     e->nz / kBrickZ <= 64 && (uint64_t)e->n < 0x80000000ull && one.occ != nullptr;
-        const uint32_t bys = (uint32_t)(e->ny / kBrickY), bzs = (uint32_t)(e->nz / kBrickZ);
+        const uint32_t bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
+        bool brick = nv > 1 && e->brick && bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
+                     (uint64_t)e->planes * bys * bzs < 0x80000000ull && one.occ != nullptr;
         const uint32_t nbricks = brick ? (uint32_t)((uint64_t)e->planes * bys * bzs) : 0u;
         // the -1 fill of empty bricks rides along with the final list stage when there is one
         const uint32_t nstrips = brick ? (uint32_t)((uint64_t)e->planes * bys) : 0u;
