@@ -235,6 +235,15 @@ int sc_label_points(const double *points, int64_t P, int L, int V, const double 
                     double *scores_out, int32_t *labels_out);
 const char *sc_label_points_last_error(void);
 
+/* Page-locked host memory for the read-back of sc_get_values (no reference counterpart: the
+ * reference's values_h is a pageable NumPy array, cl.py:173).  A 512 MiB volume reads back in
+ * ~10 ms into such a buffer against ~50 ms into pageable memory, but allocating it takes ~0.1 s
+ * during which other threads' HIP calls stall (measured: doing it on a thread beside the mask
+ * ingest made a one-shot run slower), so it only pays for callers that keep the buffer across
+ * many read-backs.  sc_host_free needs no engine: the buffer may outlive it. */
+int sc_host_alloc(int device, int64_t bytes, void **ptr);
+void sc_host_free(void *ptr);
+
 /* Device-memory helpers so that hosts without a HIP binding can stage inputs in HBM
  * (bench.py, tests): plain hipMalloc / hipMemcpy / hipFree on the engine's device. */
 int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr);

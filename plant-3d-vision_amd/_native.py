@@ -61,6 +61,8 @@ _SIGNATURES = {
     "sc_free_host": ("v", ["p"]),
     "sc_label_points": ("i", ["p", "q", "i", "i", "p", "p", "p", "p", "i", "i", "i", "i", "p", "p"]),
     "sc_label_points_last_error": ("s", []),
+    "sc_host_alloc": ("i", ["i", "q", "p"]),
+    "sc_host_free": ("v", ["p"]),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
     "sc_dev_free": ("i", ["p", "p"]),
     "sc_dev_upload": ("i", ["p", "p", "p", "q"]),
@@ -202,6 +204,24 @@ def addr(a):
     """Address of a C-contiguous ndarray's data."""
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data
+
+
+def pinned_empty(shape, dtype, device=0):
+    """``np.empty(shape, dtype)`` in page-locked host memory (``sc_host_alloc``): device-to-host
+    copies into it run at the link's rate.  The memory is released when the last view of the
+    array is collected.  Takes ~0.1 s for 512 MiB: call it off the critical path."""
+    import weakref
+    b = backend()
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    if nbytes <= 0:
+        return np.empty(shape, dtype)
+    out = np.zeros(1, dtype=np.uintp)
+    check(b.call("sc_host_alloc", int(device), nbytes, addr(out)), "sc_host_alloc")
+    ptr = int(out[0])
+    owner = (ctypes.c_ubyte * nbytes).from_address(ptr)
+    weakref.finalize(owner, b.call, "sc_host_free", ptr)
+    return np.frombuffer(owner, dtype=dtype).reshape(shape)
 
 
 def device_count():

@@ -126,7 +126,9 @@ class Backprojection(object):
         # strictly serial read -> process loop, cl.py:282-303); results do not depend on it
         self.decode_workers = (min(8, os.cpu_count() or 1) if decode_workers is None
                                else max(1, int(decode_workers)))
-        self.values_h = None
+        self._values_h = None
+        self._spare = None
+        self._prefault = None
         self.values_d = None
         self.intrinsics_d = None
         self.rot_d = None
@@ -147,8 +149,9 @@ class Backprojection(object):
         self._lut = None
         if self.views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(self.views_per_launch))
-        self.values_h = np.ascontiguousarray(
-            self.default_value * np.ones(self.shape, dtype=self.dtype), dtype=self.dtype)
+        self._values_h = None  # cl.py:173 builds default * ones here; see the values_h property
+        self._spare = None
+        self._start_prefault()
         self.volinfo_d = np.array([*self.origin, self.voxel_size], dtype=np.float32)  # cl.py:182
         self.shape_d = np.array(self.shape, dtype=np.int32)  # cl.py:186
         return
@@ -216,15 +219,65 @@ class Backprojection(object):
         """Flush and wait: the reference's ``queue.finish()`` (cl.py:226)."""
         self._engine.synchronize()
 
+    # -- host copy of the volume ---------------------------------------------------------------
+    # The reference keeps ``values_h = default_value * ones(shape)`` from construction / clear()
+    # on (cl.py:173,309) and copies the device buffer into it in get_values.  Building that array
+    # costs 0.1-0.5 s of host time at 512^3, at construction and again at every clear(); but a
+    # FRESH array is no better: its first-touch page faults make the 512 MiB read-back take 50 ms
+    # instead of 10 (measured; page-locking does not beat already-touched pageable memory here,
+    # tools/bench_host_masks.py).  So: the destination of the next read-back is allocated and
+    # touched on a host thread while the device works (no HIP calls on that thread), the default-
+    # valued contents are only written if somebody reads ``values_h`` before a read-back, and
+    # clear() hands out a new buffer unless nobody else holds the old one (arrays returned by
+    # get_values keep their contents across clear(), as in the reference).
+    @property
+    def values_h(self):
+        if self._values_h is None:
+            buf = self._take_buffer()
+            buf[...] = self.default_value
+            self._values_h = buf
+        return self._values_h
+
+    @values_h.setter
+    def values_h(self, value):
+        self._values_h = value
+
+    def _start_prefault(self):
+        import threading
+        box = {}
+        shape, dtype = tuple(int(s) for s in self.shape), self.dtype
+
+        def work():
+            arr = np.empty(shape, dtype=dtype)
+            flat = arr.reshape(-1)
+            flat[:: max(1, 4096 // arr.itemsize)] = 0  # one write per page
+            box["array"] = arr
+
+        th = threading.Thread(target=work, name="spacecarve-prefault", daemon=True)
+        th.start()
+        self._prefault = (th, box)
+
+    def _take_buffer(self):
+        """An array of the volume's shape whose pages are (normally) already touched."""
+        shape = tuple(int(s) for s in self.shape)
+        buf, self._spare = self._spare, None
+        if buf is None and self._prefault is not None:
+            th, box = self._prefault
+            self._prefault = None
+            th.join()
+            buf = box.get("array")
+        if buf is None or buf.dtype != self.dtype or buf.shape != shape:
+            buf = np.empty(shape, dtype=self.dtype)
+        return buf
+
     def get_values(self):
         """Gets computed values from the device (cl.py:229-232); the returned array
         aliases ``values_h`` like the reference's."""
-        if self.values_h is None or self.values_h.dtype != self.dtype:
-            self.values_h = np.empty(self.shape, dtype=self.dtype)
-        flat = self.values_h.reshape(tuple(int(s) for s in self.shape))
-        self._engine.get_values(flat)
+        if self._values_h is None:
+            self._values_h = self._take_buffer()
+        self._engine.get_values(self._values_h)
         self.values_d = self._engine.values_device_ptr()
-        return self.values_h.reshape(self.shape)
+        return self._values_h.reshape(self.shape)
 
     def process_fileset(self, fs, camera_metadata, invert=False):
         """Processes a whole fileset (cl.py:234-257): one volume, or with ``labels`` a
@@ -289,8 +342,15 @@ class Backprojection(object):
 
     def clear(self):
         """Clear computed values (cl.py:307-311)."""
-        self.values_h = np.ascontiguousarray(
-            self.default_value * np.ones(self.shape).astype(self.dtype), dtype=self.dtype)
+        # values_h becomes a fresh default-valued array (cl.py:309), built when read.  The old
+        # buffer is recycled only when nobody else holds it or a view of it.
+        import sys
+        old, self._values_h = self._values_h, None
+        if old is not None and old.base is None and sys.getrefcount(old) == 2:
+            self._spare = old
+        elif self._spare is None and self._prefault is None:
+            self._start_prefault()
+        del old
         self._engine.clear()
         return
 

@@ -2218,6 +2218,18 @@ int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
     return SC_OK;
 }
 
+int sc_host_alloc(int device, int64_t bytes, void **ptr) {
+    if (!ptr || bytes <= 0) return fail(SC_ERR_INVALID, "bad argument");
+    *ptr = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return SC_OK;
+}
+
+void sc_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 int sc_dev_alloc(sc_engine *e, int64_t bytes, void **ptr) {
     if (!e || !ptr || bytes <= 0) return fail(SC_ERR_INVALID, "bad argument");
     int rc = use_device(e);

@@ -336,6 +336,47 @@ def test_clear_and_reuse(gpu_device):
     assert np.array_equal(bp.get_values(), first)
 
 
+def test_arrays_returned_by_get_values_survive_clear(gpu_device):
+    """cl.py:229-232,307-311: get_values fills and returns values_h (repeated calls alias it),
+    clear() rebinds values_h to a new default-valued array, so an array handed out before a
+    clear keeps its contents."""
+    shape, origin, vs, views = scene(40, 6, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    bp = Backprojection(shape, origin, vs, default_value=3)
+    assert (bp.values_h == 3).all() and bp.values_h.shape == tuple(shape)  # default * ones, cl.py:173
+    bp.close()
+    bp = Backprojection(shape, origin, vs)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    held = bp.get_values()
+    assert np.array_equal(held, want)
+    assert np.shares_memory(held, bp.get_values())   # same values_h, like the reference
+    bp.clear()
+    assert (bp.values_h == 0).all()
+    inv = [(K, R, t, np.invert(m)) for K, R, t, m in views]
+    for K, R, t, m in inv:
+        bp.process_view(K, R, t, m)
+    other = bp.get_values()
+    assert not np.shares_memory(held, other)
+    assert np.array_equal(held, want)                # untouched by the second read-back
+    assert np.array_equal(other, oracle_c.carve(shape, origin, vs, inv))
+    bp.close()
+
+
+def test_read_back_into_page_locked_memory(gpu_device):
+    """sc_host_alloc / pinned_empty: an opt-in destination for Engine.get_values."""
+    shape, origin, vs, views = scene(40, 6, "plant")
+    want = oracle_c.carve(shape, origin, vs, views)
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    out = nat.pinned_empty(shape, np.int32)
+    for K, R, t, m in views:
+        e.process_view(K, R, t, m, nat.SC_MASK_U8)
+    assert e.get_values(out) is out and np.array_equal(out, want)
+    e.close()
+    assert np.array_equal(out, want)  # the buffer outlives the engine
+    del out
+
+
 @pytest.mark.parametrize("vpl", [0, 1, 2])
 def test_average_matches_oracle_bitwise(gpu_device, vpl):
     shape, origin, vs, views = scene((20, 17, 22), 6, "noise", width=160, height=120, fx=130.0,
