@@ -83,8 +83,9 @@ class SpaceCarveError(RuntimeError):
 
 def build(force=False):
     """Compile ``csrc/spacecarve.hip`` for gfx950 into ``libspacecarve.so`` (in-tree)."""
-    src = os.path.join(_PKG_DIR, "csrc", "spacecarve.hip")
-    deps = [src, HEADER_PATH, os.path.join(_PKG_DIR, "csrc", "Makefile")]
+    csrc = os.path.join(_PKG_DIR, "csrc")
+    deps = [os.path.join(csrc, f) for f in ("spacecarve.hip", "vol2pcd.hip", "label_points.hip", "Makefile")]
+    deps.append(HEADER_PATH)
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH

@@ -773,6 +773,10 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
                 for (int q = 0; q < U; ++q) {
                     const bool have = vi + q < v1;  // wave-uniform
                     const ViewDesc d = views[have ? vi + q : vi];
+                    // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
+                    // tiles_x and the mask pointer one by one where they are first used, three
+                    // more scalar-load round trips inside each projection
+                    asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
                     int uu, vv;
                     ok[q] = project(d.R[0] * x + d.R[1] * y, d.R[3] * x + d.R[4] * y,
                                     d.R[6] * x + d.R[7] * y, z, d, uu, vv) & alive & have;
