@@ -427,10 +427,19 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
 // wave-uniform view, so its descriptor stays in scalar registers), the verdicts meet in LDS.
 constexpr int kFlagWaves = 8;
 
+// Its own descriptors may travel in the kernel arguments (`own`, when `views` is null); block 0
+// then also copies the batch's descriptors from the host's page-locked staging buffer to the
+// device array the later kernels read -- no separate host-to-device copy on the stream.
+struct FlagViews { ViewDesc v[kFlagWaves]; };
+struct DescCopy { const uint32_t *src; uint32_t *dst; uint32_t words; };
+
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
-    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl) {
+    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
+    FlagViews own, DescCopy dc) {
     __shared__ unsigned long long s_mask[kFlagWaves];
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t lb = blockIdx.x * 64u + lane;
     bool culled = false;
@@ -440,9 +449,13 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
         const uint32_t rem = lb - il * per_plane;
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
         const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-        for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
-            const ViewDesc d = views[vi];
-            culled |= brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+        if (views == nullptr) {  // grid-uniform: nviews <= kFlagWaves, one view per wavefront
+            if ((int)wave < nviews) culled = brick_is_carved(own.v[wave], g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+        } else {
+            for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
+                const ViewDesc d = views[vi];
+                culled |= brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+            }
         }
     }
     const unsigned long long mine = __ballot(culled);
@@ -826,7 +839,14 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                               const ViewDesc *__restrict__ views,
-                                                              int nviews, const ListCtl *ctl) {
+                                                              int nviews, const ListCtl *ctl,
+                                                              ListCtl *next) {
+    // last kernel of a batch: leave the counters of the NEXT batch zeroed (the two blocks
+    // alternate; nobody else touches that one now), so no memset sits on the stream
+    if (next != nullptr) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(next);
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < sizeof(ListCtl) / 4; i += gridDim.x * kBlock) z[i] = 0u;
+    }
     if (!ctl->overflow) return;
     Append none{nullptr, nullptr, 0u, 0u};
     uint64_t nblk = (g.ngroups + kBlock - 1) / kBlock;
@@ -1173,6 +1193,9 @@ struct sc_engine {
 
     uint8_t *flags = nullptr;  // fused carve, brick form: one emptiness verdict per brick (inside ctl's allocation)
     uint32_t *live = nullptr;  // ... and the bricks no view found empty (count in ctl->nlive)
+    ListCtl *ctl2[2] = {nullptr, nullptr};  // counter blocks of alternate batches (ctl points at the current one)
+    bool ctl_clean[2] = {false, false};     // known to be all zero
+    int ctl_idx = 0;
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
@@ -1555,10 +1578,15 @@ int ensure_ctl(sc_engine *e) {
         nbricks = (size_t)e->planes * (size_t)((e->ny + kBrickY - 1) / kBrickY) * (size_t)((e->nz + kBrickZ - 1) / kBrickZ);
     char *base = nullptr;
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), sizeof(ListCtl) + flag_bytes + nbricks * sizeof(uint32_t) + 16));
-    e->ctl = reinterpret_cast<ListCtl *>(base);
-    e->flags = reinterpret_cast<uint8_t *>(base + sizeof(ListCtl));
-    e->live = reinterpret_cast<uint32_t *>(base + sizeof(ListCtl) + flag_bytes);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + nbricks * sizeof(uint32_t) + 16));
+    HIP_TRY(hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream));
+    e->ctl2[0] = reinterpret_cast<ListCtl *>(base);
+    e->ctl2[1] = e->ctl2[0] + 1;
+    e->ctl_clean[0] = e->ctl_clean[1] = true;
+    e->ctl_idx = 0;
+    e->ctl = e->ctl2[0];
+    e->flags = reinterpret_cast<uint8_t *>(base + 2 * sizeof(ListCtl));
+    e->live = reinterpret_cast<uint32_t *>(base + 2 * sizeof(ListCtl) + flag_bytes);
     return SC_OK;
 }
 
@@ -1571,7 +1599,7 @@ int flush(sc_engine *e, size_t count = 0) {
     if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
     bool vec = (e->nz % 4) == 0;
     dim3 grid((uint32_t)blocks), block(kBlock);
-    const ViewDesc *vd = nullptr;
+    const ViewDesc *vd = nullptr, *vpin = nullptr;
     if (nv > 1) {
         int rcs = step_begin(e);
         if (rcs) return rcs;
@@ -1597,12 +1625,21 @@ int flush(sc_engine *e, size_t count = 0) {
         }
         ViewDesc *pin = e->views_pin + e->views_head, *dev = e->views_dev + e->views_head;
         memcpy(pin, e->pending.data(), nv * sizeof(ViewDesc));
-        HIP_TRY(hipMemcpyAsync(dev, pin, nv * sizeof(ViewDesc), hipMemcpyHostToDevice, e->stream));
         e->views_head += nv;
         vd = dev;
+        vpin = pin;
     }
     const ViewDesc &one = e->pending[0];
     int rc;
+    // the descriptors reach the device array either by a copy on the stream, or -- brick form of
+    // the fused carve -- through the flags kernel, which gets its own in its arguments
+    bool desc_uploaded = false;
+    auto upload_desc = [&]() -> int {
+        if (desc_uploaded || vd == nullptr) return SC_OK;
+        desc_uploaded = true;
+        HIP_TRY(hipMemcpyAsync(const_cast<ViewDesc *>(vd), vpin, nv * sizeof(ViewDesc), hipMemcpyHostToDevice, e->stream));
+        return SC_OK;
+    };
     if (e->mode == SC_MODE_CARVE) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
@@ -1617,6 +1654,13 @@ int flush(sc_engine *e, size_t count = 0) {
         bool brick = nv > 1 && e->brick && bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
                      (uint64_t)e->planes * bys * bzs < 0x80000000ull && one.occ != nullptr;
         const uint32_t nbricks = brick ? (uint32_t)((uint64_t)e->planes * bys * bzs) : 0u;
+        int flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
+        if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
+        const bool desc_by_flags = brick && flag_views <= kFlagWaves;
+        if (!desc_by_flags) {
+            rc = upload_desc();
+            if (rc) return rc;
+        }
         // the -1 fill of empty bricks rides along with the final list stage when there is one
         const uint32_t nstrips = brick ? (uint32_t)((uint64_t)e->planes * bys) : 0u;
         // strips [0, dense_store_strips) are filled by the dense kernel's store blocks, the others
@@ -1628,8 +1672,12 @@ int flush(sc_engine *e, size_t count = 0) {
         if (compact || brick) {
             rc = ensure_ctl(e);
             if (rc) return rc;
-            // list counters, overflow flag, live-brick count (the flags kernel writes every verdict)
-            HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
+            // list counters, overflow flag, live-brick count: this batch takes the block the previous
+            // batch's final stage left zeroed (a memset only if there was no such stage)
+            e->ctl_idx ^= 1;
+            e->ctl = e->ctl2[e->ctl_idx];
+            if (!e->ctl_clean[e->ctl_idx]) HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
+            e->ctl_clean[e->ctl_idx] = false;
         }
         if (compact) {
             rc = ensure_lists(e);
@@ -1660,14 +1708,21 @@ int flush(sc_engine *e, size_t count = 0) {
             if (brick) {
                 const uint32_t nwalkers = ((uint32_t)e->list_blocks + 7u) & ~7u;  // whole groups of 8 XCDs
                 dim3 bgrid(nwalkers + dense_store_strips);  // live-list walkers, then store blocks
-                // every view of the batch may veto a brick, not only the dense stage's
-                int flag_views = (int)nv;
-                if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
+                FlagViews own{};
+                DescCopy dc{nullptr, nullptr, 0u};
+                if (desc_by_flags) {
+                    for (int q = 0; q < flag_views; ++q) own.v[q] = e->pending[(size_t)q];
+                    dc = DescCopy{reinterpret_cast<const uint32_t *>(vpin),
+                                  reinterpret_cast<uint32_t *>(const_cast<ViewDesc *>(vd)),
+                                  (uint32_t)(nv * sizeof(ViewDesc) / 4)};
+                    desc_uploaded = true;
+                }
                 hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
-                                   e->stream, g, vd, flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl);
+                                   e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
+                                   flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc);
                 rc = ltf.end();
                 if (rc) return rc;
                 rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
@@ -1727,18 +1782,22 @@ int flush(sc_engine *e, size_t count = 0) {
                                        st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs);
                 }
             }
+            // the resume kernel is also what zeroes the next batch's counters
+            e->ctl_clean[e->ctl_idx ^ 1] = true;
             if (vec)
                 hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl);
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1]);
             else
                 hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl);
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1]);
             HIP_TRY(hipGetLastError());
             rc = lt2.end();
             if (rc) return rc;
         }
     } else {
         float *st = static_cast<float *>(e->state);
+        rc = upload_desc();
+        if (rc) return rc;
         LaunchTimer lt{e, SC_KERNEL_AVERAGE};
         rc = lt.begin();
         if (rc) return rc;
@@ -1907,7 +1966,7 @@ void sc_destroy(sc_engine *e) {
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
-    if (e->ctl) (void)hipFree(e->ctl);
+    if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
     if (e->state) (void)hipFree(e->state);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
