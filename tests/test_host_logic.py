@@ -124,3 +124,26 @@ def test_voxels_run_averaging_exp_clip_and_labels():
 def test_voxels_run_without_bounding_box_exits():
     with pytest.raises(SystemExit):
         tasks_cl.voxels_run([], None, backprojection_cls=OracleBackprojection)  # tasks/cl.py:120-122
+
+
+def test_voxels_run_post_processing_helpers_match_numpy_expressions():
+    """tasks/cl.py:168,172-174: `len(np.unique(vol)) == 1` and `np.exp(vol); vol[vol > 1] = 1`
+    are restated (no sort; slabs on threads) -- the results must be the same arrays."""
+    from plant3dvision_amd.tasks.cl import _exp_clip, _single_valued
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64):
+        v = (rng.standard_normal((33, 200, 180)) * 3).astype(dt)  # > 2^20 elements: threaded path
+        v[3, 4, 5] = np.nan
+        v[1, 2, 3] = -np.inf
+        v[0, 0, 1] = np.inf
+        want = np.exp(v)
+        want[want > 1] = 1.0
+        got = _exp_clip(v)
+        assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True)
+        small = v[:2, :3, :4]
+        w2 = np.exp(small); w2[w2 > 1] = 1.0
+        assert np.array_equal(_exp_clip(small), w2, equal_nan=True)
+    last = np.zeros(10000); last[-1] = 1
+    for arr in (np.zeros((5, 5)), np.arange(9.0), np.full((3, 3), np.nan), np.array([np.nan, 1.0]),
+                np.array([1.0, np.nan]), np.zeros(10000, dtype=np.int32), last, np.full((2, 2), -1, dtype=np.int32)):
+        assert _single_valued(arr) == (len(np.unique(arr)) == 1), arr
