@@ -87,6 +87,8 @@ extern "C" {
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
+#define SC_OPT_FULL_BRICKS 19     /* 1 (default): a brick EVERY view of the batch sees whole, in-image, over
+                                     foreground only gets its labels (0 -> 1) without projecting a voxel */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

@@ -58,7 +58,7 @@ struct ViewDesc {   // 104 bytes, read with scalar loads (the view index is wave
     int32_t tiles_x;
     int32_t pad;
     float Wf, Hf;
-    const uint8_t *occ;  // carve: one byte per 32x32 tile, non-zero if the tile holds foreground
+    const uint8_t *occ;  // carve: one byte per 32x32 tile: bit 0 some foreground, bit 1 only foreground
 };
 static_assert(sizeof(ViewDesc) == 104, "ViewDesc layout");
 
@@ -97,6 +97,7 @@ struct ListCtl {
 struct CullStores {
     const uint8_t *flags;  // null: nothing deferred
     uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
+    int32_t kept, fresh;   // see Fill
 };
 
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
@@ -368,8 +369,8 @@ constexpr int kBrickY = 16, kBrickZ = 64;
 // every corner in front of the camera its image is the convex hull of the images of its four
 // corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
 // corners hold for every voxel of the brick.
-__device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDesc &g, float x, int j0,
-                                                int k0) {
+__device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
+                                                  int k0) {
     float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
     float pzmin = INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
@@ -396,7 +397,7 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
     }
-    if (nan) return false;
+    if (nan) return 0u;
     bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
     // pixel-space slack: 2 px + propagated dot-product error + relative slack of the final ops
     float inv = 2.0f / pzmin;
@@ -405,13 +406,19 @@ __device__ __forceinline__ bool brick_is_carved(const ViewDesc &d, const GridDes
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
     // a NaN anywhere makes a comparison false -> no culling
     bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
-    if (!inside) return false;
+    if (!inside) return 0u;
     int tx0 = (int)umin >> 5, tx1 = (int)umax >> 5, ty0 = (int)vmin >> 5, ty1 = (int)vmax >> 5;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) return false;
-    uint32_t o = 0;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) return 0u;
+    uint32_t any = 0, all = 3;
     for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) o |= d.occ[ty * d.tiles_x + tx];
-    return o == 0;
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            uint32_t o = d.occ[ty * d.tiles_x + tx];
+            any |= o;
+            all &= o;
+        }
+    // every voxel of the brick lands in-image on a pixel of these tiles: all of them background
+    // (EMPTY: the view carves the whole brick) or all of them foreground (FULL: the view keeps it)
+    return (any & 1u) == 0 ? 1u : ((all & 2u) != 0 ? 2u : 0u);
 }
 
 // The emptiness verdict of every brick ahead of the dense kernel: flags[brick] = 1 when ANY of the
@@ -436,39 +443,73 @@ struct DescCopy { const uint32_t *src; uint32_t *dst; uint32_t words; };
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
-    FlagViews own, DescCopy dc) {
-    __shared__ unsigned long long s_mask[kFlagWaves];
+    FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall) {
+    __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves];
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t lb = blockIdx.x * 64u + lane;
-    bool culled = false;
-    if (lb < nbricks) {
-        const uint32_t per_plane = bricks_y * bricks_z;
-        const uint32_t il = lb / per_plane;
-        const uint32_t rem = lb - il * per_plane;
-        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-        const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    const bool valid = lb < nbricks;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    const int j0 = (int)(by * kBrickY), k0 = (int)(bz * kBrickZ);
+    // round 0: the first `nviews` views, one per wavefront (more: strided)
+    bool empty = false, full = true;
+    if (valid) {
         if (views == nullptr) {  // grid-uniform: nviews <= kFlagWaves, one view per wavefront
-            if ((int)wave < nviews) culled = brick_is_carved(own.v[wave], g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+            if ((int)wave < nviews) {
+                const uint32_t v = brick_verdict(own.v[wave], g, x, j0, k0);
+                empty = v == 1u;
+                full = v == 2u;
+            }
         } else {
             for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
                 const ViewDesc d = views[vi];
-                culled |= brick_is_carved(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+                const uint32_t v = brick_verdict(d, g, x, j0, k0);
+                empty |= v == 1u;
+                full &= v == 2u;
             }
         }
     }
-    const unsigned long long mine = __ballot(culled);
-    if (lane == 0) s_mask[wave] = mine;
-    __syncthreads();
-    if (wave != 0) return;
-    unsigned long long any = 0;
+    unsigned long long any_empty = 0, cand = 0;
+    {
+        const unsigned long long me = __ballot(empty), mf = __ballot(full && valid);
+        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; }
+        __syncthreads();
+        cand = ~0ull;
 #pragma unroll
-    for (int w = 0; w < kFlagWaves; ++w) any |= s_mask[w];
-    const bool valid = lb < nbricks, dead = (any >> lane) & 1ull;
-    if (valid) flags[lb] = dead ? 1 : 0;
+        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; }
+        cand &= ~any_empty;
+    }
+    // FULL candidates (every view so far sees the whole brick over foreground) go through the
+    // remaining views, 8 per round, until one view says otherwise: on a plant no brick gets past
+    // round 0; inside a solid object this is what spares its voxels all their projections
+    for (int base = nviews; base < nall && cand != 0; base += kFlagWaves) {  // block-uniform
+        const int vi = base + (int)wave;
+        bool e2 = false, f2 = true;
+        if (vi < nall && ((cand >> lane) & 1ull)) {
+            const ViewDesc d = allviews[vi];
+            const uint32_t v = brick_verdict(d, g, x, j0, k0);
+            e2 = v == 1u;
+            f2 = v == 2u;
+        }
+        const unsigned long long me = __ballot(e2), mf = __ballot(f2);
+        __syncthreads();  // the previous round's masks have been read by everybody
+        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; }
+        cand &= ~any_empty;
+    }
+    if (nall <= 0) cand = 0;  // fullness not asked for
+    if (wave != 0) return;
+    const bool dead = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
+    if (valid) flags[lb] = dead ? 1 : (kept ? 2 : 0);
     // the bricks left go on the live list, one atomic per block
-    const bool alive = valid && !dead;
+    const bool alive = valid && !dead && !kept;
     const unsigned long long m = __ballot(alive);
     if (m != 0) {
         uint32_t base = 0;
@@ -609,28 +650,43 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     }
 }
 
-// -1 over every brick of a strip that the flags kernel found empty: live voxels become -1,
-// dead ones are -1 already.  One 16-byte store per lane and brick, nothing else.
+// The bricks of a strip the flags kernel has settled.  EMPTY (flag 1): live voxels become -1, dead
+// ones are -1 already -- one 16-byte store per lane and brick, nothing else.  FULL (flag 2): every
+// view keeps every voxel, so a label 0 becomes 1 and any other label stays (backprojection.c:81):
+// `kept` is that value for a volume known to hold `init` everywhere (fresh), else the labels are
+// read, patched and written back.
+struct Fill {
+    int32_t kept;   // label of a FULL brick's voxels when the volume is fresh: init == 0 ? 1 : init
+    int32_t fresh;  // the volume holds `init` everywhere (nothing applied since clear)
+};
+
 __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
                                                     const uint8_t *__restrict__ flags, uint32_t strip,
-                                                    uint32_t bricks_y, uint32_t bricks_z) {
+                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
     const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
-    const unsigned long long culled =
-        __ballot(lane < bricks_z && flags[strip * bricks_z + min(lane, bricks_z - 1)] != 0);
+    const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
+    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
     if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
     int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
     const bool vec = (g.nz & 3u) == 0;
     for (uint32_t bz = 0; bz < bricks_z; ++bz) {
-        if (!((culled >> bz) & 1ull)) continue;
+        const bool isfull = (full >> bz) & 1ull;
+        if (!((culled >> bz) & 1ull) && !isfull) continue;
         const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
         if (k0 >= g.nz) continue;
-        if (vec) {
-            *reinterpret_cast<int4 *>(col + k0) = make_int4(-1, -1, -1, -1);
-        } else {
-            const uint32_t n = min(4u, g.nz - k0);
-            for (uint32_t e = 0; e < n; ++e) col[k0 + e] = -1;
+        const uint32_t n = min(4u, g.nz - k0);
+        if (!isfull || fill.fresh) {
+            const int32_t val = isfull ? fill.kept : -1;
+            if (vec) {
+                *reinterpret_cast<int4 *>(col + k0) = make_int4(val, val, val, val);
+            } else {
+                for (uint32_t e = 0; e < n; ++e) col[k0 + e] = val;
+            }
+        } else {  // FULL brick of a stored volume: 0 -> 1, the rest as it is
+            for (uint32_t e = 0; e < n; ++e)
+                if (col[k0 + e] == 0) col[k0 + e] = 1;
         }
     }
 }
@@ -649,7 +705,8 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
                                                              const uint32_t *__restrict__ live,
                                                              const ListCtl *ctl, uint32_t nwalkers) {
     if (blockIdx.x >= nwalkers) {
-        store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z);
+        store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
+                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0});
         return;
     }
     const uint32_t nlive = ctl->nlive;
@@ -722,7 +779,8 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
     const bool split = FINAL && cs.flags != nullptr;
     const uint32_t nbid = split ? gridDim.x - (cs.nstrips - cs.first) : gridDim.x;
     if (split && blockIdx.x >= nbid) {
-        store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z);
+        store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z,
+                            Fill{cs.kept, cs.fresh});
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
@@ -1086,7 +1144,7 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
                                                         int64_t out_view_words, uint32_t flip,
                                                         uint8_t *__restrict__ occ) {
     // flip: 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
-    __shared__ uint32_t occ_s[ROWS * 4];
+    __shared__ uint32_t occ_s[ROWS * 4], hole_s[ROWS * 4];
     const int lane = threadIdx.x & 63;
     const int txb = (tiles_x + 3) >> 2;            // panels per tile row
     const int tyb = (tiles_y + ROWS - 1) / ROWS;   // block rows per view
@@ -1096,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
     int by = (int)(r % tyb);
     int view = (int)(r / tyb);
     if (view >= nviews) return;  // block-uniform
-    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = 0;
+    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = hole_s[threadIdx.x] = 0;
     int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
     int c = lane & 7;                                      // 16-pixel chunk inside the panel
     int u0 = bx * 128 + c * 16;
@@ -1120,14 +1178,17 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restric
         if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
             out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
             if (word) occ_s[k * 4 + (c >> 1)] = 1;  // racing stores of the same value
+            if (~word) hole_s[k * 4 + (c >> 1)] = 1;  // some background (padding counts as such)
         }
     }
     __syncthreads();
-    // tile occupancy: every byte written here (0 or 1), nothing for the host to clear
+    // tile occupancy: bit 0 = some foreground, bit 1 = nothing but foreground; every byte is
+    // written here, nothing for the host to clear
     if (threadIdx.x < ROWS * 4) {
         int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
         if (ty < tiles_y && txo < tiles_x)
-            occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] = occ_s[threadIdx.x] ? 1 : 0;
+            occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] =
+                (occ_s[threadIdx.x] ? 1 : 0) | (hole_s[threadIdx.x] ? 0 : 2);
     }
 }
 
@@ -1196,6 +1257,7 @@ struct sc_engine {
     ListCtl *ctl2[2] = {nullptr, nullptr};  // counter blocks of alternate batches (ctl points at the current one)
     bool ctl_clean[2] = {false, false};     // known to be all zero
     int ctl_idx = 0;
+    int64_t full_bricks = 1;      // bricks every view sees whole over foreground get their label without projections
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
@@ -1722,7 +1784,8 @@ int flush(sc_engine *e, size_t count = 0) {
                 }
                 hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
-                                   flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc);
+                                   flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
+                                   desc_by_flags ? vpin : vd, e->full_bricks ? (int)nv : 0);
                 rc = ltf.end();
                 if (rc) return rc;
                 rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
@@ -1755,12 +1818,13 @@ int flush(sc_engine *e, size_t count = 0) {
             rc = lt2.begin();
             if (rc) return rc;
             int vg = (int)e->view_group;
-            CullStores none{nullptr, 0u, 0u, 0u, 0u}, cs = none;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0}, cs = none;
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
             dim3 fgrid(list_blocks);
             if (defer_stores) {
-                cs = CullStores{e->flags, bys, bzs, nstrips, dense_store_strips};
+                cs = CullStores{e->flags, bys, bzs, nstrips, dense_store_strips, init == 0 ? 1 : init,
+                                e->fresh ? 1 : 0};
                 fgrid = dim3((uint32_t)e->defer_stores + (nstrips - dense_store_strips));
             }
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
@@ -2017,6 +2081,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_STAGE2_VIEWS:
             if (value < 0 || value > 4096) return fail(SC_ERR_INVALID, "stage2_views must be in [0, 4096]");
             e->stage2_views = value;
+            return SC_OK;
+        case SC_OPT_FULL_BRICKS:
+            e->full_bricks = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_DEFER_SHARE:
             if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "defer_share must be in [0, 16]");

@@ -157,6 +157,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_STAGE1_VIEWS": 64},                                          # single (final) list stage
     {"SC_OPT_STAGE1_VIEWS": 2, "SC_OPT_STAGE2_VIEWS": 3, "SC_OPT_VIEW_GROUP": 2},
     {"SC_OPT_VIEW_GROUP": 5, "SC_OPT_PACK_ROWS": 1},
+    {"SC_OPT_FULL_BRICKS": 0},
     {"SC_OPT_COMPACT": 0},                                                # bricks without survivor lists
     {"SC_OPT_VIEW_ORDER": 0},
 ])
@@ -192,6 +193,36 @@ def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape
     assert np.array_equal(e.get_values(), want), ("host masks", opts)
     e.dev_free(ptr)
     e.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 32, 128), (5, 37, 131), (3, 16, 64)])
+@pytest.mark.parametrize("default_value", [0, 1, -1, 7])
+@pytest.mark.parametrize("defer", [1536, 0])
+def test_bricks_every_view_keeps_whole(gpu_device, shape, default_value, defer):
+    """A brick that EVERY view sees whole, in-image, over foreground only is labelled without
+    projecting a voxel (0 -> 1, other labels stay).  Masks: all foreground ("solid"), then a
+    disc big enough to hold the inner bricks but not the outer ones; a fresh volume, a second
+    batch over the stored one, and a batch of inverted masks over that."""
+    sh, origin, vs, views = scene(shape, 9, "solid")
+    H, W = views[0][3].shape
+    yy, xx = np.mgrid[0:H, 0:W]
+    disc = (((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.30 * min(H, W)) ** 2).astype(np.uint8) * 255
+    for masks in ([m for _, _, _, m in views], [disc] * len(views)):
+        vv = [(K, R, t, m) for (K, R, t, _), m in zip(views, masks)]
+        want = oracle_c.carve(sh, origin, vs, vv, default_value, nthreads=4)
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=default_value)
+        e.set_option(nat.SC_OPT_DEFER_STORES, defer)
+        for K, R, t, m in vv:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), ("fresh", histogram3(want))
+        for K, R, t, m in vv:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), "stored state"
+        inv = [(K, R, t, np.invert(m)) for K, R, t, m in vv]
+        for K, R, t, m in inv:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), oracle_c.carve(sh, origin, vs, vv + inv, default_value, nthreads=4))
+        e.close()
 
 
 def test_fused_compaction_with_slab_and_default_values(gpu_device):
