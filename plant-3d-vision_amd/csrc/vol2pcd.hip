@@ -38,28 +38,49 @@ constexpr int kBlk = 8;  // activity is tracked per 8x8x8 block of voxels
 
 int fail_v(int code, const char *msg);  // defined below
 
-// Geometry shared by the per-voxel kernels: one thread per voxel, threads along z,
-// blockIdx.y = y, blockIdx.z = x (no divisions), plus the block-activity map.
+// Geometry shared by the per-voxel kernels.  They run on the ACTIVE 8^3 blocks only (a list built
+// on the device: a few per cent of a plant's volume): thread block b takes list entry b, thread t
+// the voxels t and t + 256 of its 512.
 struct Vol {
     int nx, ny, nz;
     int nby, nbz;            // blocks along y and z
     const uint8_t *active;   // [nbx][nby][nbz], 1 = within reach of the surface
+    const uint32_t *list;    // linear ids of the blocks a kernel walks (active, or halo)
+    const uint32_t *cols;    // columns of blocks (bx * nby + by) holding an active block (shell kernels)
 };
 
-__device__ __forceinline__ bool voxel(const Vol &v, int &x, int &y, int &z, int64_t &i) {
-    x = blockIdx.z;
-    y = blockIdx.y;
-    z = blockIdx.x * kB + threadIdx.x;
-    if (z >= v.nz) return false;
+__device__ __forceinline__ bool voxel(const Vol &v, int q, int &x, int &y, int &z, int64_t &i) {
+    const uint32_t b = v.list[blockIdx.x];
+    const int bz = (int)(b % (uint32_t)v.nbz), by = (int)((b / (uint32_t)v.nbz) % (uint32_t)v.nby),
+              bx = (int)(b / ((uint32_t)v.nbz * (uint32_t)v.nby));
+    const int l = (int)threadIdx.x + q * kB;  // 0..511: dx = l >> 6, dy = (l >> 3) & 7, dz = l & 7
+    x = bx * kBlk + (l >> 6);
+    y = by * kBlk + ((l >> 3) & 7);
+    z = bz * kBlk + (l & 7);
+    if (x >= v.nx || y >= v.ny || z >= v.nz) return false;
     i = ((int64_t)x * v.ny + y) * v.nz + z;
-    return v.active[((int64_t)(x / kBlk) * v.nby + (y / kBlk)) * v.nbz + (z / kBlk)] != 0;
+    return true;
 }
 
+// binarise (proc3d.py:515): 16 voxels per thread, one 16-byte store
 template <typename T>
 __global__ __launch_bounds__(kB) void occ_kernel(const T *__restrict__ vol, uint8_t *__restrict__ occ,
                                                  int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x;
-    if (i < n) occ[i] = (double)vol[i] > 0.5 ? 1 : 0;  // proc3d.py:515
+    int64_t i0 = ((int64_t)blockIdx.x * kB + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    if (i0 + 16 <= n && (reinterpret_cast<uintptr_t>(occ) & 15) == 0) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bits |= ((double)vol[i0 + q * 4 + e] > 0.5 ? 1u : 0u) << (8 * e);
+            w[q] = bits;
+        }
+        *reinterpret_cast<uint4 *>(occ + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int64_t i = i0; i < min(n, i0 + 16); ++i) occ[i] = (double)vol[i] > 0.5 ? 1 : 0;
+    }
 }
 
 // per 8^3 block: bit 0 = holds a foreground voxel, bit 1 = holds a background voxel
@@ -107,49 +128,118 @@ __global__ __launch_bounds__(kB) void block_active_kernel(const uint8_t *__restr
     active[b] = (uint8_t)((((own & 1u) && (near & 2u)) || ((own & 2u) && (near & 1u))) ? 1 : 0);
 }
 
+// Compact the block map into two lists: ACTIVE blocks (the per-voxel kernels walk these) and HALO
+// blocks (inactive, but within rb blocks of an active one: the EDT passes of active voxels read
+// them, so they must hold "far").  counts[0] / counts[1] receive the list lengths.
+__global__ __launch_bounds__(kB) void block_lists_kernel(const uint8_t *__restrict__ active, int nbx, int nby,
+                                                         int nbz, int rb, uint32_t *__restrict__ act_list,
+                                                         uint32_t *__restrict__ halo_list,
+                                                         uint32_t *__restrict__ counts) {
+    int64_t b = (int64_t)blockIdx.x * kB + threadIdx.x;
+    bool is_act = false, is_halo = false;
+    if (b < (int64_t)nbx * nby * nbz) {
+        is_act = active[b] != 0;
+        if (!is_act) {
+            int bz = (int)(b % nbz), by = (int)((b / nbz) % nby), bx = (int)(b / ((int64_t)nbz * nby));
+            uint32_t near = 0;
+            for (int x = max(0, bx - rb); x <= min(nbx - 1, bx + rb); ++x)
+                for (int y = max(0, by - rb); y <= min(nby - 1, by + rb); ++y)
+                    for (int z = max(0, bz - rb); z <= min(nbz - 1, bz + rb); ++z)
+                        near |= active[((int64_t)x * nby + y) * nbz + z];
+            is_halo = near != 0;
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    unsigned long long ma = __ballot(is_act), mh = __ballot(is_halo);
+    uint32_t ba = 0, bh = 0;
+    if (lane == 0) {
+        if (ma) ba = atomicAdd(&counts[0], (uint32_t)__popcll(ma));
+        if (mh) bh = atomicAdd(&counts[1], (uint32_t)__popcll(mh));
+    }
+    ba = __shfl(ba, 0);
+    bh = __shfl(bh, 0);
+    if (is_act) act_list[ba + (uint32_t)__popcll(ma & below)] = (uint32_t)b;
+    if (is_halo) halo_list[bh + (uint32_t)__popcll(mh & below)] = (uint32_t)b;
+}
+
+// halo blocks: (far, far) in both EDT buffers
+__global__ __launch_bounds__(kB) void halo_fill_kernel(uint32_t *__restrict__ g0, uint32_t *__restrict__ g1, Vol v) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int x, y, z;
+        int64_t i;
+        if (!voxel(v, q, x, y, z, i)) continue;
+        g0[i] = 0xffffffffu;
+        g1[i] = 0xffffffffu;
+    }
+}
+
+// columns of blocks (bx, by) that hold an active block: the shell kernels visit only their rows
+__global__ __launch_bounds__(kB) void column_list_kernel(const uint8_t *__restrict__ active, int ncols, int nbz,
+                                                         uint32_t *__restrict__ col_list,
+                                                         uint32_t *__restrict__ count) {
+    int c = (int)(blockIdx.x * kB + threadIdx.x);
+    bool any = false;
+    if (c < ncols)
+        for (int bz = 0; bz < nbz; ++bz) any |= active[(int64_t)c * nbz + bz] != 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(any), below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (any) col_list[base + (uint32_t)__popcll(m & below)] = (uint32_t)c;
+}
+
 // EDT pass along z (the contiguous axis).  Two channels per voxel, packed lo/hi 16 bits:
 // A = squared distance to the nearest BACKGROUND voxel of the line, B = to the nearest FOREGROUND
 // voxel; a voxel's own class gives 0 in the other channel.  Exact up to R, kFar beyond.
-// Inactive voxels keep the (far, far) the buffers are pre-filled with: no active voxel of the
-// other class lies within R of them, so they are never anybody's nearest site.
+// Inactive voxels count as (far, far): no active voxel of the other class lies within R of them,
+// so they are never anybody's nearest site (halo blocks are filled with that, the rest is never read).
 __global__ __launch_bounds__(kB) void edt_z_kernel(const uint8_t *__restrict__ occ,
                                                    uint32_t *__restrict__ g, Vol v, int R) {
-    int x, y, k;
-    int64_t i;
-    if (!voxel(v, x, y, k, i)) return;
-    uint8_t c = occ[i];
-    uint32_t best = kFar;
-    for (int d = 1; d <= R; ++d) {
-        bool hit = (k - d >= 0 && occ[i - d] != c) || (k + d < v.nz && occ[i + d] != c);
-        if (hit) { best = (uint32_t)(d * d); break; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int x, y, k;
+        int64_t i;
+        if (!voxel(v, q, x, y, k, i)) continue;
+        uint8_t c = occ[i];
+        uint32_t best = kFar;
+        for (int d = 1; d <= R; ++d) {
+            bool hit = (k - d >= 0 && occ[i - d] != c) || (k + d < v.nz && occ[i + d] != c);
+            if (hit) { best = (uint32_t)(d * d); break; }
+        }
+        g[i] = c ? best : (best << 16);  // fg: A=best,B=0 ; bg: A=0,B=best
     }
-    g[i] = c ? best : (best << 16);  // fg: A=best,B=0 ; bg: A=0,B=best
 }
 
 // EDT pass along y: both channels,  H(p) = min_j ( j^2 + G(p + j*stride) ), |j| <= R.
 __global__ __launch_bounds__(kB) void edt_y_kernel(const uint32_t *__restrict__ g,
                                                    uint32_t *__restrict__ h, Vol v, int R) {
-    int x, p, z;
-    int64_t i;
-    if (!voxel(v, x, p, z, i)) return;
-    const int64_t stride = v.nz;
-    uint32_t w0 = g[i];
-    uint32_t a = w0 & 0xffffu, b = w0 >> 16;
-    for (int j = 1; j <= R; ++j) {
-        uint32_t jj = (uint32_t)(j * j);
-        if (jj >= a && jj >= b) break;  // nothing farther can improve either channel
-        if (p - j >= 0) {
-            uint32_t w = g[i - j * stride];
-            a = min(a, (w & 0xffffu) + jj);
-            b = min(b, (w >> 16) + jj);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int x, p, z;
+        int64_t i;
+        if (!voxel(v, q, x, p, z, i)) continue;
+        const int64_t stride = v.nz;
+        uint32_t w0 = g[i];
+        uint32_t a = w0 & 0xffffu, b = w0 >> 16;
+        for (int j = 1; j <= R; ++j) {
+            uint32_t jj = (uint32_t)(j * j);
+            if (jj >= a && jj >= b) break;  // nothing farther can improve either channel
+            if (p - j >= 0) {
+                uint32_t w = g[i - j * stride];
+                a = min(a, (w & 0xffffu) + jj);
+                b = min(b, (w >> 16) + jj);
+            }
+            if (p + j < v.ny) {
+                uint32_t w = g[i + j * stride];
+                a = min(a, (w & 0xffffu) + jj);
+                b = min(b, (w >> 16) + jj);
+            }
         }
-        if (p + j < v.ny) {
-            uint32_t w = g[i + j * stride];
-            a = min(a, (w & 0xffffu) + jj);
-            b = min(b, (w >> 16) + jj);
-        }
+        h[i] = min(a, kFar) | (min(b, kFar) << 16);
     }
-    h[i] = min(a, kFar) | (min(b, kFar) << 16);
 }
 
 // last EDT pass (along x) fused with the signed distance of proc3d.py:518-522:
@@ -157,38 +247,46 @@ __global__ __launch_bounds__(kB) void edt_y_kernel(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(kB) void edt_x_kernel(const uint32_t *__restrict__ g,
                                                    const uint8_t *__restrict__ occ,
                                                    double *__restrict__ sd, Vol v, int R) {
-    int p, y, z;
-    int64_t i;
-    if (!voxel(v, p, y, z, i)) return;
-    const int64_t stride = (int64_t)v.ny * v.nz;
-    bool fg = occ[i] != 0;
-    int sh = fg ? 0 : 16;
-    uint32_t a = (g[i] >> sh) & 0xffffu;
-    for (int j = 1; j <= R; ++j) {
-        uint32_t jj = (uint32_t)(j * j);
-        if (jj >= a) break;
-        if (p - j >= 0) a = min(a, ((g[i - j * stride] >> sh) & 0xffffu) + jj);
-        if (p + j < v.nx) a = min(a, ((g[i + j * stride] >> sh) & 0xffffu) + jj);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int p, y, z;
+        int64_t i;
+        if (!voxel(v, q, p, y, z, i)) continue;
+        const int64_t stride = (int64_t)v.ny * v.nz;
+        bool fg = occ[i] != 0;
+        int sh = fg ? 0 : 16;
+        uint32_t a = (g[i] >> sh) & 0xffffu;
+        for (int j = 1; j <= R; ++j) {
+            uint32_t jj = (uint32_t)(j * j);
+            if (jj >= a) break;
+            if (p - j >= 0) a = min(a, ((g[i - j * stride] >> sh) & 0xffffu) + jj);
+            if (p + j < v.nx) a = min(a, ((g[i + j * stride] >> sh) & 0xffffu) + jj);
+        }
+        double d = sqrt((double)a);  // exact integer in, correctly rounded sqrt
+        sd[i] = fg ? d - 0.5 : -d + 0.5;
     }
-    double d = sqrt((double)a);  // exact integer in, correctly rounded sqrt
-    sd[i] = fg ? d - 0.5 : -d + 0.5;
 }
 
-// np.gradient along one axis (unit spacing, edge_order 1)
+// np.gradient along one axis (unit spacing, edge_order 1).  At the rim of the active region a
+// neighbour may be an inactive voxel holding anything: such values can only reach voxels farther
+// from the shell than anything the shell's points depend on (see R).
 template <int AXIS>
 __global__ __launch_bounds__(kB) void gradient_kernel(const double *__restrict__ f,
                                                       double *__restrict__ out, Vol v) {
-    int x, y, z;
-    int64_t i;
-    if (!voxel(v, x, y, z, i)) return;
-    const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
-    const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
-    const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
-    double r;
-    if (p == 0) r = f[i + stride] - f[i];
-    else if (p == len - 1) r = f[i] - f[i - stride];
-    else r = (f[i + stride] - f[i - stride]) / 2.0;
-    out[i] = r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int x, y, z;
+        int64_t i;
+        if (!voxel(v, q, x, y, z, i)) continue;
+        const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
+        const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
+        const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
+        double r;
+        if (p == 0) r = f[i + stride] - f[i];
+        else if (p == len - 1) r = f[i] - f[i - stride];
+        else r = (f[i + stride] - f[i - stride]) / 2.0;
+        out[i] = r;
+    }
 }
 
 __device__ __forceinline__ int reflect_index(int q, int len) {  // scipy "reflect": d c b a | a b c d | d c b a
@@ -204,69 +302,95 @@ struct GaussW { double w[5]; };  // w[0] centre .. w[4] farthest
 template <int AXIS>
 __global__ __launch_bounds__(kB) void gauss_kernel(const double *__restrict__ f, double *__restrict__ out,
                                                    Vol v, GaussW gw) {
-    int x, y, z;
-    int64_t i;
-    if (!voxel(v, x, y, z, i)) return;
-    const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
-    const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
-    const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
-    int64_t base = i - (int64_t)p * stride;
-    double tmp = f[i] * gw.w[0];
-    if (p >= 4 && p + 4 < len) {
 #pragma unroll
-        for (int j = 4; j >= 1; --j) tmp += (f[i - j * stride] + f[i + j * stride]) * gw.w[j];
-    } else {
+    for (int q = 0; q < 2; ++q) {
+        int x, y, z;
+        int64_t i;
+        if (!voxel(v, q, x, y, z, i)) continue;
+        const int64_t stride = AXIS == 0 ? (int64_t)v.ny * v.nz : AXIS == 1 ? v.nz : 1;
+        const int p = AXIS == 0 ? x : AXIS == 1 ? y : z;
+        const int len = AXIS == 0 ? v.nx : AXIS == 1 ? v.ny : v.nz;
+        int64_t base = i - (int64_t)p * stride;
+        double tmp = f[i] * gw.w[0];
+        if (p >= 4 && p + 4 < len) {
 #pragma unroll
-        for (int j = 4; j >= 1; --j)
-            tmp += (f[base + (int64_t)reflect_index(p - j, len) * stride] +
-                    f[base + (int64_t)reflect_index(p + j, len) * stride]) * gw.w[j];
+            for (int j = 4; j >= 1; --j) tmp += (f[i - j * stride] + f[i + j * stride]) * gw.w[j];
+        } else {
+#pragma unroll
+            for (int j = 4; j >= 1; --j)
+                tmp += (f[base + (int64_t)reflect_index(p - j, len) * stride] +
+                        f[base + (int64_t)reflect_index(p + j, len) * stride]) * gw.w[j];
+        }
+        out[i] = tmp;
     }
-    out[i] = tmp;
 }
 
-// shell test of proc3d.py:535: (dist > -lsv) * (dist <= -lsv + sqrt(3)); counts per 1024-voxel chunk
+// shell test of proc3d.py:535: (dist > -lsv) * (dist <= -lsv + sqrt(3)), on active voxels only (the
+// signed distance of the others is never computed).  A chunk is up to 1024 voxels of one (x, y)
+// row, chunk id = (x * ny + y) * nzseg + segment -- C order, like the reference's np.argwhere.  Only
+// rows of block columns that hold an active block are visited (the counts of the others stay 0).
 constexpr int kChunk = 1024;
-__global__ __launch_bounds__(kB) void shell_count_kernel(const double *__restrict__ sd, int64_t n,
+
+__device__ __forceinline__ bool on_shell(const double *__restrict__ sd, const Vol &v, int x, int y, int z,
+                                         double lo, double hi, int64_t &i, double &d) {
+    if (z >= v.nz) return false;
+    if (v.active[((int64_t)(x / kBlk) * v.nby + (y / kBlk)) * v.nbz + (z / kBlk)] == 0) return false;
+    i = ((int64_t)x * v.ny + y) * v.nz + z;
+    d = sd[i];
+    return (d > lo) & (d <= hi);
+}
+
+// blockIdx.x = 64 * (entry of the active-column list) + row inside the column, blockIdx.y = z segment
+__device__ __forceinline__ bool shell_row(const Vol &v, int &x, int &y) {
+    const uint32_t c = v.cols[blockIdx.x >> 6], l = blockIdx.x & 63u;
+    x = (int)(c / (uint32_t)v.nby) * kBlk + (int)(l >> 3);
+    y = (int)(c % (uint32_t)v.nby) * kBlk + (int)(l & 7u);
+    return x < v.nx && y < v.ny;
+}
+
+__global__ __launch_bounds__(kB) void shell_count_kernel(const double *__restrict__ sd, Vol v,
                                                          double lo, double hi,
                                                          uint32_t *__restrict__ counts) {
     __shared__ uint32_t s[kB / 64];
-    int64_t base = (int64_t)blockIdx.x * kChunk;
+    int x, y;
+    if (!shell_row(v, x, y)) return;  // block-uniform
     uint32_t c = 0;
     for (int q = 0; q < kChunk / kB; ++q) {
-        int64_t i = base + q * kB + threadIdx.x;
-        if (i < n) {
-            double d = sd[i];
-            c += (d > lo) & (d <= hi);
-        }
+        int z = (int)blockIdx.y * kChunk + q * kB + (int)threadIdx.x;
+        int64_t i;
+        double d;
+        c += on_shell(sd, v, x, y, z, lo, hi, i, d) ? 1u : 0u;
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0)
+        counts[((int64_t)x * v.ny + y) * gridDim.y + blockIdx.y] = s[0] + s[1] + s[2] + s[3];
 }
 
 // C-order compaction of the shell + the per-point step of proc3d.py:539-553,563
 __global__ __launch_bounds__(kB) void shell_points_kernel(const double *__restrict__ sd,
                                                           const double *__restrict__ gx,
                                                           const double *__restrict__ gy,
-                                                          const double *__restrict__ gz, int64_t n,
-                                                          int ny, int nz, double lo, double hi,
+                                                          const double *__restrict__ gz, Vol v,
+                                                          double lo, double hi,
                                                           double lsv, double ox, double oy, double oz,
-                                                          double vs, const uint64_t *__restrict__ offsets,
+                                                          double vs, const uint32_t *__restrict__ counts,
+                                                          const uint64_t *__restrict__ offsets,
                                                           double *__restrict__ pts,
                                                           double *__restrict__ nrm) {
     __shared__ uint32_t wsum[kB / 64];
-    int64_t base = (int64_t)blockIdx.x * kChunk;
-    uint64_t off = offsets[blockIdx.x];
+    int x, y;
+    if (!shell_row(v, x, y)) return;  // block-uniform
+    const int64_t chunk = ((int64_t)x * v.ny + y) * gridDim.y + blockIdx.y;
+    if (counts[chunk] == 0) return;  // block-uniform
+    uint64_t off = offsets[chunk];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int q = 0; q < kChunk / kB; ++q) {
-        int64_t i = base + q * kB + threadIdx.x;
-        bool on = false;
+        int z = (int)blockIdx.y * kChunk + q * kB + (int)threadIdx.x;
+        int64_t i = 0;
         double d = 0.0;
-        if (i < n) {
-            d = sd[i];
-            on = (d > lo) & (d <= hi);
-        }
+        bool on = on_shell(sd, v, x, y, z, lo, hi, i, d);
         unsigned long long b = __ballot(on);
         if (lane == 0) wsum[wave] = (uint32_t)__popcll(b);
         __syncthreads();
@@ -284,8 +408,7 @@ __global__ __launch_bounds__(kB) void shell_points_kernel(const double *__restri
             if (nn > 0.0) {
                 double u0 = a / nn, u1 = bq / nn, u2 = c / nn;
                 double val = d + lsv - sqrt(3.0) / 2.0;
-                int64_t col = i / nz;
-                double xi = (double)(col / ny), yi = (double)(col % ny), zi = (double)(i % nz);
+                double xi = (double)x, yi = (double)y, zi = (double)z;
                 // index2point (proc3d.py:45): voxel_size * idx + origin
                 px = vs * (xi - u0 * val) + ox;
                 py = vs * (yi - u1 * val) + oy;
@@ -301,6 +424,57 @@ __global__ __launch_bounds__(kB) void shell_points_kernel(const double *__restri
         off += total;
         __syncthreads();
     }
+}
+
+// Exclusive prefix sum of the chunk counts (C order) on the device, so that only the total
+// crosses PCIe: per x-plane sums, then every plane scans its own counts from its base.
+__global__ __launch_bounds__(kB) void plane_sums_kernel(const uint32_t *__restrict__ counts, int64_t per_plane,
+                                                        uint64_t *__restrict__ plane_sum) {
+    __shared__ uint64_t s[kB / 64];
+    const uint32_t *c = counts + (int64_t)blockIdx.x * per_plane;
+    uint64_t sum = 0;
+    for (int64_t i = threadIdx.x; i < per_plane; i += kB) sum += c[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) plane_sum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(kB) void chunk_offsets_kernel(const uint32_t *__restrict__ counts, int64_t per_plane,
+                                                           const uint64_t *__restrict__ plane_sum,
+                                                           uint64_t *__restrict__ offsets,
+                                                           uint64_t *__restrict__ total) {
+    __shared__ uint64_t s[kB / 64];
+    __shared__ uint64_t carry;
+    // base of this plane = sum of the planes before it
+    uint64_t before = 0;
+    for (uint32_t x = threadIdx.x; x < blockIdx.x; x += kB) before += plane_sum[x];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = s[0] + s[1] + s[2] + s[3];
+    __syncthreads();
+    const uint32_t *c = counts + (int64_t)blockIdx.x * per_plane;
+    uint64_t *o = offsets + (int64_t)blockIdx.x * per_plane;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t t = 0; t < per_plane; t += kB) {
+        const int64_t i = t + threadIdx.x;
+        const uint64_t mine = i < per_plane ? c[i] : 0;
+        uint64_t inc = mine;  // inclusive scan inside the wavefront
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t up = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += up;
+        }
+        if (lane == 63) s[wave] = inc;
+        __syncthreads();
+        uint64_t base = carry;
+        for (uint32_t w = 0; w < wave; ++w) base += s[w];
+        if (i < per_plane) o[i] = base + inc - mine;
+        __syncthreads();
+        if (threadIdx.x == kB - 1) carry = base + inc;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry;
 }
 
 thread_local char g_verr[256];
@@ -346,38 +520,49 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     const int nbx = (int)((nx + kBlk - 1) / kBlk), nby = (int)((ny + kBlk - 1) / kBlk),
               nbz = (int)((nz + kBlk - 1) / kBlk);
     const int64_t nb = (int64_t)nbx * nby * nbz;
-    const uint32_t nchunks = (uint32_t)((n + kChunk - 1) / kChunk);
+    const uint32_t nzseg = (uint32_t)((nz + kChunk - 1) / kChunk);
+    const int64_t nchunks = nx * ny * (int64_t)nzseg;
     const double lo = -level_set_value, hi = -level_set_value + std::sqrt(3.0);
     int rc = SC_OK;
     void *vol_d = nullptr;
     char *scratch = nullptr;
     double *pts_d = nullptr, *nrm_d = nullptr;
-    std::vector<uint32_t> hc;
-    std::vector<uint64_t> ho;
     GaussW gw;
     memcpy(gw.w, gauss_w, sizeof gw.w);
     uint64_t total = 0;
+    uint32_t nlist[3] = {0, 0, 0};
     hipStream_t st = nullptr;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    // one scratch allocation: occ | cls | active | counts | offsets | sd | A (g0,g1 then ga) | gb | gx | gy | gz
+    // one scratch allocation:
+    // occ | cls | active | block lists (active, halo) + their lengths + shell total | counts | offsets |
+    // sd | A (g0,g1 then ga) | gb | gx | gy | gz
     const size_t o_occ = 0, o_cls = o_occ + al((size_t)n), o_act = o_cls + al((size_t)nb),
-                 o_cnt = o_act + al((size_t)nb), o_off = o_cnt + al((size_t)nchunks * 4),
+                 o_la = o_act + al((size_t)nb), o_lh = o_la + al((size_t)nb * 4), o_lc = o_lh + al((size_t)nb * 4),
+                 o_ln = o_lc + al((size_t)nbx * nby * 4),
+                 o_pl = o_ln + al(64), o_cnt = o_pl + al((size_t)nx * 8), o_off = o_cnt + al((size_t)nchunks * 4),
                  o_sd = o_off + al((size_t)nchunks * 8), o_a = o_sd + al((size_t)n * 8),
                  o_b = o_a + al((size_t)n * 8), o_gx = o_b + al((size_t)n * 8),
                  o_gy = o_gx + al((size_t)n * 8), o_gz = o_gy + al((size_t)n * 8),
                  bytes = o_gz + al((size_t)n * 8);
     uint8_t *occ, *cls, *act;
-    uint32_t *counts, *g0, *g1;
-    uint64_t *offs_d;
+    uint32_t *counts, *g0, *g1, *list_act, *list_halo, *list_cols, *list_n;
+    uint64_t *offs_d, *total_d, *plane_d;
     double *sd, *ga, *gb, *gx, *gy, *gz;
-    Vol v;
-    dim3 grid((uint32_t)((nz + kB - 1) / kB), (uint32_t)ny, (uint32_t)nx), block(kB);
+    Vol v, vh;
+    dim3 block(kB);
 
+    if (nb > 0xffffffffLL || nchunks > 0x7fffffffLL) return fail_v(SC_ERR_INVALID, "volume too large");
     V_TRY(hipSetDevice(device));
     V_TRY(hipMalloc(reinterpret_cast<void **>(&scratch), bytes));
     occ = reinterpret_cast<uint8_t *>(scratch + o_occ);
     cls = reinterpret_cast<uint8_t *>(scratch + o_cls);
     act = reinterpret_cast<uint8_t *>(scratch + o_act);
+    list_act = reinterpret_cast<uint32_t *>(scratch + o_la);
+    list_halo = reinterpret_cast<uint32_t *>(scratch + o_lh);
+    list_cols = reinterpret_cast<uint32_t *>(scratch + o_lc);
+    list_n = reinterpret_cast<uint32_t *>(scratch + o_ln);
+    total_d = reinterpret_cast<uint64_t *>(scratch + o_ln + 16);
+    plane_d = reinterpret_cast<uint64_t *>(scratch + o_pl);
     counts = reinterpret_cast<uint32_t *>(scratch + o_cnt);
     offs_d = reinterpret_cast<uint64_t *>(scratch + o_off);
     sd = reinterpret_cast<double *>(scratch + o_sd);
@@ -388,7 +573,8 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     gx = reinterpret_cast<double *>(scratch + o_gx);
     gy = reinterpret_cast<double *>(scratch + o_gy);
     gz = reinterpret_cast<double *>(scratch + o_gz);
-    v = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act};
+    v = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act, list_act, list_cols};
+    vh = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act, list_halo, list_cols};
     if (on_device) {
         vol_d = const_cast<void *>(volume);
     } else {
@@ -396,47 +582,57 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
         V_TRY(hipMemcpy(vol_d, volume, (size_t)n * esz, hipMemcpyHostToDevice));
     }
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(occ_kernel<int32_t>, dim3(blocks_for(n)), block, 0, st, (const int32_t *)vol_d, occ, n); break;
-        case 1: hipLaunchKernelGGL(occ_kernel<float>, dim3(blocks_for(n)), block, 0, st, (const float *)vol_d, occ, n); break;
-        case 2: hipLaunchKernelGGL(occ_kernel<double>, dim3(blocks_for(n)), block, 0, st, (const double *)vol_d, occ, n); break;
-        default: hipLaunchKernelGGL(occ_kernel<uint8_t>, dim3(blocks_for(n)), block, 0, st, (const uint8_t *)vol_d, occ, n); break;
+        case 0: hipLaunchKernelGGL(occ_kernel<int32_t>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const int32_t *)vol_d, occ, n); break;
+        case 1: hipLaunchKernelGGL(occ_kernel<float>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const float *)vol_d, occ, n); break;
+        case 2: hipLaunchKernelGGL(occ_kernel<double>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const double *)vol_d, occ, n); break;
+        default: hipLaunchKernelGGL(occ_kernel<uint8_t>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const uint8_t *)vol_d, occ, n); break;
     }
     hipLaunchKernelGGL(block_class_kernel, dim3(blocks_for(nb)), block, 0, st, occ, (int)nx, (int)ny, (int)nz, nbx, nby, nbz, cls);
     hipLaunchKernelGGL(block_active_kernel, dim3(blocks_for(nb)), block, 0, st, cls, nbx, nby, nbz, rb, act);
-    // inactive voxels: (far, far) in both EDT buffers, NaN signed distance (never on the shell)
-    V_TRY(hipMemsetAsync(g0, 0xff, (size_t)n * 8, st));
-    V_TRY(hipMemsetAsync(sd, 0xff, (size_t)n * 8, st));
-    hipLaunchKernelGGL(edt_z_kernel, grid, block, 0, st, occ, g0, v, R);
-    hipLaunchKernelGGL(edt_y_kernel, grid, block, 0, st, g0, g1, v, R);
-    hipLaunchKernelGGL(edt_x_kernel, grid, block, 0, st, g1, occ, sd, v, R);
+    V_TRY(hipMemsetAsync(list_n, 0, 64, st));
+    hipLaunchKernelGGL(block_lists_kernel, dim3(blocks_for(nb)), block, 0, st, act, nbx, nby, nbz, rb, list_act,
+                       list_halo, list_n);
+    hipLaunchKernelGGL(column_list_kernel, dim3(blocks_for((int64_t)nbx * nby)), block, 0, st, act, nbx * nby, nbz,
+                       list_cols, list_n + 2);
+    V_TRY(hipMemsetAsync(counts, 0, (size_t)nchunks * 4, st));  // rows the shell kernels skip count nothing
     V_TRY(hipGetLastError());
-    // gradient along each axis, then gaussian_filter: axes 0, 1, 2 in turn (proc3d.py:525-531)
-    hipLaunchKernelGGL(gradient_kernel<0>, grid, block, 0, st, sd, ga, v);
-    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gx, v, gw);
-    hipLaunchKernelGGL(gradient_kernel<1>, grid, block, 0, st, sd, ga, v);
-    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gy, v, gw);
-    hipLaunchKernelGGL(gradient_kernel<2>, grid, block, 0, st, sd, ga, v);
-    hipLaunchKernelGGL(gauss_kernel<0>, grid, block, 0, st, ga, gb, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<1>, grid, block, 0, st, gb, ga, v, gw);
-    hipLaunchKernelGGL(gauss_kernel<2>, grid, block, 0, st, ga, gz, v, gw);
-    V_TRY(hipGetLastError());
-    hipLaunchKernelGGL(shell_count_kernel, dim3(nchunks), block, 0, st, sd, n, lo, hi, counts);
-    V_TRY(hipGetLastError());
-    hc.resize(nchunks);
-    V_TRY(hipMemcpy(hc.data(), counts, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
-    ho.resize(nchunks);
-    for (uint32_t c = 0; c < nchunks; ++c) { ho[c] = total; total += hc[c]; }
+    // the only host round trip before the result: how many blocks the per-voxel kernels walk
+    V_TRY(hipMemcpy(nlist, list_n, sizeof nlist, hipMemcpyDeviceToHost));
+    if (nlist[0] > 0) {
+        const dim3 ga_(nlist[0]);
+        // halo blocks hold (far, far) in both EDT buffers; other inactive voxels are never read
+        if (nlist[1] > 0) hipLaunchKernelGGL(halo_fill_kernel, dim3(nlist[1]), block, 0, st, g0, g1, vh);
+        hipLaunchKernelGGL(edt_z_kernel, ga_, block, 0, st, occ, g0, v, R);
+        hipLaunchKernelGGL(edt_y_kernel, ga_, block, 0, st, g0, g1, v, R);
+        hipLaunchKernelGGL(edt_x_kernel, ga_, block, 0, st, g1, occ, sd, v, R);
+        V_TRY(hipGetLastError());
+        // gradient along each axis, then gaussian_filter: axes 0, 1, 2 in turn (proc3d.py:525-531)
+        hipLaunchKernelGGL(gradient_kernel<0>, ga_, block, 0, st, sd, ga, v);
+        hipLaunchKernelGGL(gauss_kernel<0>, ga_, block, 0, st, ga, gb, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<1>, ga_, block, 0, st, gb, ga, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<2>, ga_, block, 0, st, ga, gx, v, gw);
+        hipLaunchKernelGGL(gradient_kernel<1>, ga_, block, 0, st, sd, ga, v);
+        hipLaunchKernelGGL(gauss_kernel<0>, ga_, block, 0, st, ga, gb, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<1>, ga_, block, 0, st, gb, ga, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<2>, ga_, block, 0, st, ga, gy, v, gw);
+        hipLaunchKernelGGL(gradient_kernel<2>, ga_, block, 0, st, sd, ga, v);
+        hipLaunchKernelGGL(gauss_kernel<0>, ga_, block, 0, st, ga, gb, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<1>, ga_, block, 0, st, gb, ga, v, gw);
+        hipLaunchKernelGGL(gauss_kernel<2>, ga_, block, 0, st, ga, gz, v, gw);
+        V_TRY(hipGetLastError());
+        const dim3 rows(nlist[2] * 64u, nzseg);
+        hipLaunchKernelGGL(shell_count_kernel, rows, block, 0, st, sd, v, lo, hi, counts);
+        hipLaunchKernelGGL(plane_sums_kernel, dim3((uint32_t)nx), block, 0, st, counts, ny * (int64_t)nzseg, plane_d);
+        hipLaunchKernelGGL(chunk_offsets_kernel, dim3((uint32_t)nx), block, 0, st, counts, ny * (int64_t)nzseg, plane_d,
+                           offs_d, total_d);
+        V_TRY(hipGetLastError());
+        V_TRY(hipMemcpy(&total, total_d, sizeof total, hipMemcpyDeviceToHost));
+    }
     if (total > 0) {
-        V_TRY(hipMemcpy(offs_d, ho.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
         V_TRY(hipMalloc(reinterpret_cast<void **>(&pts_d), (size_t)total * 48));
         nrm_d = pts_d + total * 3;
-        hipLaunchKernelGGL(shell_points_kernel, dim3(nchunks), block, 0, st, sd, gx, gy, gz, n, (int)ny,
-                           (int)nz, lo, hi, level_set_value, origin[0], origin[1], origin[2], voxel_size,
-                           offs_d, pts_d, nrm_d);
+        hipLaunchKernelGGL(shell_points_kernel, dim3(nlist[2] * 64u, nzseg), block, 0, st, sd, gx, gy, gz, v, lo, hi, level_set_value,
+                           origin[0], origin[1], origin[2], voxel_size, counts, offs_d, pts_d, nrm_d);
         V_TRY(hipGetLastError());
         *points_out = static_cast<double *>(malloc((size_t)total * 24));
         *normals_out = static_cast<double *>(malloc((size_t)total * 24));

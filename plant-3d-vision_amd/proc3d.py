@@ -86,15 +86,21 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
         raise nat.SpaceCarveError(f"sc_vol2pcd: {msg} (code {rc})")
     n = int(cnt[0])
     if n:
-        pts = np.ctypeslib.as_array((ctypes.c_double * (3 * n)).from_address(int(out[0]))).reshape(n, 3).copy()
-        nrm = np.ctypeslib.as_array((ctypes.c_double * (3 * n)).from_address(int(out[1]))).reshape(n, 3).copy()
-        b.call("sc_free_host", int(out[0]))
-        b.call("sc_free_host", int(out[1]))
+        # the library's buffers become the arrays (no copy); they are released with the last view
+        import weakref
+
+        def adopt(address):
+            owner = (ctypes.c_double * (3 * n)).from_address(address)
+            weakref.finalize(owner, b.call, "sc_free_host", address)
+            return np.frombuffer(owner, dtype=np.float64).reshape(n, 3)
+
+        pts, nrm = adopt(int(out[0])), adopt(int(out[1]))
     else:
         pts = np.zeros((0, 3))
         nrm = np.zeros((0, 3))
     ok = ~np.isnan(nrm).any(axis=1)  # proc3d.py:559-561: keep points with a positive gradient norm
-    pts, nrm = pts[ok], nrm[ok]
+    if not ok.all():
+        pts, nrm = pts[ok], nrm[ok]
     if as_open3d:
         try:
             import open3d as o3d  # type: ignore
