@@ -116,8 +116,8 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
             vol = eng.get_values()  # flushes and waits: `src` may go now
             del src
             if mode == nat.SC_MODE_AVERAGE and log:
-                vol = np.exp(vol)
-                vol[vol > 1] = 1.0
+                from .tasks.cl import _exp_clip
+                vol = _exp_clip(vol)  # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174), slab-wise on threads
             out[label] = vol
     finally:
         eng.close()
