@@ -15,9 +15,13 @@
 //     launch = the reference's schedule).  The carve update is order-independent, so
 //     dead lanes drop out and a wavefront leaves the view loop as soon as a ballot says
 //     every one of its voxels is carved.
-//   * A fused carve (many views) is dense only for its first two views; the few voxels
-//     still alive are then compacted into survivor lists (wave-aggregated atomics on 256
-//     sharded counters) and finished by a persistent kernel with one lane per survivor.
+//   * A fused carve (many views) first settles whole 16x64-voxel BRICKS from four corner
+//     projections each: bricks some view sees entirely over background are EMPTY (-1, filled
+//     by store blocks beside the final stage), bricks every view sees entirely over
+//     foreground are FULL (0 -> 1).  Only the remaining LIVE bricks are projected voxel by
+//     voxel, for two views; the voxels still alive are compacted into survivor lists
+//     (wave-aggregated atomics on 256 sharded counters) and finished by persistent kernels
+//     with one lane per survivor.
 //   * Carve masks live in HBM as 1 bit per pixel in 32x32-pixel tiles (one 128-byte line
 //     per tile): the 64..256 z-neighbours a wavefront projects land on a short image
 //     segment of arbitrary orientation, i.e. on a handful of lines, whatever the camera roll.
