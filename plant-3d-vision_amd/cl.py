@@ -243,29 +243,15 @@ class Backprojection(object):
         self._values_h = value
 
     def _start_prefault(self):
-        import threading
-        box = {}
-        shape, dtype = tuple(int(s) for s in self.shape), self.dtype
-
-        def work():
-            arr = np.empty(shape, dtype=dtype)
-            flat = arr.reshape(-1)
-            flat[:: max(1, 4096 // arr.itemsize)] = 0  # one write per page
-            box["array"] = arr
-
-        th = threading.Thread(target=work, name="spacecarve-prefault", daemon=True)
-        th.start()
-        self._prefault = (th, box)
+        self._prefault = nat.TouchedEmpty(tuple(int(s) for s in self.shape), self.dtype)
 
     def _take_buffer(self):
         """An array of the volume's shape whose pages are (normally) already touched."""
         shape = tuple(int(s) for s in self.shape)
         buf, self._spare = self._spare, None
         if buf is None and self._prefault is not None:
-            th, box = self._prefault
+            buf = self._prefault.result()
             self._prefault = None
-            th.join()
-            buf = box.get("array")
         if buf is None or buf.dtype != self.dtype or buf.shape != shape:
             buf = np.empty(shape, dtype=self.dtype)
         return buf

@@ -106,6 +106,9 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
                 raise ValueError("masks must be contiguous uint8 [n_img, Sy, Sx]")
             if q:
                 eng.clear()  # cl.py:252-253
+            # the label's host array: pages touched on host threads while the device works
+            dest = nat.TouchedEmpty(tuple(int(s) for s in shape),
+                                    np.float32 if mode == nat.SC_MODE_AVERAGE else np.int32)
             if mode == nat.SC_MODE_AVERAGE:
                 src = (255 - m) if invert else m
                 eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, nat.SC_MASK_U8_LUT)
@@ -113,7 +116,7 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
                 code = nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8
                 src = m
                 eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, code)
-            vol = eng.get_values()  # flushes and waits: `src` may go now
+            vol = eng.get_values(dest.result())  # flushes and waits: `src` may go now
             del src
             if mode == nat.SC_MODE_AVERAGE and log:
                 from .tasks.cl import _exp_clip
