@@ -684,7 +684,11 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
         if (!isfull || fill.fresh) {
             const int32_t val = isfull ? fill.kept : -1;
             if (vec) {
-                *reinterpret_cast<int4 *>(col + k0) = make_int4(val, val, val, val);
+                // streaming store: the fill is written once and not read again by this batch; kept
+                // out of the caches it does not evict the masks the next batch packs
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i vv = {val, val, val, val};
+                __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(col + k0));
             } else {
                 for (uint32_t e = 0; e < n; ++e) col[k0 + e] = val;
             }
