@@ -747,12 +747,19 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
     uint64_t grp = (uint64_t)lb * (kBlock * G) + threadIdx.x;
     Append none{nullptr, nullptr, 0u, 0u};
     int4 cur = make_int4(-1, -1, -1, -1);
-    if (G > 1 && grp < g.ngroups) cur = *reinterpret_cast<const int4 *>(labels + grp * 4);
+    // streaming loads: the state (512 MiB) is far bigger than the Infinity Cache, every view
+    // reads all of it once
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto stream_load = [&](uint64_t gidx) {
+        v4i q = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(labels + gidx * 4));
+        return make_int4(q.x, q.y, q.z, q.w);
+    };
+    if (G > 1 && grp < g.ngroups) cur = stream_load(grp);
 #pragma unroll 1
     for (int s = 0; s < G; ++s, grp += kBlock) {
         int4 nxt = make_int4(-1, -1, -1, -1);
         if (G > 1 && s + 1 < G && grp + kBlock < g.ngroups)
-            nxt = *reinterpret_cast<const int4 *>(labels + (grp + kBlock) * 4);
+            nxt = stream_load(grp + kBlock);
         if (grp < g.ngroups) carve_group<FRESH, VEC>(labels, g, &view, 1, init, grp, cur, none);
         cur = nxt;
     }
