@@ -1274,7 +1274,7 @@ struct sc_engine {
     int ctl_idx = 0;
     int64_t full_bricks = 1;      // bricks every view sees whole over foreground get their label without projections
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
-    int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
+    int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
     int64_t flag_views = 8;    // views that may veto a brick (0 = all of the batch)
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
