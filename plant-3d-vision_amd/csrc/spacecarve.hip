@@ -392,7 +392,10 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
         ez = fmaxf(ez, (fabsf(rzx) + fabsf(rzy) + fabsf(rzz) + fabsf(d.t[2])) * 0x1p-19f);
         ex = fmaxf(ex, (fabsf(rxx) + fabsf(rxy) + fabsf(rxz) + fabsf(d.t[0])) * 0x1p-19f);
         ey = fmaxf(ey, (fabsf(ryx) + fabsf(ryy) + fabsf(ryz) + fabsf(d.t[1])) * 0x1p-19f);
-        float qx = px / pz, qy = py / pz;
+        // an ESTIMATE of the voxel kernels' correctly rounded quotients is enough here (v_rcp_f32
+        // is good to 1 ulp, the product adds half of one); the slack below pays for it
+        float rz = __builtin_amdgcn_rcpf(pz);
+        float qx = px * rz, qy = py * rz;
         float u = qx * d.K[0] + d.K[2], v = qy * d.K[1] + d.K[3];
         // fminf/fmaxf drop NaN operands: track them explicitly
         nan |= __builtin_isunordered(u, v) | __builtin_isunordered(pz, pz);
@@ -403,10 +406,15 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     }
     if (nan) return 0u;
     bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
-    // pixel-space slack: 2 px + propagated dot-product error + relative slack of the final ops
+    // pixel-space slack: 2 px + propagated dot-product error + 8 ulp of the largest magnitude in
+    // q * f + c (quotient estimate above, the voxel kernels' own division, product and sum
+    // roundings -- relative to the OPERANDS, so that a principal point far outside the picture,
+    // where q * f and c cancel, cannot make the bound too small)
     float inv = 2.0f / pzmin;
-    float mu = 2.0f + fabsf(d.K[0]) * (ex + qxm * ez) * inv + fmaxf(fabsf(umin), fabsf(umax)) * 0x1p-20f;
-    float mv = 2.0f + fabsf(d.K[1]) * (ey + qym * ez) * inv + fmaxf(fabsf(vmin), fabsf(vmax)) * 0x1p-20f;
+    float mu = 2.0f + fabsf(d.K[0]) * (ex + qxm * ez) * inv +
+               (fabsf(d.K[0]) * qxm + fabsf(d.K[2]) + fmaxf(fabsf(umin), fabsf(umax))) * 0x1p-20f;
+    float mv = 2.0f + fabsf(d.K[1]) * (ey + qym * ez) * inv +
+               (fabsf(d.K[1]) * qym + fabsf(d.K[3]) + fmaxf(fabsf(vmin), fabsf(vmax))) * 0x1p-20f;
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
     // a NaN anywhere makes a comparison false -> no culling
     bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
