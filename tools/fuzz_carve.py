@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): random grid shapes, scenes, camera set-ups, default values
+and pipeline knobs; every volume must equal the oracle's, fresh and on a second batch.
+Usage: timeout -k 10 300 tools/fuzz_carve.py [cases] [seed]     (diagnostic, not part of the test suite;
+prints each case before it runs so that a fault can be traced to its parameters)"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from plant3dvision_amd import _native as nat, scenes
+from oracle import oracle_c
+
+KNOBS = {
+    "SC_OPT_FLAG_VIEWS": [0, 1, 3, 8, 11], "SC_OPT_DENSE_VIEWS": [1, 2, 3], "SC_OPT_STAGE1_VIEWS": [1, 4, 8, 64],
+    "SC_OPT_STAGE2_VIEWS": [0, 2], "SC_OPT_VIEW_GROUP": [1, 5, 16], "SC_OPT_LIST_BLOCKS": [8, 64, 2048],
+    "SC_OPT_DEFER_STORES": [0, 8, 1280], "SC_OPT_DEFER_SHARE": [0, 5, 16], "SC_OPT_FULL_BRICKS": [0, 1],
+    "SC_OPT_BRICK": [0, 1, 1, 1], "SC_OPT_COMPACT": [0, 1, 1, 1], "SC_OPT_VIEW_ORDER": [0, 1],
+    "SC_OPT_PACK_ROWS": [1, 2, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5],
+}
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    bad = 0
+    for c in range(cases):
+        shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
+        kind = str(rng.choice(["plant", "noise", "solid", "empty"]))
+        nviews = int(rng.integers(1, 16))
+        kw = dict(radius_factor=float(rng.choice([0.3, 0.8, 1.5, 3.0])), tilt_deg=float(rng.choice([0.0, 0.0, 25.0, 50.0])))
+        if rng.random() < 0.3:
+            w, h = int(rng.integers(20, 400)), int(rng.integers(20, 300))
+            kw.update(width=w, height=h, fx=float(rng.uniform(0.3, 3.0) * w), fy=float(rng.uniform(0.3, 3.0) * w),
+                      cx=float(rng.uniform(0.2, 0.8) * w), cy=float(rng.uniform(0.2, 0.8) * h))
+        sh, origin, vs, views = scenes.make_scene(shape, nviews, kind, **kw)
+        dv = int(rng.choice([0, 0, 0, 1, -1, 5]))
+        opts = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
+        print(f"case {c}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts}", flush=True)
+        want = oracle_c.carve(sh, origin, vs, views, dv, nthreads=4)
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=dv)
+        for k, v in opts.items():
+            e.set_option(getattr(nat, k), v)
+        device_masks = rng.random() < 0.5
+        stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+        K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+        ptr = e.dev_alloc(stack.nbytes); e.dev_upload(ptr, stack)
+        ok = True
+        for rnd in range(2):
+            if device_masks:
+                e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+            else:
+                for Kq, Rq, tq, m in views:
+                    e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+            got = e.get_values()
+            if not np.array_equal(got, want):
+                ok = False
+                print(f"MISMATCH case {c} round {rnd}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts} "
+                      f"device {device_masks}: {int((got != want).sum())} voxels differ")
+        e.dev_free(ptr); e.close()
+        bad += 0 if ok else 1
+    print(f"{cases} cases, {bad} with mismatches")
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main())
