@@ -151,8 +151,11 @@ def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=
     poses = ring_cameras(n_views, center, radius, tilt_deg=tilt_deg, fx=fx, fy=fy, cx=cx, cy=cy)
     masks = []
     if kind == "plant":
-        # lattice spacing ~1.5 px at the nearest depth
-        spacing = 1.5 * (radius - 0.75 * extent) / fx
+        # lattice spacing ~1.5 px at the nearest depth -- but never finer than extent / 800 (the
+        # default ring gives extent / 620): a ring close to or inside the volume would otherwise
+        # ask for a lattice of billions of points (or a negative spacing, i.e. none at all); its
+        # masks are then dotted rather than solid near the camera, which the parity tests do not mind
+        spacing = max(1.5 * (radius - 0.75 * extent) / fx, extent / 800.0)
         # stem radius 0.006 * extent = 3 voxels at 512^3; the scene is
         # scale-invariant in pixel space, so every n sees the same masks
         pts = phantom_points(extent, center, spacing, seed=1234 if seed is None else seed)

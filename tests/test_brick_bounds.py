@@ -1,0 +1,91 @@
+"""CPU check of the bound behind the fused carve's brick verdicts (csrc/spacecarve.hip,
+``brick_verdict``): the image of a brick's four corners, widened by the slack the kernel computes,
+must contain the float32 pixel coordinates the reference arithmetic (backprojection.c:3-34) gives
+EVERY voxel of the brick, and a brick judged in front of the camera must have every voxel in front.
+The kernel's test is restated here in NumPy float32, operation by operation; its quotient is an
+estimate (v_rcp_f32, 1 ulp, times the numerator), modelled as the exact quotient with the bound on
+that error taken OFF the slack."""
+import numpy as np
+import pytest
+
+from tests.helpers import scene
+
+F = np.float32
+BY, BZ = 16, 64
+
+
+def voxel_pixels(shape, origin, vs, K, R, t):
+    """float32 (p_z, u_f, v_f) of every voxel, the reference's operations in order."""
+    nx, ny, nz = shape
+    x = (F(origin[0]) + np.arange(nx, dtype=np.int32).astype(F) * F(vs)).astype(F)[:, None, None]
+    y = (F(origin[1]) + np.arange(ny, dtype=np.int32).astype(F) * F(vs)).astype(F)[None, :, None]
+    z = (F(origin[2]) + np.arange(nz, dtype=np.int32).astype(F) * F(vs)).astype(F)[None, None, :]
+    R = np.asarray(R, dtype=F).reshape(9); t = np.asarray(t, dtype=F).reshape(3); K = np.asarray(K, dtype=F).reshape(4)
+    row = lambda a, b, c, d: (((a * x) + (b * y)) + (c * z)) + d
+    with np.errstate(all="ignore"):
+        pz = row(R[6], R[7], R[8], t[2]); px = row(R[0], R[1], R[2], t[0]); py = row(R[3], R[4], R[5], t[1])
+        return pz, ((px / pz) * K[0]) + K[2], ((py / pz) * K[1]) + K[3]
+
+
+def brick_box(origin, vs, K, R, t, i, j0, k0):
+    """The kernel's bounding box of brick (plane i, columns j0.., voxels k0..): None if it gives up,
+    else (umin, umax, vmin, vmax) AFTER widening, with the estimate-error allowance removed."""
+    R = np.asarray(R, dtype=F).reshape(9); t = np.asarray(t, dtype=F).reshape(3); K = np.asarray(K, dtype=F).reshape(4)
+    x = F(F(origin[0]) + F(i) * F(vs))
+    ez = ex = ey = qxm = qym = F(0)
+    pzmin, umin, umax, vmin, vmax = F(np.inf), F(np.inf), F(-np.inf), F(np.inf), F(-np.inf)
+    with np.errstate(all="ignore"):
+        for c in range(4):
+            y = F(F(origin[1]) + F(j0 + (BY - 1 if c >> 1 else 0)) * F(vs))
+            z = F(F(origin[2]) + F(k0 + (BZ - 1 if c & 1 else 0)) * F(vs))
+            rzx, rzy, rzz = R[6] * x, R[7] * y, R[8] * z
+            rxx, rxy, rxz = R[0] * x, R[1] * y, R[2] * z
+            ryx, ryy, ryz = R[3] * x, R[4] * y, R[5] * z
+            pz = ((rzx + rzy) + rzz) + t[2]; px = ((rxx + rxy) + rxz) + t[0]; py = ((ryx + ryy) + ryz) + t[1]
+            ez = max(ez, (abs(rzx) + abs(rzy) + abs(rzz) + abs(t[2])) * F(2.0 ** -19))
+            ex = max(ex, (abs(rxx) + abs(rxy) + abs(rxz) + abs(t[0])) * F(2.0 ** -19))
+            ey = max(ey, (abs(ryx) + abs(ryy) + abs(ryz) + abs(t[1])) * F(2.0 ** -19))
+            qx, qy = px / pz, py / pz
+            u, v = qx * K[0] + K[2], qy * K[1] + K[3]
+            if np.isnan(u) or np.isnan(v) or np.isnan(pz):
+                return None
+            pzmin = min(pzmin, pz); qxm = max(qxm, abs(qx)); qym = max(qym, abs(qy))
+            umin, umax, vmin, vmax = min(umin, u), max(umax, u), min(vmin, v), max(vmax, v)
+        if not pzmin > F(4) * ez:
+            return None
+        inv = F(2) / pzmin
+        mu = F(2) + abs(K[0]) * (ex + qxm * ez) * inv + (abs(K[0]) * qxm + abs(K[2]) + max(abs(umin), abs(umax))) * F(2.0 ** -20)
+        mv = F(2) + abs(K[1]) * (ey + qym * ez) * inv + (abs(K[1]) * qym + abs(K[3]) + max(abs(vmin), abs(vmax))) * F(2.0 ** -20)
+        # the kernel's quotients are estimates: up to 1.5 ulp of q off, i.e. |K q| 2^-22 px, and the
+        # box it widens may be that much narrower than the one computed here
+        mu = mu - abs(K[0]) * qxm * F(2.0 ** -22)
+        mv = mv - abs(K[1]) * qym * F(2.0 ** -22)
+    return float(umin - mu), float(umax + mu), float(vmin - mv), float(vmax + mv)
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((3, 40, 150), dict(radius_factor=1.5)),
+    ((2, 33, 130), dict(radius_factor=0.35)),                     # cameras among the bricks
+    ((2, 48, 192), dict(radius_factor=0.8, tilt_deg=40.0)),
+    ((2, 32, 128), dict(radius_factor=3.0, width=2000, height=1500, fx=3000.0, fy=3000.0, cx=1000.0, cy=750.0)),
+    ((2, 20, 70), dict(radius_factor=1.0, width=200, height=90, fx=150.0, fy=150.0, cx=100.0, cy=45.0)),
+    ((2, 32, 64), dict(radius_factor=2.0, width=640, height=480, fx=900.0, fy=900.0, cx=4000.0, cy=-2500.0)),  # principal point far outside
+])
+def test_corner_box_with_slack_holds_every_voxel(shape, kw):
+    sh, origin, vs, views = scene(shape, 7, "plant", **kw)
+    checked = 0
+    for K, R, t, _ in views:
+        pz, uf, vf = voxel_pixels(sh, origin, vs, K, R, t)
+        for i in range(sh[0]):
+            for j0 in range(0, sh[1], BY):
+                for k0 in range(0, sh[2], BZ):
+                    box = brick_box(origin, vs, K, R, t, i, j0, k0)
+                    if box is None:
+                        continue
+                    sl = (i, slice(j0, min(sh[1], j0 + BY)), slice(k0, min(sh[2], k0 + BZ)))
+                    assert (pz[sl] > 0).all(), "a brick judged in front has a voxel behind"
+                    u, v = uf[sl], vf[sl]
+                    assert (u >= box[0]).all() and (u <= box[1]).all(), (i, j0, k0, box, float(u.min()), float(u.max()))
+                    assert (v >= box[2]).all() and (v <= box[3]).all(), (i, j0, k0, box, float(v.min()), float(v.max()))
+                    checked += 1
+    assert checked > 0
