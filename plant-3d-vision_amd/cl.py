@@ -82,6 +82,26 @@ def auto_format_bytes(size_bytes, unit="octets"):
         v /= base
 
 
+def _assign_slabs(dst, src, workers=None):
+    """``dst[...] = src`` (same shape, casting as NumPy does) slab by slab on a few threads: the
+    float64 stack of ``process_fileset`` (cl.py:249,254) is 1 GiB per label at 512^3, and the
+    single-threaded copy-with-cast costs more than the whole carve."""
+    if src.ndim == 0 or src.shape[0] < 2 or src.size < (1 << 22):
+        dst[...] = src
+        return
+    workers = workers or min(8, os.cpu_count() or 1)
+    n0 = src.shape[0]
+    bounds = [n0 * q // workers for q in range(workers + 1)]
+
+    def work(q):
+        a, b = bounds[q], bounds[q + 1]
+        if b > a:
+            dst[a:b] = src[a:b]
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(work, range(workers)))
+
+
 class Backprojection(object):
     """Back-projection onto a voxel volume (drop-in for ``plant3dvision.cl.Backprojection``).
 
@@ -274,7 +294,7 @@ class Backprojection(object):
                 logger.info(f"Processing label '{label}'...")
                 if i != 0:
                     self.clear()
-                result[i, :] = self.process_label(fs, camera_metadata, label, invert)
+                _assign_slabs(result[i], self.process_label(fs, camera_metadata, label, invert))  # result[i, :] = ...
             return result
         else:
             return self.process_label(fs, camera_metadata, None, invert=invert)
