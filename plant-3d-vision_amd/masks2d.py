@@ -120,7 +120,7 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
             del src
             if mode == nat.SC_MODE_AVERAGE and log:
                 from .tasks.cl import _exp_clip
-                vol = _exp_clip(vol)  # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174), slab-wise on threads
+                vol = _exp_clip(vol)  # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174)
             out[label] = vol
     finally:
         eng.close()

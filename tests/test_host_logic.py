@@ -128,11 +128,11 @@ def test_voxels_run_without_bounding_box_exits():
 
 def test_voxels_run_post_processing_helpers_match_numpy_expressions():
     """tasks/cl.py:168,172-174: `len(np.unique(vol)) == 1` and `np.exp(vol); vol[vol > 1] = 1`
-    are restated (no sort; slabs on threads) -- the results must be the same arrays."""
+    are restated (no sort; np.minimum instead of a boolean-mask store) -- the results must be the same arrays."""
     from plant3dvision_amd.tasks.cl import _exp_clip, _single_valued
     rng = np.random.default_rng(5)
     for dt in (np.float32, np.float64):
-        v = (rng.standard_normal((33, 200, 180)) * 3).astype(dt)  # > 2^20 elements: threaded path
+        v = (rng.standard_normal((33, 200, 180)) * 3).astype(dt)
         v[3, 4, 5] = np.nan
         v[1, 2, 3] = -np.inf
         v[0, 0, 1] = np.inf
