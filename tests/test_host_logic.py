@@ -147,3 +147,27 @@ def test_voxels_run_post_processing_helpers_match_numpy_expressions():
     for arr in (np.zeros((5, 5)), np.arange(9.0), np.full((3, 3), np.nan), np.array([np.nan, 1.0]),
                 np.array([1.0, np.nan]), np.zeros(10000, dtype=np.int32), last, np.full((2, 2), -1, dtype=np.int32)):
         assert _single_valued(arr) == (len(np.unique(arr)) == 1), arr
+
+
+def test_touched_empty_is_a_plain_array_with_resident_pages():
+    """``_native.TouchedEmpty``: the read-back buffers whose pages are touched on host threads."""
+    from plant3dvision_amd._native import TouchedEmpty
+    for shape, dt in (((3, 5, 7), np.int32), ((64, 64, 300), np.float32), ((0, 4), np.int32)):
+        arr = TouchedEmpty(shape, dt, threads=3).result()
+        assert arr.shape == shape and arr.dtype == dt and arr.flags["C_CONTIGUOUS"] and arr.flags["WRITEABLE"]
+        arr[...] = 7
+        assert (arr == 7).all()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("radius_factor", [0.3, 0.76, 0.8, 1.0, 2.0])
+def test_synthetic_scene_stays_small_for_any_camera_ring(radius_factor):
+    """The plant phantom is sampled on a lattice whose spacing follows the nearest camera depth; a
+    ring just outside 0.75 x the extent once asked for ~10^10 points (host memory of the GPU box)."""
+    import resource
+    from plant3dvision_amd import scenes
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    shape, origin, vs, views = scenes.make_scene((8, 24, 40), 3, "plant", radius_factor=radius_factor)
+    assert len(views) == 3 and views[0][3].dtype == np.uint8
+    grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
+    assert grown_mb < 1500, grown_mb
