@@ -80,7 +80,7 @@ constexpr int kBlock = 256;
 constexpr int kTile = 32;        // mask tile edge in pixels (32 rows x 32 bits = 128 B)
 constexpr int kSub = 256;        // sharded append counters = sub-lists of a survivor list
 constexpr int kStreamGroups = 2; // 16-byte groups per lane in the per-view streaming kernel
-                                 // (measured: 1 -> 0.0882, 2 -> 0.0863, 3 -> 0.0905, 4 -> 0.0932 ms)
+                                 // (measured with streaming loads: 2 -> 0.0803, 3 -> 0.0811, 4 -> 0.0860 ms)
 constexpr int kXcdRun = 16;      // consecutive logical blocks kept on one XCD
 
 // Survivor lists of the fused carve (see carve_list_kernel).  Zeroed before every fused launch.
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
         v4i q = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(labels + gidx * 4));
         return make_int4(q.x, q.y, q.z, q.w);
     };
-    if (G > 1 && grp < g.ngroups) cur = stream_load(grp);
+    if (!FRESH && VEC && grp < g.ngroups) cur = stream_load(grp);  // carve_group takes the stored labels from `cur`
 #pragma unroll 1
     for (int s = 0; s < G; ++s, grp += kBlock) {
         int4 nxt = make_int4(-1, -1, -1, -1);
