@@ -89,6 +89,8 @@ extern "C" {
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
 #define SC_OPT_FULL_BRICKS 19     /* 1 (default): a brick EVERY view of the batch sees whole, in-image, over
                                      foreground only gets its labels (0 -> 1) without projecting a voxel */
+#define SC_OPT_AVG_BRICK 20       /* averaging with uint8 masks + table. 1 (default): bricks whose footprint in a
+                                     view is all 0 or all 255 add table[0] / table[255] without projecting */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

@@ -30,7 +30,7 @@ SC_OPT_VIEW_GROUP, SC_OPT_BRICK, SC_OPT_FLAG_VIEWS, SC_OPT_STAGE2_VIEWS = 9, 10,
 SC_KERNEL_CARVE, SC_KERNEL_AVERAGE, SC_KERNEL_PACK, SC_KERNEL_FILL, SC_KERNEL_LIST = 0, 1, 2, 3, 4
 SC_KERNEL_FLAGS, SC_KERNEL_STEP = 5, 6
 SC_OPT_PACK_ROWS, SC_OPT_DEFER_STORES, SC_OPT_DEFER_SHARE = 13, 14, 15
-SC_OPT_FULL_BRICKS = 19
+SC_OPT_FULL_BRICKS, SC_OPT_AVG_BRICK = 19, 20
 
 # name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
 _SIGNATURES = {

@@ -374,7 +374,7 @@ constexpr int kBrickY = 16, kBrickZ = 64;
 // corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
 // corners hold for every voxel of the brick.
 __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
-                                                  int k0) {
+                                                  int k0, int occ_tx) {
     float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
     float pzmin = INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
@@ -424,7 +424,7 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     uint32_t any = 0, all = 3;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
-            uint32_t o = d.occ[ty * d.tiles_x + tx];
+            uint32_t o = d.occ[ty * occ_tx + tx];
             any |= o;
             all &= o;
         }
@@ -473,14 +473,14 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     if (valid) {
         if (views == nullptr) {  // grid-uniform: nviews <= kFlagWaves, one view per wavefront
             if ((int)wave < nviews) {
-                const uint32_t v = brick_verdict(own.v[wave], g, x, j0, k0);
+                const uint32_t v = brick_verdict(own.v[wave], g, x, j0, k0, own.v[wave].tiles_x);
                 empty = v == 1u;
                 full = v == 2u;
             }
         } else {
             for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
                 const ViewDesc d = views[vi];
-                const uint32_t v = brick_verdict(d, g, x, j0, k0);
+                const uint32_t v = brick_verdict(d, g, x, j0, k0, d.tiles_x);
                 empty |= v == 1u;
                 full &= v == 2u;
             }
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
         bool e2 = false, f2 = true;
         if (vi < nall && ((cand >> lane) & 1ull)) {
             const ViewDesc d = allviews[vi];
-            const uint32_t v = brick_verdict(d, g, x, j0, k0);
+            const uint32_t v = brick_verdict(d, g, x, j0, k0, d.tiles_x);
             e2 = v == 1u;
             f2 = v == 2u;
         }
@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ v
 __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict__ raw,
                                                        int64_t row_stride, int64_t view_stride, int W,
                                                        int H, int nviews, int tiles_x, int tiles_y,
-                                                       uint8_t *__restrict__ out, int fast) {
+                                                       uint8_t *__restrict__ out, int fast,
+                                                       uint8_t *__restrict__ uni) {
     int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int chunks = (W + 15) >> 4;
     int64_t total = (int64_t)nviews * H * chunks;
@@ -1054,10 +1055,127 @@ __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict
     const uint8_t *src = raw + view * view_stride + (int64_t)v * row_stride + c * 16;
     uint8_t *dst = out + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
     if (fast) {
-        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+        const uint4 q = *reinterpret_cast<const uint4 *>(src);
+        *reinterpret_cast<uint4 *>(dst) = q;
+        if (uni != nullptr) {
+            // one byte per 32x32-pixel tile (host-initialised to 2): bit 0 = some byte is not 0,
+            // bit 1 = every byte is 255 -- what brick_verdict reads as "some / only foreground"
+            // (average_brick_kernel).  Bits only ever move one way; the byte is looked at first so
+            // that most lanes find nothing left to change.
+            const bool anynz = (q.x | q.y | q.z | q.w) != 0u;
+            const bool all255 = (q.x & q.y & q.z & q.w) == 0xffffffffu;
+            const int otx = (W + 31) >> 5, oty = (H + 31) >> 5;
+            const int64_t tile = (int64_t)view * otx * oty + (int64_t)(v >> 5) * otx + (c >> 1);
+            uint32_t *word = reinterpret_cast<uint32_t *>(uni) + (tile >> 2);
+            const uint32_t sh = (uint32_t)(tile & 3) * 8u;
+            const uint32_t cur = __atomic_load_n(word, __ATOMIC_RELAXED) >> sh;
+            if (anynz && !(cur & 1u)) atomicOr(word, 1u << sh);
+            if (!all255 && (cur & 2u)) atomicAnd(word, ~(2u << sh));
+        }
     } else {
         int n = min(16, W - c * 16);
         for (int k = 0; k < n; ++k) dst[k] = src[k];
+    }
+}
+
+// ---- brick form of the averaging kernel (uint8 masks + table) ---------------------------------
+// Masks out of a segmentation are mostly flat: background 0, foreground 255.  Where a brick's
+// footprint in a view (same conservative box as the carve's brick_verdict) lies over tiles of
+// nothing but 0, every voxel of the brick is in-image and adds table[0] for that view; over tiles of
+// nothing but 255, table[255]: the same float32 addition the reference performs
+// (backprojection.c:54), in the same view order, without projecting anything.  Only views whose
+// footprint is mixed are projected voxel by voxel.
+__global__ __launch_bounds__(kBlock) void avg_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
+                                                           int nviews, uint32_t bricks_y, uint32_t bricks_z,
+                                                           uint32_t nbricks, uint8_t *__restrict__ verd) {
+    const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t vi = blockIdx.y;  // block-uniform view: scalar descriptor
+    if (lb >= nbricks) return;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    const ViewDesc d = views[vi];
+    verd[(size_t)lb * (uint32_t)nviews + vi] =
+        (uint8_t)brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), (d.W + 31) >> 5);
+}
+
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict__ values, GridDesc g,
+                                                               const ViewDesc *__restrict__ views, int nviews,
+                                                               float init, const float *__restrict__ lut,
+                                                               uint32_t bricks_y, uint32_t bricks_z,
+                                                               const uint8_t *__restrict__ verd) {
+    __shared__ float lut_s[256];
+    lut_s[threadIdx.x] = lut[threadIdx.x];  // kBlock == 256
+    __syncthreads();
+    const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const bool vec = (g.nz & 3u) == 0;
+    float *p = values + ((uint64_t)il * g.ny + j) * g.nz + k0;
+    float val[4] = {init, init, init, init};
+    if (!FRESH) {
+        if (vec) {
+            if (inside) {
+                float4 q = *reinterpret_cast<const float4 *>(p);
+                val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nvalid) val[e] = p[e];
+        }
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;
+    const float add0 = lut_s[0], add255 = lut_s[255];
+    const uint8_t *myverd = verd + (size_t)lb * (uint32_t)nviews;
+    for (int v0 = 0; v0 < nviews; v0 += 64) {
+        // the verdicts of up to 64 views, one per lane, handed out with v_readlane
+        const int nv = min(64, nviews - v0);
+        const uint32_t mine = ((int)lane < nv) ? myverd[v0 + (int)lane] : 0u;
+        for (int q = 0; q < nv; ++q) {
+            const uint32_t c = __builtin_amdgcn_readlane(mine, q);  // wave-uniform (brick-uniform)
+            if (c != 0u) {
+                const float add = c == 1u ? add0 : add255;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = val[e] + add;  // :54, every voxel is in-image
+                continue;
+            }
+            const ViewDesc d = views[v0 + q];
+            const float ax = d.R[0] * x + d.R[1] * y, ay = d.R[3] * x + d.R[4] * y, az = d.R[6] * x + d.R[7] * y;
+            const uint8_t *m = static_cast<const uint8_t *>(d.mask);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                const bool ok = project(ax, ay, az, z[e], d, u, v);
+                const uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
+                                     (uint32_t)((v & 7) * 16 + (u & 15));
+                uint32_t b = 0;
+                if (ok) b = m[off];
+                const float add = lut_s[b];
+                if (ok) val[e] = val[e] + add;  // :54
+            }
+        }
+    }
+    if (vec) {
+        if (inside) *reinterpret_cast<float4 *>(p) = make_float4(val[0], val[1], val[2], val[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) p[e] = val[e];
     }
 }
 
@@ -1281,6 +1399,9 @@ struct sc_engine {
     bool ctl_clean[2] = {false, false};     // known to be all zero
     int ctl_idx = 0;
     int64_t full_bricks = 1;      // bricks every view sees whole over foreground get their label without projections
+    int64_t avg_brick = 1;        // averaging, uint8 + table: brick form with uniform-footprint verdicts
+    uint8_t *verd = nullptr;      // ... its [bricks][views] verdicts
+    size_t verd_cap = 0;
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
@@ -1595,18 +1716,30 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
     int64_t total = (int64_t)V * H * ((W + 15) / 16);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+    // per 32x32-pixel tile: is it all 0 / all 255?  (brick form of the averaging kernel)
+    const size_t uni_per_view = (size_t)((W + 31) / 32) * (size_t)((H + 31) / 32);
+    uint8_t *uni = nullptr;
+    if (fast && e->avg_brick) {
+        void *u = nullptr;
+        size_t bytes = (uni_per_view * (size_t)V + 3) & ~(size_t)3;
+        rc = arena_alloc(e, bytes, &u);
+        if (rc) return rc;
+        uni = static_cast<uint8_t *>(u);
+        HIP_TRY(hipMemsetAsync(uni, 0x02, bytes, e->stream));
+    }
     LaunchTimer lt{e, SC_KERNEL_PACK};
     rc = lt.begin();
     if (rc) return rc;
     hipLaunchKernelGGL(tile8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
                        static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V, tiles_x,
-                       tiles_y, static_cast<uint8_t *>(tiled), fast);
+                       tiles_y, static_cast<uint8_t *>(tiled), fast, uni);
     HIP_TRY(hipGetLastError());
     rc = lt.end();
     if (rc) return rc;
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
-        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W);
+        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W,
+                  uni ? uni + (size_t)q * uni_per_view : nullptr);
         d.tiles_x = tiles_x;
         d.pad = 1;
         e->pending.push_back(d);
@@ -1885,6 +2018,48 @@ int flush(sc_engine *e, size_t count = 0) {
         float *st = static_cast<float *>(e->state);
         rc = upload_desc();
         if (rc) return rc;
+        // brick form: uint8 masks with uniformity flags on every view of the batch, a table, a grid it fits
+        const uint32_t abys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), abzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
+        bool abrick = nv > 1 && e->avg_brick && e->lut_dev != nullptr && (uint64_t)e->n < 0x80000000ull &&
+                      (uint64_t)e->planes * abys * abzs < 0x80000000ull;
+        for (size_t q = 0; q < nv && abrick; ++q) abrick = e->pending[q].pad == 1 && e->pending[q].occ != nullptr;
+        if (abrick) {
+            const uint32_t anb = (uint32_t)((uint64_t)e->planes * abys * abzs);
+            const size_t need = (size_t)anb * nv;
+            if (need > e->verd_cap) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (e->verd) (void)hipFree(e->verd);
+                e->verd = nullptr;
+                e->verd_cap = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->verd), need));
+                e->verd_cap = need;
+            }
+            LaunchTimer ltf{e, SC_KERNEL_FLAGS};
+            rc = ltf.begin();
+            if (rc) return rc;
+            hipLaunchKernelGGL(avg_flags_kernel, dim3((anb + kBlock - 1) / kBlock, (uint32_t)nv), block, 0, e->stream,
+                               g, vd, (int)nv, abys, abzs, anb, e->verd);
+            rc = ltf.end();
+            if (rc) return rc;
+            LaunchTimer lta{e, SC_KERNEL_AVERAGE};
+            rc = lta.begin();
+            if (rc) return rc;
+            if (e->fresh)
+                hipLaunchKernelGGL(average_brick_kernel<true>, dim3(anb), block, 0, e->stream, st, g, vd, (int)nv,
+                                   e->default_value, e->lut_dev, abys, abzs, e->verd);
+            else
+                hipLaunchKernelGGL(average_brick_kernel<false>, dim3(anb), block, 0, e->stream, st, g, vd, (int)nv,
+                                   e->default_value, e->lut_dev, abys, abzs, e->verd);
+            HIP_TRY(hipGetLastError());
+            rc = lta.end();
+            if (rc) return rc;
+            rc = step_end(e, nv > 1);
+            if (rc) return rc;
+            e->fresh = false;
+            e->pending.erase(e->pending.begin(), e->pending.begin() + (ptrdiff_t)nv);
+            if (e->pending.empty()) arena_reset(e);
+            return SC_OK;
+        }
         LaunchTimer lt{e, SC_KERNEL_AVERAGE};
         rc = lt.begin();
         if (rc) return rc;
@@ -2051,6 +2226,7 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->verd) (void)hipFree(e->verd);
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
@@ -2107,6 +2283,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_FULL_BRICKS:
             e->full_bricks = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_AVG_BRICK:
+            e->avg_brick = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_DEFER_SHARE:
             if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "defer_share must be in [0, 16]");

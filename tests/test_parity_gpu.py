@@ -450,6 +450,48 @@ def test_average_uint8_masks_table_path(gpu_device, w, h, log):
         bp.close()
 
 
+@pytest.mark.parametrize("shape,kw", [
+    ((6, 32, 128), dict()),
+    ((5, 37, 131), dict(radius_factor=1.2)),                                     # bricks stick out; nz % 4 != 0
+    ((4, 16, 64), dict(radius_factor=0.4)),                                      # cameras among the bricks
+    ((3, 48, 64), dict(width=208, height=96, fx=150.0, fy=150.0, cx=100.0, cy=45.0)),
+])
+@pytest.mark.parametrize("log", [False, True])
+@pytest.mark.parametrize("kind", ["plant", "solid", "empty", "grey"])
+def test_average_brick_form_on_flat_masks(gpu_device, shape, kw, log, kind):
+    """Averaging with uint8 masks + table works on bricks: where a brick's footprint in a view is
+    all 0 (or all 255) every voxel adds table[0] (table[255]) without being projected.  Binary
+    masks (what Segmentation2D writes), constant masks, and grey ones (nothing is flat) must all
+    equal the oracle bit for bit, with the brick form on and off, on a fresh volume and on a
+    second batch accumulated over the stored one, through host and device masks."""
+    sh, origin, vs, views = scene(shape, 7, "plant" if kind == "grey" else kind, **kw)
+    if kind == "grey":
+        rng = np.random.default_rng(11)
+        views = [(K, R, t, rng.integers(0, 256, m.shape, dtype=np.uint8)) for K, R, t, m in views]
+    conv = (lambda m: np.log(EPS + img_as_float32(m))) if log else img_as_float32
+    with np.errstate(divide="ignore"):
+        fviews = [(K, R, t, conv(m)) for K, R, t, m in views]
+        want1 = oracle_c.average(sh, origin, vs, fviews)
+        want2 = oracle_c.average(sh, origin, vs, fviews + fviews)
+        lut = conv(np.arange(256, dtype=np.uint8))
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    V, H, W = stack.shape
+    for brick in (1, 0):
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_AVERAGE)
+        e.set_option(nat.SC_OPT_AVG_BRICK, brick)
+        e.set_lut(lut)
+        ptr = e.dev_alloc(stack.nbytes)
+        e.dev_upload(ptr, stack)
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8_LUT)
+        assert np.array_equal(e.get_values().view(np.uint32), want1.view(np.uint32)), (brick, "fresh")
+        for Kq, Rq, tq, m in views:  # second batch, host masks, on the stored sums
+            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8_LUT)
+        assert np.array_equal(e.get_values().view(np.uint32), want2.view(np.uint32)), (brick, "stored")
+        e.dev_free(ptr)
+        e.close()
+
+
 def test_average_mixed_uint8_and_float_views(gpu_device):
     shape, origin, vs, views = scene(18, 6, "noise", width=64, height=48, fx=50.0, fy=50.0, cx=32.0, cy=24.0)
     rng = np.random.default_rng(4)
