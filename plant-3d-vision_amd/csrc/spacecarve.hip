@@ -1042,8 +1042,7 @@ __global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ v
 __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict__ raw,
                                                        int64_t row_stride, int64_t view_stride, int W,
                                                        int H, int nviews, int tiles_x, int tiles_y,
-                                                       uint8_t *__restrict__ out, int fast,
-                                                       uint8_t *__restrict__ uni) {
+                                                       uint8_t *__restrict__ out, int fast) {
     int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int chunks = (W + 15) >> 4;
     int64_t total = (int64_t)nviews * H * chunks;
@@ -1055,27 +1054,36 @@ __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict
     const uint8_t *src = raw + view * view_stride + (int64_t)v * row_stride + c * 16;
     uint8_t *dst = out + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
     if (fast) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(src);
-        *reinterpret_cast<uint4 *>(dst) = q;
-        if (uni != nullptr) {
-            // one byte per 32x32-pixel tile (host-initialised to 2): bit 0 = some byte is not 0,
-            // bit 1 = every byte is 255 -- what brick_verdict reads as "some / only foreground"
-            // (average_brick_kernel).  Bits only ever move one way; the byte is looked at first so
-            // that most lanes find nothing left to change.
-            const bool anynz = (q.x | q.y | q.z | q.w) != 0u;
-            const bool all255 = (q.x & q.y & q.z & q.w) == 0xffffffffu;
-            const int otx = (W + 31) >> 5, oty = (H + 31) >> 5;
-            const int64_t tile = (int64_t)view * otx * oty + (int64_t)(v >> 5) * otx + (c >> 1);
-            uint32_t *word = reinterpret_cast<uint32_t *>(uni) + (tile >> 2);
-            const uint32_t sh = (uint32_t)(tile & 3) * 8u;
-            const uint32_t cur = __atomic_load_n(word, __ATOMIC_RELAXED) >> sh;
-            if (anynz && !(cur & 1u)) atomicOr(word, 1u << sh);
-            if (!all255 && (cur & 2u)) atomicAnd(word, ~(2u << sh));
-        }
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
     } else {
         int n = min(16, W - c * 16);
         for (int k = 0; k < n; ++k) dst[k] = src[k];
     }
+}
+
+// One byte per 32x32-pixel tile of a 16x8-tiled uint8 mask (W % 16 == 0): bit 0 = some byte is not
+// 0, bit 1 = every byte is 255 -- what brick_verdict reads as "some / only foreground"
+// (average_brick_kernel).  One wavefront per tile: lane l takes the 16 pixels (row l >> 1, half
+// l & 1); pixels beyond the picture do not count.  (Setting the flags from the tiling kernel
+// itself, with atomics on the shared bytes, cost 1 ms per 72 masks.)
+__global__ __launch_bounds__(kBlock) void uniform_tiles_kernel(const uint8_t *__restrict__ tiled, int W, int H,
+                                                               int nviews, int tiles_x, int tiles_y,
+                                                               uint8_t *__restrict__ uni) {
+    const int otx = (W + 31) >> 5, oty = (H + 31) >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (tile >= (int64_t)nviews * otx * oty) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int tx = (int)(tile % otx), ty = (int)((tile / otx) % oty), view = (int)(tile / ((int64_t)otx * oty));
+    const int v = ty * 32 + (lane >> 1), c = tx * 2 + (lane & 1);
+    bool nz = false, hole = false;
+    if (v < H && c * 16 < W) {
+        const uint8_t *src = tiled + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
+        const uint4 q = *reinterpret_cast<const uint4 *>(src);
+        nz = (q.x | q.y | q.z | q.w) != 0u;
+        hole = (q.x & q.y & q.z & q.w) != 0xffffffffu;
+    }
+    const unsigned long long anynz = __ballot(nz), anyhole = __ballot(hole);
+    if (lane == 0) uni[tile] = (uint8_t)((anynz ? 1u : 0u) | (anyhole ? 0u : 2u));
 }
 
 // ---- brick form of the averaging kernel (uint8 masks + table) ---------------------------------
@@ -1725,14 +1733,18 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
         rc = arena_alloc(e, bytes, &u);
         if (rc) return rc;
         uni = static_cast<uint8_t *>(u);
-        HIP_TRY(hipMemsetAsync(uni, 0x02, bytes, e->stream));
     }
     LaunchTimer lt{e, SC_KERNEL_PACK};
     rc = lt.begin();
     if (rc) return rc;
     hipLaunchKernelGGL(tile8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
                        static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V, tiles_x,
-                       tiles_y, static_cast<uint8_t *>(tiled), fast, uni);
+                       tiles_y, static_cast<uint8_t *>(tiled), fast);
+    if (uni) {
+        int64_t ntiles = (int64_t)V * (int64_t)uni_per_view;
+        hipLaunchKernelGGL(uniform_tiles_kernel, dim3((uint32_t)((ntiles + 3) / 4)), dim3(kBlock), 0, e->stream,
+                           static_cast<const uint8_t *>(tiled), W, H, V, tiles_x, tiles_y, uni);
+    }
     HIP_TRY(hipGetLastError());
     rc = lt.end();
     if (rc) return rc;
