@@ -653,6 +653,32 @@ def test_cyclic_planes_interleave_to_the_whole_grid(gpu_device, world):
         assert np.array_equal(got, want), (world, vpl)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_average_on_cyclic_planes_and_slabs(gpu_device, world):
+    """The averaging kernels (brick form included) on a rank's planes use GLOBAL x indices too."""
+    shape, origin, vs, views = scene((13, 32, 70), 6, "plant")
+    lut = img_as_float32(np.arange(256, dtype=np.uint8))
+    want = oracle_c.average(shape, origin, vs, [(K, R, t, img_as_float32(m)) for K, R, t, m in views])
+    got_c = np.empty(shape, dtype=np.float32)
+    parts = []
+    for r in range(world):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, cyclic=(r, world))
+        e.set_lut(lut)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8_LUT)
+        got_c[r::world] = e.get_values()
+        e.close()
+        i0, i1 = shape[0] * r // world, shape[0] * (r + 1) // world
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, slab=(i0, i1))
+        e.set_lut(lut)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8_LUT)
+        parts.append(e.get_values())
+        e.close()
+    assert np.array_equal(got_c.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.concatenate(parts, axis=0).view(np.uint32), want.view(np.uint32))
+
+
 def test_full_size_512_cubed_72_views_properties(gpu_device):
     """BASELINE cfg 3 at full size: the oracle would take minutes, so check properties the
     domain offers: fused == per-view schedule == permuted order (order independence),
