@@ -488,6 +488,10 @@ def test_average_brick_form_on_flat_masks(gpu_device, shape, kw, log, kind):
         for Kq, Rq, tq, m in views:  # second batch, host masks, on the stored sums
             e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8_LUT)
         assert np.array_equal(e.get_values().view(np.uint32), want2.view(np.uint32)), (brick, "stored")
+        e.clear()
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 3)  # batches of 3 views (the last one shorter), in order
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8_LUT)
+        assert np.array_equal(e.get_values().view(np.uint32), want1.view(np.uint32)), (brick, "batches of 3")
         e.dev_free(ptr)
         e.close()
 
