@@ -91,6 +91,8 @@ extern "C" {
                                      foreground only gets its labels (0 -> 1) without projecting a voxel */
 #define SC_OPT_AVG_BRICK 20       /* averaging with uint8 masks + table. 1 (default): bricks whose footprint in a
                                      view is all 0 or all 255 add table[0] / table[255] without projecting */
+#define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
+#define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

@@ -31,6 +31,7 @@ SC_KERNEL_CARVE, SC_KERNEL_AVERAGE, SC_KERNEL_PACK, SC_KERNEL_FILL, SC_KERNEL_LI
 SC_KERNEL_FLAGS, SC_KERNEL_STEP = 5, 6
 SC_OPT_PACK_ROWS, SC_OPT_DEFER_STORES, SC_OPT_DEFER_SHARE = 13, 14, 15
 SC_OPT_FULL_BRICKS, SC_OPT_AVG_BRICK = 19, 20
+SC_OPT_STAGE1_STORE_SHARE, SC_OPT_STAGE1_LIST_BLOCKS = 17, 21
 
 # name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
 _SIGNATURES = {

@@ -799,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
     // blocks: this stage is bound by projection arithmetic and the -1 fill of the bricks the flags
     // kernel found empty by HBM writes, so the two run side by side instead of one after the
     // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
-    const bool split = FINAL && cs.flags != nullptr;
+    const bool split = cs.flags != nullptr;
     const uint32_t nbid = split ? gridDim.x - (cs.nstrips - cs.first) : gridDim.x;
     if (split && blockIdx.x >= nbid) {
         store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z,
@@ -1410,6 +1410,8 @@ struct sc_engine {
     int64_t avg_brick = 1;        // averaging, uint8 + table: brick form with uniform-footprint verdicts
     uint8_t *verd = nullptr;      // ... its [bricks][views] verdicts
     size_t verd_cap = 0;
+    int64_t stage1_store_share = 4;  // sixteenths of the deferred strips filled beside the FIRST list stage
+    int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
@@ -1990,10 +1992,18 @@ int flush(sc_engine *e, size_t count = 0) {
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
             dim3 fgrid(list_blocks);
+            CullStores cs1 = none;
+            dim3 grid1(list_blocks);
             if (defer_stores) {
-                cs = CullStores{e->flags, bys, bzs, nstrips, dense_store_strips, init == 0 ? 1 : init,
-                                e->fresh ? 1 : 0};
-                fgrid = dim3((uint32_t)e->defer_stores + (nstrips - dense_store_strips));
+                // the first list stage may take a share of the fill as well (it waits on memory)
+                uint32_t mid = dense_store_strips;
+                if ((size_t)s1 < nv && e->stage1_store_share > 0) {
+                    mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
+                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0};
+                    grid1 = dim3((uint32_t)e->stage1_list_blocks + (mid - dense_store_strips));
+                }
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0};
+                fgrid = dim3((uint32_t)e->defer_stores + (nstrips - mid));
             }
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
             int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
@@ -2002,8 +2012,8 @@ int flush(sc_engine *e, size_t count = 0) {
                 hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream, st,
                                    g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs);
             } else {
-                hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, none);
+                hipLaunchKernelGGL(carve_list_kernel<false>, grid1, block, 0, e->stream, st,
+                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1);
                 if (s2 > s1 && (size_t)s2 < nv) {
                     hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream,
                                        st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none);
@@ -2298,6 +2308,14 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_AVG_BRICK:
             e->avg_brick = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_STAGE1_STORE_SHARE:
+            if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "stage1_store_share must be in [0, 16]");
+            e->stage1_store_share = value;
+            return SC_OK;
+        case SC_OPT_STAGE1_LIST_BLOCKS:
+            if (value < 1 || value > 65536) return fail(SC_ERR_INVALID, "stage1_list_blocks must be in [1, 65536]");
+            e->stage1_list_blocks = value;
             return SC_OK;
         case SC_OPT_DEFER_SHARE:
             if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "defer_share must be in [0, 16]");

@@ -158,6 +158,9 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_STAGE1_VIEWS": 2, "SC_OPT_STAGE2_VIEWS": 3, "SC_OPT_VIEW_GROUP": 2},
     {"SC_OPT_VIEW_GROUP": 5, "SC_OPT_PACK_ROWS": 1},
     {"SC_OPT_FULL_BRICKS": 0},
+    {"SC_OPT_STAGE1_STORE_SHARE": 0},                                     # the final stage fills everything
+    {"SC_OPT_STAGE1_STORE_SHARE": 16, "SC_OPT_STAGE1_LIST_BLOCKS": 8},    # ... the first stage does
+    {"SC_OPT_STAGE1_STORE_SHARE": 9, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_DEFER_STORES": 40},  # all three kernels fill
     {"SC_OPT_COMPACT": 0},                                                # bricks without survivor lists
     {"SC_OPT_VIEW_ORDER": 0},
 ])
