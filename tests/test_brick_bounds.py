@@ -89,3 +89,50 @@ def test_corner_box_with_slack_holds_every_voxel(shape, kw):
                     assert (v >= box[2]).all() and (v <= box[3]).all(), (i, j0, k0, box, float(v.min()), float(v.max()))
                     checked += 1
     assert checked > 0
+
+
+def _random_pose(rng, center, extent):
+    """A camera somewhere around (or inside) the volume, looking roughly at it, random roll."""
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    dist = extent * rng.choice([0.2, 0.6, 1.0, 2.5, 8.0])
+    C = np.asarray(center) + d * dist
+    aim = np.asarray(center) + rng.normal(size=3) * extent * rng.choice([0.0, 0.2, 0.6])
+    fwd = aim - C; fwd /= np.linalg.norm(fwd)
+    up = rng.normal(size=3); up -= fwd * (up @ fwd); up /= np.linalg.norm(up)
+    right = np.cross(up, fwd)
+    R = np.stack([right, np.cross(fwd, right), fwd])
+    return R.reshape(9).astype(F), (-R @ C).astype(F)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_corner_box_random_cameras(seed):
+    """Random poses (far, near, inside the grid; any roll), focal lengths from fisheye-wide to
+    telephoto, principal points in and far out of the picture: whenever the kernel's test accepts a
+    brick's box, every voxel of the brick must be in front and project inside it."""
+    rng = np.random.default_rng(1000 + seed)
+    shape = (2, int(rng.integers(5, 40)), int(rng.integers(10, 150)))
+    vs = float(rng.choice([0.25, 1.0, 3.0]))
+    origin = (rng.normal(size=3) * 50.0).astype(F)
+    extent = max(shape) * vs
+    center = origin + np.array(shape) * vs / 2.0
+    accepted = 0
+    for _ in range(10):
+        R, t = _random_pose(rng, center, extent)
+        w, h = int(rng.integers(40, 2000)), int(rng.integers(40, 1500))
+        f = float(w * rng.choice([0.2, 0.8, 2.0, 10.0]))
+        cx = float(w * rng.choice([0.5, 0.3, -2.0, 6.0])); cy = float(h * rng.choice([0.5, 0.7, 4.0]))
+        K = np.array([f, f * rng.uniform(0.8, 1.25), cx, cy], dtype=F)
+        pz, uf, vf = voxel_pixels(shape, origin, vs, K, R, t)
+        for i in range(shape[0]):
+            for j0 in range(0, shape[1], BY):
+                for k0 in range(0, shape[2], BZ):
+                    box = brick_box(origin, vs, K, R, t, i, j0, k0)
+                    if box is None:
+                        continue
+                    sl = (i, slice(j0, min(shape[1], j0 + BY)), slice(k0, min(shape[2], k0 + BZ)))
+                    assert (pz[sl] > 0).all()
+                    u, v = uf[sl], vf[sl]
+                    assert (u >= box[0]).all() and (u <= box[1]).all(), (seed, box, float(u.min()), float(u.max()))
+                    assert (v >= box[2]).all() and (v <= box[3]).all(), (seed, box, float(v.min()), float(v.max()))
+                    accepted += 1
+    assert accepted > 0
