@@ -30,7 +30,8 @@ def load():
     if _lib is not None:
         return _lib
     build()
-    lib = ctypes.CDLL(_LIB_PATH)
+    # SPACECARVE_ORACLE_LIB: another build of the same source, e.g. `make -C oracle sanitize`
+    lib = ctypes.CDLL(os.environ.get("SPACECARVE_ORACLE_LIB") or _LIB_PATH)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int32)
     common_tail = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
