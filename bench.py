@@ -307,13 +307,14 @@ def main():
             "metric": "Mvoxels*views/sec space-carve, 512^3 x 72 views per MI355X",
             "value": value, "unit": "Mvoxel*views/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 addressing / int32 state",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE cfg 3: {a.n}^3 voxels x {V} views per GPU, scene S1 "
                                    f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
                        "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
                        "parallelism": f"x-planes cyclic over {world} rank(s), no data-path collective",
-                       "path": a.path, "views_per_launch": V if a.path == "fused" else 1},
+                       "path": a.path, "views_per_launch": V if a.path == "fused" else 1,
+                       "arithmetic": "float32 projection (no contraction, correctly rounded divide) into int32 labels"},
             "roofline": roof(a.path, stats, traffic_for(a.path)),
             "kernels": {k: stats[k] for k in ("carve", "step") if stats[k]["launches"]},
             "kernels_breakdown_pass": breakdown,
