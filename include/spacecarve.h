@@ -108,7 +108,8 @@ typedef struct sc_engine sc_engine;
 
 int sc_abi_version(void);
 const char *sc_last_error(void);
-/* number of visible HIP devices whose architecture is gfx950 */
+/* number of visible HIP devices whose architecture is gfx950 (others are skipped); sc_create*
+ * take a HIP ordinal and check that device alone */
 int sc_device_count(int *count);
 
 /*
@@ -151,9 +152,18 @@ int sc_set_option(sc_engine *e, int key, int64_t value);
  * afterwards (views already enqueued are flushed with the previous table). */
 int sc_set_lut(sc_engine *e, const float *lut256);
 
-/* Run the engine's work on an existing hipStream_t (e.g. torch's current stream);
- * NULL restores the engine's own stream. */
+/* Run the engine's work on an existing hipStream_t (a non-default stream of the caller);
+ * NULL restores the engine's own stream.  The engine's own stream is non-blocking: it does not
+ * synchronise with the legacy default stream (handle 0, which is what torch's default stream
+ * is), so a caller whose masks are produced there uses sc_order_after instead. */
 int sc_set_stream(sc_engine *e, void *hip_stream);
+
+/* Order everything the engine enqueues from now on AFTER the work enqueued so far on
+ * `producer_stream` (a hipStream_t; NULL = the legacy default stream): an event recorded there
+ * and waited for on the engine's stream.  For device-resident masks another stream is still
+ * writing (sc_process_views_device); replaces nothing in the reference, whose single in-order
+ * queue (cl.py:29-30) has no such hazard. */
+int sc_order_after(sc_engine *e, void *producer_stream);
 
 /*
  * Backprojection.process_view (cl.py:190-227): one view from a HOST mask.

@@ -23,9 +23,9 @@
  * PIN STATUS: see DESIGN.md "Oracle".  The reference's own tests hold no
  * numeric vectors for carve/average (tests/unit/test_cl.py:5-9 only builds two
  * objects); the conventions they do pin (tests/unit/test_proc3d.py:12-30) are
- * checked in tests/test_oracle.py.  Where tests/golden/ref_opencl_*.npz exist
- * they are outputs of the reference kernel text itself, compiled by the
- * image's OpenCL compiler and run on the GPU box (oracle/ref_opencl/).
+ * checked in tests/test_oracle.py.  No output of the reference itself exists
+ * to compare with (its kernels need OpenCL images, which neither box offers):
+ * PARITY UNPINNED against an execution of the reference.
  *
  * Layout: labels/values are C-order [nx][ny][nz], z fastest (common.h:6-8).
  * mask is row-major [H][W]; u indexes columns, v rows (cl.py:217 builds the

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "sc_clear": ("i", ["p"]),
     "sc_set_option": ("i", ["p", "i", "q"]),
     "sc_set_stream": ("i", ["p", "p"]),
+    "sc_order_after": ("i", ["p", "p"]),
     "sc_set_lut": ("i", ["p", "p"]),
     "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
@@ -334,7 +335,13 @@ class Engine:
         self._call("sc_set_lut", addr(lut))
 
     def set_stream(self, stream_ptr):
+        """Adopt a caller's (non-default) HIP stream; 0 restores the engine's own."""
         self._call("sc_set_stream", int(stream_ptr or 0))
+
+    def order_after(self, stream_ptr):
+        """Everything enqueued from now on runs after what ``stream_ptr`` holds so far
+        (0 = the legacy default stream, e.g. torch's default stream)."""
+        self._call("sc_order_after", int(stream_ptr or 0))
 
     # -- work -------------------------------------------------------------------------
     def clear(self):

@@ -102,6 +102,59 @@ def _assign_slabs(dst, src, workers=None):
         list(pool.map(work, range(workers)))
 
 
+def averaging_table(log):
+    """What the host conversion of cl.py:205-208 makes of each of the 256 byte values: the
+    conversions are elementwise, so ``table[mask] == convert(mask)`` bit for bit."""
+    lut = img_as_float32(np.arange(256, dtype=np.uint8))  # cl.py:205-206
+    if log:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lut = np.log(EPS + lut)  # cl.py:207-208
+    return np.ascontiguousarray(lut, dtype=np.float32)
+
+
+def submit_view(engine, dtype, log, lut, intrinsics, rot, tvec, mask, invert=False):
+    """The host half of ``process_view`` (cl.py:205-215) for an engine of state type ``dtype``
+    (int32 carve / float32 average), shared by ``Backprojection`` and ``ShardedBackprojection``.
+    Returns the averaging table in use (``lut``, built and handed to the engine on first need).
+
+    For 1-byte carving masks the fileset loop's ``np.invert`` (cl.py:300-301) is folded into the
+    device-side bit packing (``SC_MASK_U8_INV`` / ``SC_MASK_BOOL_INV``); every other case inverts
+    on the host exactly as the reference does."""
+    mask = np.asarray(mask)
+    fold = invert and dtype == np.int32 and mask.dtype in (np.uint8, np.bool_)
+    if invert and not fold:
+        mask = np.invert(mask)
+    if dtype == np.float32 and mask.dtype == np.uint8:
+        # averaging of a uint8 mask: ship the bytes and let the device look the float up in a
+        # 256-entry table built by the SAME host operations on the 256 byte values
+        if lut is None:
+            lut = averaging_table(log)
+            engine.set_lut(lut)
+        engine.process_view(intrinsics, rot, tvec, np.ascontiguousarray(mask), nat.SC_MASK_U8_LUT)
+        return lut
+    if dtype == np.float32 and mask.dtype != np.float32:
+        mask = img_as_float32(mask)  # cl.py:205-206
+    if log and dtype == np.float32:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mask = np.log(EPS + mask)  # cl.py:207-208
+
+    if dtype == np.int32:
+        # cl.py:215 casts to int32 and the kernel tests == 0 (backprojection.c:79);
+        # for 1-byte masks that test is done on the bytes themselves
+        if mask.dtype == np.bool_:
+            mask_h = np.ascontiguousarray(mask).view(np.uint8)
+            code = nat.SC_MASK_BOOL_INV if fold else nat.SC_MASK_U8
+        elif mask.dtype == np.uint8:
+            mask_h = np.ascontiguousarray(mask)
+            code = nat.SC_MASK_U8_INV if fold else nat.SC_MASK_U8
+        else:
+            mask_h, code = np.ascontiguousarray(mask, dtype=np.int32), nat.SC_MASK_I32
+    else:
+        mask_h, code = np.ascontiguousarray(mask, dtype=np.float32), nat.SC_MASK_F32
+    engine.process_view(intrinsics, rot, tvec, mask_h, code)
+    return lut
+
+
 class Backprojection(object):
     """Back-projection onto a voxel volume (drop-in for ``plant3dvision.cl.Backprojection``).
 
@@ -187,48 +240,9 @@ class Backprojection(object):
         return
 
     def _submit_view(self, intrinsics, rot, tvec, mask, invert):
-        """``process_view`` plus the fileset loop's optional ``np.invert`` (cl.py:300-301).
-        For 1-byte carving masks the inversion is folded into the device-side bit packing
-        (``SC_MASK_U8_INV`` / ``SC_MASK_BOOL_INV``); every other case inverts on the host
-        exactly as the reference does."""
-        mask = np.asarray(mask)
-        fold = invert and self.dtype == np.int32 and mask.dtype in (np.uint8, np.bool_)
-        if invert and not fold:
-            mask = np.invert(mask)
-        if self.dtype == np.float32 and mask.dtype == np.uint8:
-            # averaging of a uint8 mask: ship the bytes and let the device look the float up in
-            # a 256-entry table built by the SAME host operations on the 256 byte values (the
-            # conversions are elementwise, so table[mask] == convert(mask) bit for bit)
-            if self._lut is None:
-                lut = img_as_float32(np.arange(256, dtype=np.uint8))  # cl.py:205-206
-                if self.log:
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        lut = np.log(EPS + lut)  # cl.py:207-208
-                self._lut = np.ascontiguousarray(lut, dtype=np.float32)
-                self._engine.set_lut(self._lut)
-            self._engine.process_view(intrinsics, rot, tvec, np.ascontiguousarray(mask),
-                                      nat.SC_MASK_U8_LUT)
-            return
-        if self.dtype == np.float32 and mask.dtype != np.float32:
-            mask = img_as_float32(mask)  # cl.py:205-206
-        if self.log and self.dtype == np.float32:
-            with np.errstate(divide="ignore", invalid="ignore"):
-                mask = np.log(EPS + mask)  # cl.py:207-208
-
-        if self.dtype == np.int32:
-            # cl.py:215 casts to int32 and the kernel tests == 0 (backprojection.c:79);
-            # for 1-byte masks that test is done on the bytes themselves
-            if mask.dtype == np.bool_:
-                mask_h = np.ascontiguousarray(mask).view(np.uint8)
-                code = nat.SC_MASK_BOOL_INV if fold else nat.SC_MASK_U8
-            elif mask.dtype == np.uint8:
-                mask_h = np.ascontiguousarray(mask)
-                code = nat.SC_MASK_U8_INV if fold else nat.SC_MASK_U8
-            else:
-                mask_h, code = np.ascontiguousarray(mask, dtype=np.int32), nat.SC_MASK_I32
-        else:
-            mask_h, code = np.ascontiguousarray(mask, dtype=np.float32), nat.SC_MASK_F32
-        self._engine.process_view(intrinsics, rot, tvec, mask_h, code)
+        """``process_view`` plus the fileset loop's optional ``np.invert`` (cl.py:300-301)."""
+        self._lut = submit_view(self._engine, self.dtype, self.log, self._lut, intrinsics, rot, tvec,
+                                mask, invert)
         return
 
     def flush(self):
@@ -294,7 +308,10 @@ class Backprojection(object):
                 logger.info(f"Processing label '{label}'...")
                 if i != 0:
                     self.clear()
-                _assign_slabs(result[i], self.process_label(fs, camera_metadata, label, invert))  # result[i, :] = ...
+                vol = self.process_label(fs, camera_metadata, label, invert)
+                _assign_slabs(result[i], vol)  # result[i, :] = ...
+                self.recycle(vol)  # ours alone: the next label reads back into the same pages
+                del vol
             return result
         else:
             return self.process_label(fs, camera_metadata, None, invert=invert)
@@ -348,17 +365,28 @@ class Backprojection(object):
 
     def clear(self):
         """Clear computed values (cl.py:307-311)."""
-        # values_h becomes a fresh default-valued array (cl.py:309), built when read.  The old
-        # buffer is recycled only when nobody else holds it or a view of it.
-        import sys
-        old, self._values_h = self._values_h, None
-        if old is not None and old.base is None and sys.getrefcount(old) == 2:
-            self._spare = old
-        elif self._spare is None and self._prefault is None:
+        # values_h becomes a fresh default-valued array (cl.py:309), built when read.  The old one
+        # may be held by the caller (get_values returned it) and keeps its contents: it is never
+        # reused here unless the caller hands it back with ``recycle``.
+        self._values_h = None
+        if self._spare is None and self._prefault is None:
             self._start_prefault()
-        del old
         self._engine.clear()
         return
+
+    def recycle(self, array):
+        """Hand an array ``get_values`` returned back as the destination of a later read-back
+        (its pages are touched already: a 512 MiB read-back into it takes 10 ms instead of 50).
+        The caller promises not to use it afterwards.  No reference counterpart."""
+        base = array
+        while getattr(base, "base", None) is not None and isinstance(base.base, np.ndarray):
+            base = base.base
+        shape = tuple(int(s) for s in self.shape)
+        if (isinstance(base, np.ndarray) and base.dtype == self.dtype and base.size == int(np.prod(shape))
+                and base.flags["C_CONTIGUOUS"] and base.flags["WRITEABLE"]):
+            if self._values_h is base:
+                self._values_h = None
+            self._spare = base.reshape(shape)
 
     def close(self):
         """Release device memory now (otherwise at garbage collection)."""

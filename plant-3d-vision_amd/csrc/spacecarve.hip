@@ -2148,11 +2148,20 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
                     (long long)i0, (long long)istride, (long long)planes, (long long)nx);
     if (mode != SC_MODE_CARVE && mode != SC_MODE_AVERAGE)
         return fail(SC_ERR_INVALID, "unknown mode %d", mode);
+    // `device` is a HIP ordinal; only that device has to be a gfx950
     int ndev = 0;
-    int rc = sc_device_count(&ndev);
-    if (rc) return rc;
+    hipError_t hq = hipGetDeviceCount(&ndev);
+    if (hq != hipSuccess) return fail(SC_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(hq));
     if (device < 0 || device >= ndev)
-        return fail(SC_ERR_DEVICE, "device %d not available (%d gfx950 device(s) visible)", device, ndev);
+        return fail(SC_ERR_DEVICE, "device %d not available (%d HIP device(s) visible)", device, ndev);
+    {
+        hipDeviceProp_t prop;
+        hq = hipGetDeviceProperties(&prop, device);
+        if (hq != hipSuccess) return fail(SC_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(hq));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SC_ERR_DEVICE, "device %d is %s; this engine is built for gfx950 only", device,
+                        prop.gcnArchName);
+    }
     sc_engine *e = new (std::nothrow) sc_engine();
     if (!e) return fail(SC_ERR_NOMEM, "host allocation failed");
     e->device = device;
@@ -2199,10 +2208,7 @@ int sc_device_count(int *count) {
     for (int d = 0; d < n; ++d) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
-        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-            return fail(SC_ERR_DEVICE, "device %d is %s; this engine is built for gfx950 only", d,
-                        prop.gcnArchName);
-        ++ok;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;  // other devices are simply not ours
     }
     *count = ok;
     return SC_OK;
@@ -2263,6 +2269,10 @@ int sc_clear(sc_engine *e) {
     if (rc) return rc;
     e->pending.clear();
     arena_reset(e);
+    if (e->step_open) {  // the views of an open SC_KERNEL_STEP window are gone: no sample for them
+        e->event_pool.push_back(e->step_start);
+        e->step_open = false;
+    }
     e->fresh = true;  // materialised lazily: a fused launch never needs to read it
     return SC_OK;
 }
@@ -2368,6 +2378,23 @@ int sc_set_stream(sc_engine *e, void *hip_stream) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return SC_OK;
+}
+
+int sc_order_after(sc_engine *e, void *producer_stream) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    // NULL is the legacy default stream here (torch's default stream has handle 0); the engine's own
+    // stream is non-blocking, so it does NOT synchronise with that stream by itself
+    hipStream_t prod = producer_stream ? static_cast<hipStream_t>(producer_stream) : hipStreamLegacy;
+    if (prod == e->stream) return SC_OK;  // same stream: already in order
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t he = hipEventRecord(ev, prod);
+    if (he == hipSuccess) he = hipStreamWaitEvent(e->stream, ev, 0);
+    (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+    if (he != hipSuccess) return fail(SC_ERR_DEVICE, "ordering after the producer stream failed: %s", hipGetErrorString(he));
     return SC_OK;
 }
 

@@ -59,7 +59,10 @@ def masks_from_predictions(pred, label_names, labels=None, inverted_labels=("bac
                 b = dilate_cross(b, dilation)  # :373-374
             m = b.to(torch.uint8) * 255  # :376
         else:
-            m = (im * 255.0).to(torch.uint8)  # :376 (truncation, as astype does in range)
+            # :376 `(im * 255).astype(np.uint8)`: truncation toward zero, and outside [0, 255]
+            # what x86 NumPy does (float -> int32 -> low byte; torch's own float -> uint8 cast is
+            # undefined there and differs between devices)
+            m = (im * 255.0).to(torch.int32).bitwise_and(255).to(torch.uint8)
         if inv:
             m = 255 - m  # :378-379
         out[name] = m.contiguous()
@@ -91,8 +94,10 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
     if type not in ("averaging", "carving"):
         raise ValueError(f"Unknown kernel type {type}, valid values are 'averaging' or 'carving'!")
     eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)
-    # everything in order on torch's stream: the masks are complete when the engine reads them
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # The engine keeps its own (non-blocking) stream and is ordered explicitly behind torch's:
+    # torch's default stream has handle 0, which is NOT a stream the engine could adopt (0 means
+    # "own stream" to sc_set_stream) and which a non-blocking stream does not synchronise with.
+    producer = torch.cuda.current_stream(dev).cuda_stream
     if mode == nat.SC_MODE_AVERAGE:
         lut = img_as_float32(np.arange(256, dtype=np.uint8))
         if log:
@@ -111,10 +116,12 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
                                     np.float32 if mode == nat.SC_MODE_AVERAGE else np.int32)
             if mode == nat.SC_MODE_AVERAGE:
                 src = (255 - m) if invert else m
+                eng.order_after(producer)  # `m` / `src` are complete before the engine reads them
                 eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, nat.SC_MASK_U8_LUT)
             else:
                 code = nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8
                 src = m
+                eng.order_after(producer)
                 eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, code)
             vol = eng.get_values(dest.result())  # flushes and waits: `src` may go now
             del src

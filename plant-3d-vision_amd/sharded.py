@@ -63,7 +63,7 @@ class ShardedBackprojection:
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, rank=None,
                  world_size=None, device=None, engine_factory=None, views_per_launch=0,
-                 partition="cyclic"):
+                 partition="cyclic", log=False):
         if rank is None or world_size is None:
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_initialized() else 0
@@ -73,6 +73,8 @@ class ShardedBackprojection:
         self.origin = origin
         self.voxel_size = voxel_size
         self.default_value = default_value
+        self.log = log
+        self._lut = None
         if type == "carving":
             self.dtype, self._mode = np.int32, nat.SC_MODE_CARVE
         elif type == "averaging":
@@ -104,17 +106,15 @@ class ShardedBackprojection:
         return (len(self.planes), self.shape[1], self.shape[2])
 
     def process_view(self, intrinsics, rot, tvec, mask, mask_dtype=None):
-        mask = np.ascontiguousarray(mask)
-        if mask_dtype is None:
-            if self._mode == nat.SC_MODE_AVERAGE:
-                mask, mask_dtype = np.ascontiguousarray(mask, dtype=np.float32), nat.SC_MASK_F32
-            elif mask.dtype == np.bool_:
-                mask, mask_dtype = mask.view(np.uint8), nat.SC_MASK_U8
-            elif mask.dtype == np.uint8:
-                mask_dtype = nat.SC_MASK_U8
-            else:
-                mask, mask_dtype = np.ascontiguousarray(mask, dtype=np.int32), nat.SC_MASK_I32
-        self._engine.process_view(intrinsics, rot, tvec, mask, mask_dtype)
+        """``Backprojection.process_view`` on this rank's planes: the same host conversions
+        (cl.py:205-215: ``img_as_float32``, the ``log`` step, the dtype casts, uint8 + table for
+        averaging).  ``mask_dtype`` hands an already converted mask straight to the engine."""
+        if mask_dtype is not None:
+            self._engine.process_view(intrinsics, rot, tvec, np.ascontiguousarray(mask), mask_dtype)
+            return
+        from .cl import submit_view
+        self._lut = submit_view(self._engine, self.dtype, self.log, self._lut, intrinsics, rot, tvec,
+                                mask, invert=False)
 
     def clear(self):
         self._engine.clear()

@@ -10,8 +10,7 @@ Inputs  : the reference's own test data ``tests/testdata/virtual_plant`` (18 vie
 Outputs : expected volumes computed by the CPU oracle (oracle/spacecarve_oracle.c), each
           asserted equal to the independent NumPy restatement (oracle/oracle_np.py) before
           it is written.  They are ORACLE outputs, not outputs of the reference's OpenCL
-          run (see DESIGN.md "Oracle" for the pin status); fixtures named ``ref_opencl_*``
-          come from oracle/ref_opencl/ instead.
+          run (see DESIGN.md "Oracle" for the pin status: parity unpinned).
 """
 import glob
 import json

@@ -39,6 +39,9 @@ class OracleEngine:
     def set_stream(self, ptr):
         pass
 
+    def order_after(self, ptr):
+        pass
+
     def clear(self):
         self._vol.clear()
 

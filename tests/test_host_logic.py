@@ -171,3 +171,56 @@ def test_synthetic_scene_stays_small_for_any_camera_ring(radius_factor):
     assert len(views) == 3 and views[0][3].dtype == np.uint8
     grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
     assert grown_mb < 1500, grown_mb
+
+
+def test_sharded_process_view_does_the_reference_conversions():
+    """ShardedBackprojection.process_view = Backprojection.process_view (cl.py:205-215): a uint8
+    mask in averaging mode goes through img_as_float32 (and log), not a bare float cast."""
+    from plant3dvision_amd.sharded import ShardedBackprojection
+    from tests.helpers import OracleEngine
+    shape, origin, vs, views = scene(12, 3, "plant")
+    rng = np.random.default_rng(3)
+    grey = [(K, R, t, rng.integers(0, 256, m.shape, dtype=np.uint8)) for K, R, t, m in views]
+    for log in (False, True):
+        conv = (lambda m: np.log(EPS + img_as_float32(m))) if log else img_as_float32
+        with np.errstate(divide="ignore"):
+            want = oracle_c.average(shape, origin, vs, [(K, R, t, conv(m)) for K, R, t, m in grey])
+        for world, part in ((1, "cyclic"), (3, "cyclic"), (2, "slab")):
+            parts = {}
+            for r in range(world):
+                sb = ShardedBackprojection(shape, origin, vs, type="averaging", rank=r, world_size=world,
+                                           engine_factory=OracleEngine, partition=part, log=log)
+                for K, R, t, m in grey:
+                    sb.process_view(K, R, t, m)
+                for i, plane in zip(sb.planes, sb.get_local()):
+                    parts[i] = plane
+            got = np.stack([parts[i] for i in range(shape[0])])
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (log, world, part)
+    # bool masks in carving mode, float masks in averaging mode: as the class does
+    sb = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, engine_factory=OracleEngine)
+    for K, R, t, m in views:
+        sb.process_view(K, R, t, m != 0)
+    assert np.array_equal(sb.get_local(), oracle_c.carve(shape, origin, vs, views))
+
+
+def test_clear_never_reuses_an_array_the_caller_holds_unless_recycled():
+    shape, origin, vs, views = scene(10, 3, "plant")
+    bp = OracleBackprojection(shape, origin, vs)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    first = bp.get_values()
+    keep = first.copy()
+    alias = first  # a second reference changes nothing: ownership is explicit, not counted
+    bp.clear()
+    assert (bp.get_values() == 0).all()          # cl.py:307-311
+    assert np.array_equal(first, keep) and alias is first  # the array handed out kept its contents
+    second = bp.get_values()
+    assert not np.shares_memory(first, second)
+    bp.recycle(first)                             # handed back: the next read-back may land in it
+    bp.clear()
+    third = bp.get_values()
+    assert np.shares_memory(third, first)
+    bp.recycle(np.zeros(3, dtype=np.int32))       # wrong size: ignored
+    bp.recycle(np.zeros(shape, dtype=np.float32)) # wrong dtype: ignored
+    bp.clear()
+    assert bp.get_values().dtype == np.int32
