@@ -10,17 +10,23 @@ whole slab (the ``Backprojection.process_fileset`` work after ingest).  The resu
 Workload (config.workload): BASELINE cfg 3, 512^3 voxels x 72 views, scene S1 "plant"
 (SURVEY.md 8d).  N GPUs: weak scaling -- a near-cubic grid of about N x 512^3 voxels (N=8 is
 BASELINE cfg 4, 1024^3) whose x-planes are dealt round-robin over the ranks, so every rank
-carves ~512^3 voxels holding the same share of the object; no data-path collective (voxels are
-independent).  ``--gather`` times the optional grid assembly AFTER the timed region
-and reports it next to the headline; it is never part of ``value``.
+carves ~512^3 voxels holding the same share of the object; the carve itself needs no collective
+(voxels are independent).  For N > 1 the line carries BOTH ``value`` (carve only) and
+``value_with_assembly`` (carve + int8 all-gather of the labels into global order on every GPU,
+SURVEY 8d's ``t_device + collective``), plus the time of ``gather_to_host`` (the reference's
+``get_values``, cl.py:229-232).
 
-Two schedules of the same kernel are measured in the same run:
-  fused  (default, ``value``): all 72 views in one launch, state in registers, 4N bytes written;
-  stream (``stream`` object) : one launch per view as the reference does (cl.py:223-226), the
-         formulation SURVEY 8d's algorithmic-bytes figure (~4 B per voxel.view) is defined on.
-The ``roofline`` object describes the dominant kernel of the ``value`` path with ITS OWN
-algorithmic bytes; ``equiv_streaming_frac`` restates its speed in units of the streaming
-roofline (capped at 1, never an HBM-utilisation claim -- SURVEY 8d honesty guard).
+Beside the headline, in the same line (N = 1):
+  stream   one launch per view as the reference does (cl.py:223-226), the formulation SURVEY 8d's
+           algorithmic-bytes figure (~4 B per voxel.view) is defined on;
+  scenes   the fused carve on S2 "solid", S3 "noise" and "dense" (a 20 % solid object, ~30 %
+           foreground: no all-empty / all-white shortcut applies to most of it);
+  average  the `average` kernel (backprojection.c:36-55) on uint8 binary, uint8 grey and float32
+           masks, against the VALU issue roofline;
+  cpu_baseline  the oracle on this box's host cores, on a bounded sample of the same workload.
+The ``roofline`` object describes the ``value`` path with ITS OWN algorithmic bytes;
+``equiv_streaming_note`` restates its speed in units of the streaming roofline (a speed ratio,
+never an HBM-utilisation claim -- SURVEY 8d honesty guard).
 """
 import argparse
 import json
@@ -35,6 +41,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# non-packed f32 VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (one wave-instruction of
+# 64 lanes per 4 cycles per SIMD; packed f32 issues no faster on gfx950)
+VALU_PEAK_TLANEOPS = 39.3
+LANE_OPS_PER_VOXEL_VIEW = 50.0  # SURVEY 8d "VALU side": ~50 lane-ops per in-image voxel.view
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
 # x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
@@ -52,7 +62,10 @@ def parse():
     ap.add_argument("--scene", default="plant", choices=["plant", "solid", "noise"])
     ap.add_argument("--path", default="fused", choices=["fused", "stream"],
                     help="schedule reported as `value` (the other is reported beside it)")
-    ap.add_argument("--gather", default="none", choices=["none", "allgather", "allgather8", "allreduce"])
+    ap.add_argument("--gather", default="none", choices=["none", "allgather", "allgather8", "allreduce"],
+                    help="also time this other assembly once (N > 1 always times the int8 all-gather)")
+    ap.add_argument("--extra-steps", type=int, default=10, help="steps per extra scene / averaging form (0 = skip)")
+    ap.add_argument("--assembly-steps", type=int, default=20, help="N > 1: steps of carve + all-gather")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--skip-other-path", action="store_true")
@@ -164,6 +177,142 @@ def cpu_baseline(shape, origin, vs, views, budget_s):
             "sample_1thread": f"{p1} central X-planes x {V} views in {t1:.2f} s, 1 thread"}
 
 
+def host_timed(engine, torch, fn, steps, warmup=1):
+    """Host clock around `steps` calls of fn() with a synchronize on both sides (ms per step)."""
+    for _ in range(warmup):
+        fn()
+    engine.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    engine.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
+    """The fused carve on the other scenes of SURVEY 8d (+ "dense"), same grid, same engine."""
+    from plant3dvision_amd import scenes
+    out = {}
+    n_local = eng.num_voxels()
+    for kind in ("dense", "solid", "noise"):
+        _, _, _, views = scenes.make_scene(tuple(shape), a.views, kind)
+        V = len(views)
+        H, W = views[0][3].shape
+        eng.dev_upload(masks_dev, np.ascontiguousarray(np.stack([m for _, _, _, m in views])))
+        K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+        fg = float(np.mean([(m != 0).mean() for _, _, _, m in views]))
+        eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
+
+        def step():
+            eng.clear()
+            eng.process_views_device(K, R, t, masks_dev, V, H, W, nat.SC_MASK_U8)
+            eng.flush()
+
+        ms = host_timed(eng, torch, step, steps, warmup=2)
+        live, s0, s1n, ovf = eng.fused_counts()
+        bytes_step = 4.0 * n_local + float(V) * W * H
+        out[kind] = {"ms_per_step": ms, "value": n_local * V / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
+                     "mask_foreground": fg,
+                     "roofline_frac_hbm": bytes_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "fused_counts": {"live_bricks": live, "alive_after_dense_stage": s0,
+                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}}
+    return out
+
+
+def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
+    """The `average` kernel (backprojection.c:36-55) on the three mask forms the host hands over
+    (cl.py:205-215): uint8 binary and uint8 grey (bytes + 256-entry table, SC_MASK_U8_LUT) and
+    float32.  Bound: VALU issue -- every in-image voxel.view costs the projection (~50 lane-ops,
+    SURVEY 8d) whatever the mask holds; HBM traffic is 4 B per voxel once."""
+    from plant3dvision_amd.cl import averaging_table, img_as_float32
+    eng = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, device=device)
+    eng.set_lut(averaging_table(False))
+    V = len(views)
+    H, W = views[0][3].shape
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    binary = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    grey = np.random.default_rng(4321).integers(0, 256, binary.shape, dtype=np.uint8)
+    buf = eng.dev_alloc(binary.size * 4)
+    n = eng.num_voxels()
+    out = {}
+    for name, data, code in (("u8_binary", binary, nat.SC_MASK_U8_LUT), ("u8_grey", grey, nat.SC_MASK_U8_LUT),
+                             ("f32", img_as_float32(binary), nat.SC_MASK_F32)):
+        eng.dev_upload(buf, data)
+
+        def step():
+            eng.clear()
+            eng.process_views_device(K, R, t, buf, V, H, W, code)
+            eng.flush()
+
+        ms = host_timed(eng, torch, step, steps, warmup=1)
+        lane_ops = LANE_OPS_PER_VOXEL_VIEW * n * V
+        ach = lane_ops / (ms * 1e-3) / 1e12
+        ent = {"ms_per_step": ms, "value": n * V / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
+               "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
+                            "frac": ach / VALU_PEAK_TLANEOPS,
+                            "lane_ops_per_step": lane_ops,
+                            "model": "%.0f lane-ops per voxel.view (SURVEY 8d) x N x V" % LANE_OPS_PER_VOXEL_VIEW}}
+        if name == "u8_binary":
+            # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
+            # projecting: the model above counts work the kernel did not do
+            ent["roofline"]["frac"] = None
+            ent["roofline"]["equivalent_frac"] = ach / VALU_PEAK_TLANEOPS
+            ent["roofline"]["note"] = ("brick form skips the projection of (brick, view) pairs with a flat footprint: "
+                                       "an equivalent rate, not VALU utilisation")
+        out[name] = ent
+    eng.dev_free(buf)
+    eng.close()
+    return out
+
+
+def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V):
+    """N > 1: carve + the labels in global order on every GPU (int8 all-gather over xGMI + one
+    strided copy), barrier + synchronize on both sides, MAX over ranks; then gather_to_host once."""
+    world = sb.world_size
+    pad = sb._planes_max() * sb.shape[1] * sb.shape[2]
+    dev = torch.device("cuda", eng.device)
+    recv = torch.empty(pad * world, dtype=torch.int8, device=dev)
+    out = torch.empty(pad * world, dtype=torch.int8, device=dev)
+
+    def step():
+        eng.clear()
+        eng.process_views_device(*call, nat.SC_MASK_U8)
+        return sb.all_gather(compress=True, widen=False, recv=recv, out=out)
+
+    def maxed(dt):
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        full = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = maxed(time.perf_counter() - t0)
+    res = {"kind": "int8 all-gather of the labels + plane interleave into global order on every GPU "
+                   "(labels stay int8 on the device; vol2pcd takes 1-byte volumes)",
+           "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value_with_assembly": n_total * V * steps / dt / 1e6,
+           "bytes_received_per_rank": int(recv.numel())}
+    del full
+    dist.barrier()
+    t0 = time.perf_counter()
+    host = sb.gather_to_host(dst=0)
+    dist.barrier()
+    res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
+    res["gather_to_host_note"] = "labels to rank 0's GPU over the collective as int8, one PCIe copy, widened to int32 on the host"
+    del host
+    return res
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -231,7 +380,17 @@ def main():
         dto, statso = timed(eng, nat, torch, dist, call, osteps, vpl[other], world)
         res_other = (dto, statso, osteps)
 
-    # optional grid assembly, outside the timed region
+    # N > 1: carve + assembly, always (t_device + collective)
+    asm = None
+    if world > 1 and a.assembly_steps > 0:
+        asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
+    extras = avg = None
+    if world == 1 and a.extra_steps > 0 and a.path == "fused":
+        extras = extra_scenes(a, nat, torch, eng, gshape, masks_dev, a.extra_steps)
+        eng.dev_upload(masks_dev, stack)
+        avg = average_forms(a, nat, torch, gshape, origin, vs, views, local_rank, max(2, a.extra_steps // 2))
+
+    # another assembly on request, once
     gather = None
     if a.gather != "none":
         torch.cuda.synchronize()
@@ -297,6 +456,9 @@ def main():
             traffic = {}
 
     def traffic_for(path):
+        # PMC traffic was collected for ONE per-rank shape (the N = 1 workload): any other slab gets null
+        if world != 1 or list(sb.slab_shape) != [a.n, a.n, a.n]:
+            return None
         key = f"{path}_{a.scene}_{a.n}_{a.views}"
         ent = traffic.get(key)
         return ent.get("hbm_bytes_per_launch") if isinstance(ent, dict) else None
@@ -312,7 +474,8 @@ def main():
             "config": {"workload": f"BASELINE cfg 3: {a.n}^3 voxels x {V} views per GPU, scene S1 "
                                    f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
                        "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
-                       "parallelism": f"x-planes cyclic over {world} rank(s), no data-path collective",
+                       "parallelism": f"x-planes cyclic over {world} rank(s); `value` has no collective, "
+                                      f"`value_with_assembly` adds the int8 all-gather",
                        "path": a.path, "views_per_launch": V if a.path == "fused" else 1,
                        "arithmetic": "float32 projection (no contraction, correctly rounded divide) into int32 labels"},
             "roofline": roof(a.path, stats, traffic_for(a.path)),
@@ -324,6 +487,13 @@ def main():
             out[other] = {"value": n_total * V * osteps / dto / 1e6, "unit": "Mvoxel*views/s",
                           "steps": osteps, "ms_per_step": dto / osteps * 1e3,
                           "roofline": roof(other, statso, traffic_for(other)), "kernels": statso}
+        if asm is not None:
+            out["value_with_assembly"] = asm["value_with_assembly"]
+            out["assembly"] = asm
+        if extras is not None:
+            out["scenes"] = extras
+        if avg is not None:
+            out["average"] = avg
         if gather is not None:
             out["gather"] = gather
         if world == 1 and a.cpu_seconds > 0:

@@ -223,6 +223,24 @@ int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                          uint64_t *mismatches, uint64_t *fast_pairs);
 
 /*
+ * Self-test of the projection the voxel kernels share (backproject_point, backprojection.c:3-34,
+ * with the coordinates of :71-73): `count` samples, each a pose record and a voxel index, give
+ * one result word each:  v * W + u + 1  when the reference would touch mask[v][u], 0 when it
+ * rejects the point.  `poses`: nposes records of 28 32-bit words
+ *   float K[4], R[9], t[3], origin[3], voxel_size;  int32 W, H, nx, ny, nz, 0, 0, 0.
+ * Explicit samples: ijk[count][3] voxel indices (+ pose_idx[count], else record 0).
+ * Hashed samples (ijk == NULL): record and voxel are drawn from (seed, sample index) by an
+ * integer hash the caller can reproduce (oracle/spacecarve_oracle.c restates it), the record per
+ * 64 consecutive samples, the voxel inside that record's nx x ny x nz grid.
+ * words_out[count] and/or digests_out[ceil(count / 65536)] (sum over a run of 65536 samples of
+ * mix32(word ^ (uint32)index)) receive the results.  The caller compares them with the reference
+ * arithmetic; no reference counterpart (the reference has no tests on this function).
+ */
+int sc_selftest_project(sc_engine *e, int64_t count, uint32_t seed, int nposes, const float *poses,
+                        const int32_t *ijk, const int32_t *pose_idx, uint32_t *words_out,
+                        uint64_t *digests_out);
+
+/*
  * The carve's immediate consumer: plant3dvision/proc3d.py::vol2pcd (:490-570, called by
  * tasks/proc3d.py:134) on the GPU.  volume: host pointer, or device pointer on `device` when
  * on_device != 0 (e.g. sc_values_device_ptr: the volume then never crosses PCIe); dtype 0 int32,

@@ -42,6 +42,10 @@ def load():
     lib.oracle_project.argtypes = [ip, ctypes.c_int64, fp, fp, fp, fp, ctypes.c_int,
                                    ctypes.c_int, ip, ip, ip]
     lib.oracle_project.restype = ctypes.c_int
+    lib.oracle_selftest_project.argtypes = [ctypes.c_int64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int]
+    lib.oracle_selftest_project.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -136,3 +140,30 @@ def project(ijk, origin, voxel_size, K, R, t, W, H):
     lib.oracle_project(_ip(ijk), n, _fp(volinfo), _fp(K), _fp(R), _fp(t), int(W), int(H),
                        _ip(u), _ip(v), _ip(ok))
     return u, v, ok
+
+
+def selftest_project(poses, count=None, seed=1, ijk=None, pose_idx=None, words=True, digests=False,
+                     nthreads=1):
+    """The reference projection on the samples of the engine's ``sc_selftest_project`` (same
+    generator, same result words / digests); ``poses`` is the same ``[n, 28]`` record array."""
+    lib = load()
+    poses = np.ascontiguousarray(poses)
+    assert poses.dtype.itemsize == 4 and poses.ndim == 2 and poses.shape[1] == 28
+    jk = pi = None
+    if ijk is not None:
+        jk = np.ascontiguousarray(np.asarray(ijk, dtype=np.int32).reshape(-1, 3))
+        count = jk.shape[0]
+        if pose_idx is not None:
+            pi = np.ascontiguousarray(np.asarray(pose_idx, dtype=np.int32).reshape(-1))
+            assert pi.size == count
+    count = int(count)
+    w = np.empty(count, dtype=np.uint32) if words else None
+    d = np.empty((count + 65535) >> 16, dtype=np.uint64) if digests else None
+    rc = lib.oracle_selftest_project(count, int(seed), int(poses.shape[0]), poses.ctypes.data,
+                                     jk.ctypes.data if jk is not None else None,
+                                     pi.ctypes.data if pi is not None else None,
+                                     w.ctypes.data if w is not None else None,
+                                     d.ctypes.data if d is not None else None, int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"oracle returned {rc}")
+    return w, d

@@ -242,4 +242,100 @@ int oracle_project(const int32_t *ijk, int64_t n, const float *volinfo, const fl
     return 0;
 }
 
+/*
+ * The sample generator and result word of the engine's projection self-test
+ * (include/spacecarve.h, sc_selftest_project), restated on the reference arithmetic above:
+ * sample i draws its pose record from (seed, i / 64) and its voxel from (seed, i); the word is
+ * v * W + u + 1 when backproject_point accepts, else 0; a digest is the sum over 65536
+ * consecutive samples of mix32(word ^ (uint32)i).
+ */
+typedef struct {
+    float K[4], R[9], t[3];
+    float ox, oy, oz, vs;
+    int32_t W, H, nx, ny, nz, pad[3];
+} pose_rec_t;
+
+static uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+typedef struct {
+    int64_t begin, end;
+    uint32_t seed, nposes;
+    const pose_rec_t *poses;
+    const int32_t *ijk, *pose_idx;
+    uint32_t *words;
+    uint64_t *digests;
+} st_job_t;
+
+static void *selftest_worker(void *arg) {
+    const st_job_t *jb = (const st_job_t *)arg;
+    for (int64_t i = jb->begin; i < jb->end; ++i) {
+        uint32_t p;
+        int vi, vj, vk;
+        if (jb->ijk) {
+            p = jb->pose_idx ? (uint32_t)jb->pose_idx[i] : 0u;
+            vi = jb->ijk[3 * i]; vj = jb->ijk[3 * i + 1]; vk = jb->ijk[3 * i + 2];
+        } else {
+            uint64_t w = (uint64_t)i >> 6;
+            uint32_t h = mix32((uint32_t)w ^ jb->seed);
+            h = mix32(h + (uint32_t)(w >> 32) * 0x9e3779b9u);
+            p = h % jb->nposes;
+            uint32_t h2 = mix32((uint32_t)i * 0x9e3779b9u + jb->seed + (uint32_t)((uint64_t)i >> 32));
+            uint32_t h3 = mix32(h2 ^ 0x85ebca6bu), h4 = mix32(h3 + 0xc2b2ae35u);
+            vi = (int)(h2 % (uint32_t)jb->poses[p].nx);
+            vj = (int)(h3 % (uint32_t)jb->poses[p].ny);
+            vk = (int)(h4 % (uint32_t)jb->poses[p].nz);
+        }
+        const pose_rec_t *r = &jb->poses[p];
+        float x = r->ox + vi * r->vs; /* backprojection.c:71-73 */
+        float y = r->oy + vj * r->vs;
+        float z = r->oz + vk * r->vs;
+        int u = 0, v = 0;
+        uint32_t word = 0;
+        if (backproject_point(x, y, z, r->K, r->R, r->t, r->W, r->H, &u, &v)) {
+            word = (uint32_t)v * (uint32_t)r->W + (uint32_t)u + 1u;
+        }
+        if (jb->words) jb->words[i] = word;
+        if (jb->digests) jb->digests[i >> 16] += (uint64_t)mix32(word ^ (uint32_t)i);
+    }
+    return NULL;
+}
+
+int oracle_selftest_project(int64_t count, uint32_t seed, int nposes, const float *poses,
+                            const int32_t *ijk, const int32_t *pose_idx, uint32_t *words_out,
+                            uint64_t *digests_out, int nthreads) {
+    if (count < 0 || nposes < 1 || !poses || (!words_out && !digests_out)) return -1;
+    int64_t nchunks = (count + 65535) >> 16;
+    if (digests_out) memset(digests_out, 0, (size_t)nchunks * sizeof(uint64_t));
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if (nthreads > nchunks) nthreads = (int)(nchunks > 0 ? nchunks : 1);
+    st_job_t jobs[256];
+    pthread_t tids[256];
+    for (int w = 0; w < nthreads; ++w) { /* whole digest chunks per thread: no shared sums */
+        st_job_t *jb = &jobs[w];
+        int64_t c0 = nchunks * w / nthreads, c1 = nchunks * (w + 1) / nthreads;
+        jb->begin = c0 << 16;
+        jb->end = (c1 << 16) < count ? (c1 << 16) : count;
+        jb->seed = seed; jb->nposes = (uint32_t)nposes;
+        jb->poses = (const pose_rec_t *)poses;
+        jb->ijk = ijk; jb->pose_idx = pose_idx;
+        jb->words = words_out; jb->digests = digests_out;
+    }
+    if (nthreads == 1) {
+        selftest_worker(&jobs[0]);
+        return 0;
+    }
+    for (int w = 0; w < nthreads; ++w) {
+        if (pthread_create(&tids[w], NULL, selftest_worker, &jobs[w]) != 0) {
+            for (int q = 0; q < w; ++q) pthread_join(tids[q], NULL);
+            return -3;
+        }
+    }
+    for (int w = 0; w < nthreads; ++w) pthread_join(tids[w], NULL);
+    return 0;
+}
+
 int oracle_abi_version(void) { return 1; }

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_fused_counts": ("i", ["p", "p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
+    "sc_selftest_project": ("i", ["p", "q", "I", "i", "p", "p", "p", "p", "p"]),
     "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_vol2pcd_last_error": ("s", []),
     "sc_free_host": ("v", ["p"]),
@@ -258,6 +259,25 @@ class TouchedEmpty:
         return self._arr
 
 
+def pose_records(entries):
+    """``[n, 28]`` uint32 array of ``sc_selftest_project`` pose records from an iterable of
+    ``(K[4], R[9], t[3], origin[3], voxel_size, W, H, shape[3] or None)``."""
+    entries = list(entries)
+    rec = np.zeros((len(entries), 28), dtype=np.uint32)
+    f = rec.view(np.float32)
+    i = rec.view(np.int32)
+    for q, (K, R, t, origin, vs, W, H, shape) in enumerate(entries):
+        f[q, 0:4] = np.asarray(K, dtype=np.float32).reshape(4)
+        f[q, 4:13] = np.asarray(R, dtype=np.float32).reshape(9)
+        f[q, 13:16] = np.asarray(t, dtype=np.float32).reshape(3)
+        f[q, 16:19] = np.asarray(origin, dtype=np.float32).reshape(3)
+        f[q, 19] = np.float32(vs)
+        i[q, 20], i[q, 21] = int(W), int(H)
+        if shape is not None:
+            i[q, 22:25] = [int(x) for x in shape]
+    return rec
+
+
 def device_count():
     out = np.zeros(1, dtype=np.int32)
     check(backend().call("sc_device_count", addr(out)), "sc_device_count")
@@ -417,6 +437,30 @@ class Engine:
         out = np.zeros(2, dtype=np.uint64)
         self._call("sc_selftest_division", int(count), int(seed), int(mode), addr(out), addr(out) + 8)
         return int(out[0]), int(out[1])
+
+    def selftest_project(self, poses, count=None, seed=1, ijk=None, pose_idx=None, words=True,
+                         digests=False):
+        """Result words (and/or digests per 65536 samples) of the kernels' projection on explicit
+        (``ijk`` [+ ``pose_idx``]) or hashed (``count``, ``seed``) samples; ``poses`` is an array
+        ``[n, 28]`` of 32-bit words (``pose_records``).  See include/spacecarve.h."""
+        poses = np.ascontiguousarray(poses)
+        if poses.dtype.itemsize != 4 or poses.ndim != 2 or poses.shape[1] != 28:
+            raise ValueError("poses must be [n, 28] 32-bit words")
+        pi = jk = None
+        if ijk is not None:
+            jk = np.ascontiguousarray(np.asarray(ijk, dtype=np.int32).reshape(-1, 3))
+            count = jk.shape[0]
+            if pose_idx is not None:
+                pi = np.ascontiguousarray(np.asarray(pose_idx, dtype=np.int32).reshape(-1))
+                if pi.size != count:
+                    raise ValueError("one pose index per sample")
+        count = int(count)
+        w = np.empty(count, dtype=np.uint32) if words else None
+        d = np.empty((count + 65535) >> 16, dtype=np.uint64) if digests else None
+        self._call("sc_selftest_project", count, int(seed), int(poses.shape[0]), addr(poses),
+                   addr(jk) if jk is not None else 0, addr(pi) if pi is not None else 0,
+                   addr(w) if w is not None else 0, addr(d) if d is not None else 0)
+        return w, d
 
     # -- device memory helpers --------------------------------------------------------
     def dev_alloc(self, nbytes):

@@ -1220,6 +1220,77 @@ __global__ __launch_bounds__(kBlock) void div_selftest_kernel(uint64_t count, ui
     if (fast) atomicAdd(&out[1], fast);
 }
 
+// Self-test of project() itself -- the only place where bit-exactness with the reference's
+// backproject_point (backprojection.c:3-34) can break -- on explicit or hashed samples.  A sample is
+// (pose record, voxel index); its result word is  v * W + u + 1  when the reference would touch
+// mask[v][u] and 0 when it rejects the point.  Hashed samples (ijk == nullptr): the pose record is
+// drawn per wavefront (as in the voxel kernels, where the view is wave-uniform and the shared-
+// reciprocal division is taken when every lane is in range), the voxel per lane inside that
+// record's grid.  The CPU oracle generates the same samples (oracle_selftest_project) and the
+// test compares the words, or a digest per 65536 samples: sum of mix32(word ^ index).
+struct PoseRec {   // 28 words; sc_selftest_project's `poses`
+    float K[4], R[9], t[3];
+    float ox, oy, oz, vs;
+    int32_t W, H, nx, ny, nz, pad[3];
+};
+static_assert(sizeof(PoseRec) == 112, "PoseRec layout");
+
+__global__ __launch_bounds__(kBlock) void project_selftest_kernel(uint64_t count, uint32_t seed, uint32_t nposes,
+                                                                  const PoseRec *__restrict__ poses,
+                                                                  const int32_t *__restrict__ ijk,
+                                                                  const int32_t *__restrict__ pose_idx,
+                                                                  uint32_t *__restrict__ words,
+                                                                  unsigned long long *__restrict__ digests) {
+    const uint64_t nwaves = (count + 63) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t w = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < nwaves;
+         w += (uint64_t)gridDim.x * (kBlock / 64)) {
+        const uint64_t i = w * 64 + lane;
+        unsigned long long part = 0;
+        if (i < count) {
+            uint32_t p;
+            int vi, vj, vk;
+            if (ijk != nullptr) {
+                p = pose_idx ? (uint32_t)pose_idx[i] : 0u;
+                vi = ijk[3 * i]; vj = ijk[3 * i + 1]; vk = ijk[3 * i + 2];
+            } else {
+                uint32_t h = mix32((uint32_t)w ^ seed);
+                h = mix32(h + (uint32_t)(w >> 32) * 0x9e3779b9u);
+                p = h % nposes;
+                const uint32_t h2 = mix32((uint32_t)i * 0x9e3779b9u + seed + (uint32_t)(i >> 32));
+                const uint32_t h3 = mix32(h2 ^ 0x85ebca6bu), h4 = mix32(h3 + 0xc2b2ae35u);
+                vi = (int)(h2 % (uint32_t)poses[p].nx);
+                vj = (int)(h3 % (uint32_t)poses[p].ny);
+                vk = (int)(h4 % (uint32_t)poses[p].nz);
+            }
+            const PoseRec r = poses[p];
+            ViewDesc d;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d.K[q] = r.K[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) d.R[q] = r.R[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d.t[q] = r.t[q];
+            d.mask = nullptr; d.occ = nullptr; d.W = r.W; d.H = r.H; d.tiles_x = 0; d.pad = 0;
+            d.Wf = (float)r.W; d.Hf = (float)r.H;
+            // exactly what the voxel kernels do: coordinates as backprojection.c:71-73, the x / y
+            // partial sums of the three dot products first (the reference's own association)
+            const float x = r.ox + (float)vi * r.vs, y = r.oy + (float)vj * r.vs, z = r.oz + (float)vk * r.vs;
+            const float ax = d.R[0] * x + d.R[1] * y, ay = d.R[3] * x + d.R[4] * y, az = d.R[6] * x + d.R[7] * y;
+            int u, v;
+            const bool ok = project(ax, ay, az, z, d, u, v);
+            const uint32_t word = ok ? (uint32_t)v * (uint32_t)r.W + (uint32_t)u + 1u : 0u;
+            if (words != nullptr) words[i] = word;
+            part = (unsigned long long)mix32(word ^ (uint32_t)i);
+        }
+        if (digests != nullptr) {  // 64 consecutive samples share a digest: one atomic per wavefront
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) atomicAdd(&digests[w >> 10], part);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
                                                       uint32_t bits) {
     uint64_t idx = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -2387,8 +2458,10 @@ int sc_order_after(sc_engine *e, void *producer_stream) {
     if (rc) return rc;
     // NULL is the legacy default stream here (torch's default stream has handle 0); the engine's own
     // stream is non-blocking, so it does NOT synchronise with that stream by itself
-    hipStream_t prod = producer_stream ? static_cast<hipStream_t>(producer_stream) : hipStreamLegacy;
-    if (prod == e->stream) return SC_OK;  // same stream: already in order
+    // (the handle 0 itself: hipStreamLegacy is not understood by every runtime this library meets --
+    // torch's bundled one crashed on it)
+    hipStream_t prod = static_cast<hipStream_t>(producer_stream);
+    if (prod != nullptr && prod == e->stream) return SC_OK;  // same stream: already in order
     hipEvent_t ev;
     HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t he = hipEventRecord(ev, prod);
@@ -2604,6 +2677,60 @@ int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
     if (he != hipSuccess) return fail(SC_ERR_DEVICE, "division self-test failed: %s", hipGetErrorString(he));
     *mismatches = host[0];
     *fast_pairs = host[1];
+    return SC_OK;
+}
+
+int sc_selftest_project(sc_engine *e, int64_t count, uint32_t seed, int nposes, const float *poses,
+                        const int32_t *ijk, const int32_t *pose_idx, uint32_t *words_out,
+                        uint64_t *digests_out) {
+    if (!e || count < 0 || nposes < 1 || !poses || (!words_out && !digests_out))
+        return fail(SC_ERR_INVALID, "bad argument");
+    if (!ijk && pose_idx) return fail(SC_ERR_INVALID, "pose_idx goes with explicit voxel indices");
+    const PoseRec *hp = reinterpret_cast<const PoseRec *>(poses);
+    for (int q = 0; q < nposes; ++q) {
+        if (hp[q].W < 1 || hp[q].H < 1 || (int64_t)hp[q].W * hp[q].H >= 0xffffffffLL)
+            return fail(SC_ERR_INVALID, "pose %d: bad picture size %d x %d", q, hp[q].W, hp[q].H);
+        if (!ijk && (hp[q].nx < 1 || hp[q].ny < 1 || hp[q].nz < 1))
+            return fail(SC_ERR_INVALID, "pose %d: hashed samples need a grid shape", q);
+    }
+    if (ijk && pose_idx)
+        for (int64_t i = 0; i < count; ++i)
+            if (pose_idx[i] < 0 || pose_idx[i] >= nposes) return fail(SC_ERR_INVALID, "pose index out of range");
+    if (count == 0) return SC_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    const size_t ndig = (size_t)((count + 65535) >> 16);
+    PoseRec *dp = nullptr;
+    int32_t *dijk = nullptr, *didx = nullptr;
+    uint32_t *dw = nullptr;
+    unsigned long long *dd = nullptr;
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&dp), (size_t)nposes * sizeof(PoseRec));
+    if (he == hipSuccess) he = hipMemcpy(dp, poses, (size_t)nposes * sizeof(PoseRec), hipMemcpyHostToDevice);
+    if (he == hipSuccess && ijk) {
+        he = hipMalloc(reinterpret_cast<void **>(&dijk), (size_t)count * 12);
+        if (he == hipSuccess) he = hipMemcpy(dijk, ijk, (size_t)count * 12, hipMemcpyHostToDevice);
+    }
+    if (he == hipSuccess && pose_idx) {
+        he = hipMalloc(reinterpret_cast<void **>(&didx), (size_t)count * 4);
+        if (he == hipSuccess) he = hipMemcpy(didx, pose_idx, (size_t)count * 4, hipMemcpyHostToDevice);
+    }
+    if (he == hipSuccess && words_out) he = hipMalloc(reinterpret_cast<void **>(&dw), (size_t)count * 4);
+    if (he == hipSuccess && digests_out) {
+        he = hipMalloc(reinterpret_cast<void **>(&dd), ndig * 8);
+        if (he == hipSuccess) he = hipMemsetAsync(dd, 0, ndig * 8, e->stream);
+    }
+    if (he == hipSuccess) {
+        const uint64_t nwaves = ((uint64_t)count + 63) >> 6;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((nwaves + 3) / 4, 16384);
+        hipLaunchKernelGGL(project_selftest_kernel, dim3(blocks), dim3(kBlock), 0, e->stream, (uint64_t)count,
+                           seed, (uint32_t)nposes, dp, dijk, didx, dw, dd);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess && words_out) he = hipMemcpy(words_out, dw, (size_t)count * 4, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && digests_out) he = hipMemcpy(digests_out, dd, ndig * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dp); (void)hipFree(dijk); (void)hipFree(didx); (void)hipFree(dw); (void)hipFree(dd);
+    if (he != hipSuccess) return fail(SC_ERR_DEVICE, "projection self-test failed: %s", hipGetErrorString(he));
     return SC_OK;
 }
 

@@ -12,6 +12,13 @@ Scenes
            splatted into every view and dilated by 2 px -- a few % foreground; headline.
 ``solid``  S2: all-255 masks: nothing is ever carved, every voxel does every view.
 ``noise``  S3: Bernoulli(0.5) pixels, ``default_rng(5678)``: worst gather incoherence.
+``dense``  a solid tri-axial ellipsoid filling 20 % of the grid's bounding box, exact silhouettes
+           (ray-cast per pixel), cameras close enough (``radius_factor`` 1.2) for ~30 % foreground:
+           what a tight bounding box around a bulky object looks like -- no shortcut for empty or
+           all-white pictures applies to most of it.
+``literal_real_plant_scene()``: the grid of ``configs/test_geom_pipe_real.toml:27-36`` with the
+           scan path of ``tests/testdata/real_plant/scan.toml`` (60 views; cameras level with the top of
+           the box, so its lower part is seen by no view).
 """
 import math
 
@@ -137,6 +144,56 @@ def splat_mask(points, K, R, t, width, height, dilate=2):
     return (m.astype(np.uint8)) * np.uint8(255)
 
 
+def ellipsoid_silhouette(K, R, t, width, height, centre, semi_axes):
+    """Exact silhouette (uint8 {0,255}) of the axis-aligned ellipsoid ``sum(((X - centre) / a)^2) <= 1``:
+    a pixel is foreground when the ray through its centre meets the ellipsoid in front of the camera."""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(t, dtype=np.float64)
+    C = -R.T @ t
+    u = (np.arange(width, dtype=np.float64) + 0.5 - float(K[2])) / float(K[0])
+    v = (np.arange(height, dtype=np.float64) + 0.5 - float(K[3])) / float(K[1])
+    a = np.asarray(semi_axes, dtype=np.float64)
+    o = (C - np.asarray(centre, dtype=np.float64)) / a
+    # ray direction in world coordinates, scaled by the semi-axes: d = R^T (u, v, 1) / a
+    dx = (R[0, 0] * u[None, :] + R[1, 0] * v[:, None] + R[2, 0]) / a[0]
+    dy = (R[0, 1] * u[None, :] + R[1, 1] * v[:, None] + R[2, 1]) / a[1]
+    dz = (R[0, 2] * u[None, :] + R[1, 2] * v[:, None] + R[2, 2]) / a[2]
+    A = dx * dx + dy * dy + dz * dz
+    B = dx * o[0] + dy * o[1] + dz * o[2]
+    Cc = float(o @ o) - 1.0
+    hit = (B * B - A * Cc >= 0.0) & (B < 0.0)
+    return hit.astype(np.uint8) * np.uint8(255)
+
+
+#: semi-axes of the "dense" object as fractions of the grid's longest edge: 4/3 pi abc = 0.2006
+DENSE_SEMI_AXES = (0.38, 0.28, 0.45)
+
+
+def literal_real_plant_scene(n_views=60, kind="plant", width=WIDTH, height=HEIGHT):
+    """The reference's literal ``Voxels`` configuration (``configs/test_geom_pipe_real.toml:27-36``):
+    bounding box x[300,450] y[300,450] z[-175,105] at voxel_size 0.5 -> 301 x 301 x 561 voxels
+    (``tasks/cl.py:143-145``), seen by the scan path of ``tests/testdata/real_plant/scan.toml``
+    (circle centre (375, 375), radius 300, z = 80, tilt 0, 60 points) through the scanner's
+    camera model (``colmap.py:78-82``).  The pictures are synthetic (the S1 phantom standing in the
+    box); poses are the nominal ones of the scan path, not COLMAP's."""
+    bbox = {"x": [300, 450], "y": [300, 450], "z": [-175, 105]}
+    vs = 0.5
+    shape = [int((bbox[a][1] - bbox[a][0]) / vs) + 1 for a in "xyz"]  # tasks/cl.py:143-145
+    origin = [float(bbox[a][0]) for a in "xyz"]
+    centre = [origin[a] + (shape[a] - 1) * vs / 2.0 for a in range(3)]
+    poses = ring_cameras(n_views, (375.0, 375.0, 80.0), 300.0)  # level cameras at z = 80
+    extent = max(shape) * vs
+    if kind == "plant":
+        pts = phantom_points(extent, centre, max(1.5 * (300.0 - 0.4 * extent) / FX, extent / 800.0))
+        masks = [splat_mask(pts, K, R, t, width, height, dilate=2) for K, R, t in poses]
+    elif kind == "dense":
+        masks = [ellipsoid_silhouette(K, R, t, width, height, centre, [f * extent for f in (0.2, 0.15, 0.45)])
+                 for K, R, t in poses]
+    else:
+        raise ValueError(f"unknown scene kind {kind!r}")
+    return shape, origin, vs, [(K, R, t, m) for (K, R, t), m in zip(poses, masks)]
+
+
 def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=VOXEL_SIZE,
                center=CENTER, radius_factor=2.0, tilt_deg=0.0, fx=FX, fy=FY, cx=CX, cy=CY,
                seed=None):
@@ -147,6 +204,8 @@ def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=
     """
     shape, origin = grid_for(n, voxel_size, center)
     extent = max(shape) * voxel_size
+    if kind == "dense" and radius_factor == 2.0:
+        radius_factor = 1.2  # close cameras: the object fills ~30 % of every picture
     radius = radius_factor * extent
     poses = ring_cameras(n_views, center, radius, tilt_deg=tilt_deg, fx=fx, fy=fy, cx=cx, cy=cy)
     masks = []
@@ -168,6 +227,9 @@ def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=
         rng = np.random.default_rng(5678 if seed is None else seed)
         for _ in poses:
             masks.append((rng.random((height, width)) < 0.5).astype(np.uint8) * np.uint8(255))
+    elif kind == "dense":
+        semi = [f * extent for f in DENSE_SEMI_AXES]
+        masks = [ellipsoid_silhouette(K, R, t, width, height, center, semi) for K, R, t in poses]
     elif kind == "empty":
         zero = np.zeros((height, width), dtype=np.uint8)
         masks = [zero for _ in poses]

@@ -140,29 +140,49 @@ class ShardedBackprojection:
             return torch.as_tensor(buf, device=f"cuda:{self.device}")
         return torch.from_numpy(np.ascontiguousarray(self.get_local()).reshape(-1))
 
-    def _max_slab_voxels(self):
-        planes = max(len(rank_planes(self.shape[0], self.world_size, r, self.partition))
-                     for r in range(self.world_size))
-        return planes * self.shape[1] * self.shape[2]
+    def _planes_max(self):
+        return max(len(rank_planes(self.shape[0], self.world_size, r, self.partition))
+                   for r in range(self.world_size))
 
-    def _assemble(self, per_rank):
-        """Full grid (torch tensor ``[nx, ny, nz]``) from one flat, possibly padded, tensor per
-        rank, placing every rank's planes at their global x indices."""
+    def _is_even(self):
+        return self.shape[0] % self.world_size == 0
+
+    def _land(self, recv, out=None):
+        """Global-order grid from the all-gather's receive buffer ``[W][P][ny*nz]`` (P = the
+        largest plane count of a rank; shorter ranks are padded at the end).
+
+        slab, nx % W == 0 : the receive buffer IS the grid -- nothing moves;
+        cyclic            : ONE strided copy (a device kernel) interleaves the planes,
+                            ``full[p*W + r] = recv[r][p]``, into a buffer of P*W planes whose
+                            first nx planes are returned (a contiguous view);
+        slab, uneven      : one block copy per rank.
+        """
         import torch
-        plane = self.shape[1] * self.shape[2]
-        first = per_rank[0]
-        full = torch.empty((self.shape[0], self.shape[1], self.shape[2]), dtype=first.dtype,
-                           device=first.device)
-        for r, flat in enumerate(per_rank):
-            pl = rank_planes(self.shape[0], self.world_size, r, self.partition)
-            full[pl.start:pl.stop:pl.step] = flat[: len(pl) * plane].reshape(len(pl), *self.shape[1:])
-        return full
+        W, P = self.world_size, self._planes_max()
+        nx, ny, nz = self.shape
+        plane = ny * nz
+        recv = recv.view(W, P, plane)
+        if self.partition == "slab" and self._is_even():
+            return recv.view(nx, ny, nz)
+        if out is None:
+            out = torch.empty(P * W * plane, dtype=recv.dtype, device=recv.device)
+        if self.partition == "cyclic":
+            out.view(P, W, plane).copy_(recv.transpose(0, 1))
+            return out[: nx * plane].view(nx, ny, nz)
+        full = out[: nx * plane].view(nx, plane)
+        for r in range(W):
+            pl = rank_planes(nx, W, r, "slab")
+            full[pl.start:pl.stop] = recv[r, : len(pl)]
+        return full.view(nx, ny, nz)
 
-    def all_gather(self, compress=False):
+    def all_gather(self, compress=False, widen=True, recv=None, out=None):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
 
-        compress=True sends carve labels as int8 (labels are in {-1, 0, 1} when
-        default_value is): 4x less xGMI traffic, widened back after the collective.
+        compress=True sends carve labels as int8 (labels are in {-1, 0, 1} when default_value
+        is): 4x less xGMI traffic; ``widen`` turns the assembled grid back into int32 (the
+        reference's dtype, cl.py:145-147) -- a device consumer that takes 1-byte volumes
+        (``vol2pcd``) passes ``widen=False`` and spares the 4 bytes per voxel.
+        recv / out: reusable buffers of ``W * P * ny * nz`` elements of the wire dtype.
         """
         import torch
         import torch.distributed as dist
@@ -170,18 +190,28 @@ class ShardedBackprojection:
         if compress:
             if self.dtype != np.int32:
                 raise ValueError("compression is for carve labels only")
+            if not -128 <= int(self.default_value) <= 127:
+                raise ValueError("default_value does not fit int8")
             local = local.to(torch.int8)
         if self.world_size == 1:
-            return local.to(torch.int32 if compress else local.dtype).reshape(self.shape)
-        pad = self._max_slab_voxels()
+            full = local.reshape(self.shape)
+            return full.to(torch.int32) if compress and widen else full
+        pad = self._planes_max() * self.shape[1] * self.shape[2]
+        if recv is None:
+            recv = torch.empty(pad * self.world_size, dtype=local.dtype, device=local.device)
         send = local
-        if local.numel() != pad:
+        if local.numel() != pad:  # a rank with one plane fewer
             send = torch.zeros(pad, dtype=local.dtype, device=local.device)
             send[: local.numel()] = local
-        recv = torch.empty(pad * self.world_size, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(recv, send)
-        full = self._assemble([recv[r * pad:(r + 1) * pad] for r in range(self.world_size)])
-        if compress:
+        staged = dist.get_backend() == "gloo" and recv.is_cuda  # rehearsal on one box: through the host
+        if staged:
+            hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(hrecv, send.cpu())
+            recv.copy_(hrecv)
+        else:
+            dist.all_gather_into_tensor(recv, send)
+        full = self._land(recv, out)
+        if compress and widen:
             full = full.to(torch.int32)
         return full
 
@@ -196,36 +226,46 @@ class ShardedBackprojection:
         pl = self.planes
         full[pl.start:pl.stop:pl.step] = local.reshape(len(pl), *self.shape[1:])
         if self.world_size > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == "gloo" and full.is_cuda:
+                h = full.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                full.copy_(h)
+            else:
+                dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full
 
-    def gather_to_host(self, dst=0):
-        """Full grid as a NumPy array on rank ``dst`` (None elsewhere): each rank copies its
-        own slab device->host over its own PCIe link; only host memory is exchanged."""
+    def gather_to_host(self, dst=0, compress=None):
+        """Full grid as a NumPy array of the reference's dtype on rank ``dst`` (None elsewhere) --
+        what ``get_values`` (cl.py:229-232) hands a ``Voxels`` run.
+
+        RCCL: the slabs travel to ``dst``'s GPU over xGMI (``dist.gather`` of tensors; carve labels
+        as int8 unless ``compress=False``), are put in global order there by the same strided copy
+        as ``all_gather``, and cross PCIe once.  gloo (CPU rehearsal and tests): each rank copies
+        its slab to the host and the host tensors are gathered."""
         import torch
         import torch.distributed as dist
-        local = np.ascontiguousarray(self.get_local())
         if self.world_size == 1:
-            return local.reshape(self.shape)
-        if dist.get_backend() == "gloo":
-            t = torch.from_numpy(local.reshape(-1))
-            pad = self._max_slab_voxels()
-            send = torch.zeros(pad, dtype=t.dtype)
-            send[: t.numel()] = t
-            bufs = [torch.empty_like(send) for _ in range(self.world_size)] if self.rank == dst else None
-            dist.gather(send, bufs, dst=dst)
-            if self.rank != dst:
-                return None
-            return self._assemble(bufs).numpy()
-        objs = [None] * self.world_size if self.rank == dst else None
-        dist.gather_object(local, objs, dst=dst)
+            return np.ascontiguousarray(self.get_local()).reshape(self.shape)
+        if compress is None:
+            compress = self.dtype == np.int32 and -128 <= int(self.default_value) <= 127
+        pad = self._planes_max() * self.shape[1] * self.shape[2]
+        on_device = self._on_gpu and dist.get_backend() != "gloo"
+        local = self._slab_tensor() if on_device else torch.from_numpy(
+            np.ascontiguousarray(self.get_local()).reshape(-1))
+        if compress:
+            local = local.to(torch.int8)
+        send = local
+        if local.numel() != pad:
+            send = torch.zeros(pad, dtype=local.dtype, device=local.device)
+            send[: local.numel()] = local
+        recv = None
+        if self.rank == dst:
+            recv = torch.empty(pad * self.world_size, dtype=send.dtype, device=send.device)
+        dist.gather(send, list(recv.view(self.world_size, pad).unbind(0)) if recv is not None else None, dst=dst)
         if self.rank != dst:
             return None
-        out = np.empty(self.shape, dtype=self.dtype)
-        for r, part in enumerate(objs):
-            pl = rank_planes(self.shape[0], self.world_size, r, self.partition)
-            out[pl.start:pl.stop:pl.step] = part
-        return out
+        full = self._land(recv).cpu().numpy()
+        return full.astype(self.dtype) if full.dtype != self.dtype else full
 
     def close(self):
         if self._engine is not None:

@@ -64,6 +64,17 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
         res = {"rank": rank, "planes": list(sb.planes), "ag": full_ag, "ar": full_ar, "host": host}
         if mode == "carving":
             res["ag8"] = sb.all_gather(compress=True).numpy()
+            narrow = sb.all_gather(compress=True, widen=False)
+            assert narrow.dtype == torch.int8
+            res["ag8n"] = narrow.numpy()
+            # reusable buffers: the second call lands in the same memory
+            pad = sb._planes_max() * shape[1] * shape[2]
+            recv = torch.empty(pad * world, dtype=torch.int32)
+            out = torch.empty(pad * world, dtype=torch.int32)
+            a = sb.all_gather(recv=recv, out=out)
+            b = sb.all_gather(recv=recv, out=out)
+            assert a.data_ptr() == b.data_ptr() and torch.equal(a, b)
+            res["host32"] = sb.gather_to_host(dst=world - 1, compress=False)
         q.put(res)
     finally:
         dist.barrier()
@@ -73,6 +84,7 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
 @pytest.mark.parametrize("world,shape,mode,partition", [(2, (16, 10, 12), "carving", "cyclic"),
                                                         (3, (17, 9, 8), "carving", "cyclic"),
                                                         (3, (17, 9, 8), "carving", "slab"),
+                                                        (2, (16, 10, 12), "carving", "slab"),
                                                         (2, (9, 8, 12), "averaging", "cyclic")])
 def test_gloo_sharded_equals_single(world, shape, mode, partition):
     _, origin, vs, views = scene(tuple(shape), 5, "plant")
@@ -97,8 +109,13 @@ def test_gloo_sharded_equals_single(world, shape, mode, partition):
         assert np.array_equal(res["ar"], want)
         if mode == "carving":
             assert np.array_equal(res["ag8"], want)
+            assert res["ag8n"].dtype == np.int8 and np.array_equal(res["ag8n"], want)
+            if res["rank"] == world - 1:
+                assert res["host32"].dtype == np.int32 and np.array_equal(res["host32"], want)
+            else:
+                assert res["host32"] is None
         if res["rank"] == 0:
-            assert np.array_equal(res["host"], want)
+            assert res["host"].dtype == want.dtype and np.array_equal(res["host"], want)
         else:
             assert res["host"] is None
 
@@ -116,3 +133,51 @@ def test_sharded_class_over_hip_engine_single_rank(gpu_device):
     assert np.array_equal(sb.all_gather().cpu().numpy(), want)
     assert np.array_equal(sb.all_reduce().cpu().numpy(), want)
     sb.close()
+
+
+def _gpu_worker(rank, world, port, shape, partition, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, origin, vs, views = scene(tuple(shape), 8, "plant")
+        sb = ShardedBackprojection(shape, origin, vs, rank=rank, world_size=world, device=0, partition=partition)
+        for K, R, t, m in views:
+            sb.process_view(K, R, t, m)
+        full = sb.all_gather()
+        assert full.is_cuda and full.dtype == torch.int32
+        narrow = sb.all_gather(compress=True, widen=False)
+        assert narrow.is_cuda and narrow.dtype == torch.int8
+        q.put({"rank": rank, "ag": full.cpu().numpy(), "ag8n": narrow.cpu().numpy(),
+               "ar": sb.all_reduce().cpu().numpy(), "host": sb.gather_to_host(dst=0)})
+        sb.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition,shape", [("cyclic", (37, 48, 64)), ("slab", (36, 32, 128))])
+def test_two_ranks_over_hip_engines_sharing_the_gpu(gpu_device, partition, shape):
+    """world_size 2 with the HIP engine behind both ranks (one GPU, gloo as the transport): the
+    device branches of all_gather / all_reduce / gather_to_host that RCCL would run on 8 GPUs."""
+    _, origin, vs, views = scene(tuple(shape), 8, "plant")
+    want = oracle_c.carve(list(shape), origin, vs, views)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, list(shape), partition, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for res in results:
+        assert np.array_equal(res["ag"], want) and np.array_equal(res["ar"], want)
+        assert res["ag8n"].dtype == np.int8 and np.array_equal(res["ag8n"], want)
+        if res["rank"] == 0:
+            assert res["host"].dtype == np.int32 and np.array_equal(res["host"], want)
+        else:
+            assert res["host"] is None
