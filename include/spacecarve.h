@@ -93,6 +93,10 @@ extern "C" {
                                      view is all 0 or all 255 add table[0] / table[255] without projecting */
 #define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
 #define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
+#define SC_OPT_PACK_RIDE 22        /* 1 (default): a batch of device-resident 1-byte masks (sc_process_views_device)
+                                     is packed when it is launched, in the order its views are applied: the
+                                     first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
+#define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

@@ -94,14 +94,25 @@ struct ListCtl {
     ListCounter count[3][kSub];  // entries appended per sub-list, one set per list stage
     uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
     uint32_t nlive;              // brick form: bricks no view found empty (entries of the live list)
-    uint32_t pad[30];
+    uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
+    uint32_t pad[29];
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
+// FULL candidates the flags kernel left open (flag 3: every view it could see keeps the brick whole,
+// but the masks of views [v0, v1) were not packed yet -- they are packed beside the dense stage): the
+// store blocks, which run after that, put the question to the remaining views.
+struct Confirm {
+    const ViewDesc *views;  // the batch's descriptors
+    int32_t v0, v1;
+    uint32_t *late;         // bricks some later view does not keep whole: carved by the resume kernel
+    ListCtl *ctl;
+};
 struct CullStores {
     const uint8_t *flags;  // null: nothing deferred
     uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
     int32_t kept, fresh;   // see Fill
+    Confirm cf;
 };
 
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
@@ -355,6 +366,97 @@ __global__ __launch_bounds__(kBlock) void carve_kernel(int32_t *__restrict__ lab
     carve_group<FRESH, VEC>(labels, g, views, nviews, init, grp, pre, ap);
 }
 
+// Mask ingest, fast form for 1-byte masks whose rows are 16-byte aligned multiples of 16 px.
+// A block turns 128-pixel x 32-row panels into 32x32 tiles.  Lane l of wavefront w loads 16
+// pixels: row 8w + l/8 of the panel, 16-byte chunk l%8 of that row's 128-byte line -- so every
+// wavefront load instruction reads 8 whole lines, and kPackRows of them are in flight per lane.
+// 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per dword), neighbouring lanes
+// join their halves with one shuffle, and the even lanes store the tile words.
+__device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
+    uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
+    return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
+}
+
+// (Measured: 44-50 us for 72 masks of 1440x1080 whatever ROWS is, and the same for a band form
+// reading whole rows contiguously.  tools/probes/read_probe.hip: a plain read of those 112 MB
+// takes 41 us when they come from HBM -- every step writes 0.5 GB of labels in between, so they
+// do -- and 19 us from the Infinity Cache.  The kernel sits on the cold-read floor.)
+// A batch of 1-byte masks to pack: slots [slot0, slot0 + nslots) of the packed arena, slot s taking
+// the raw view order[s] (the views of a fused carve are packed in the order they will be applied,
+// so that the first few can be packed ahead and the rest beside the dense stage).
+constexpr int kPackOrderMax = 256;
+struct PackJob {
+    const uint8_t *raw;
+    int64_t row_stride, view_stride;
+    int32_t W, H, tiles_x, tiles_y;
+    uint32_t *out;
+    int64_t out_view_words;
+    uint32_t flip;      // 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
+    int32_t use_order;  // 0: slot s takes raw view s
+    uint8_t *occ;
+    int32_t slot0, nslots;
+    uint16_t order[kPackOrderMax];
+};
+
+template <int ROWS>  // tile rows per block: that many 16-byte loads in flight per lane
+__device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
+    __shared__ uint32_t occ_s[ROWS * 4], hole_s[ROWS * 4];
+    const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
+    const uint32_t flip = pj.flip;
+    const int lane = threadIdx.x & 63;
+    const int txb = (tiles_x + 3) >> 2;            // panels per tile row
+    const int tyb = (tiles_y + ROWS - 1) / ROWS;   // block rows per view
+    int bx = (int)(b % (uint32_t)txb);
+    uint32_t r = b / (uint32_t)txb;
+    int by = (int)(r % (uint32_t)tyb);
+    int slot = (int)(r / (uint32_t)tyb);
+    if (slot >= pj.nslots) return;  // block-uniform
+    slot += pj.slot0;
+    const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
+    const uint8_t *raw = pj.raw + view * pj.view_stride;
+    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = hole_s[threadIdx.x] = 0;
+    int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
+    int c = lane & 7;                                      // 16-pixel chunk inside the panel
+    int u0 = bx * 128 + c * 16;
+    int tx = bx * 4 + (c >> 1);
+    uint4 q[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        int v = (by * ROWS + k) * 32 + row;
+        q[k] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
+        if (v < H && u0 < W)  // W % 16 == 0: a 16-pixel run is inside the row or outside it
+            q[k] = *reinterpret_cast<const uint4 *>(raw + (int64_t)v * pj.row_stride + u0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        int ty = by * ROWS + k;
+        uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
+                        (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
+        uint32_t other = __shfl_xor(half, 1);
+        uint32_t word = half | (other << 16);
+        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
+            pj.out[(int64_t)slot * pj.out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
+            if (word) occ_s[k * 4 + (c >> 1)] = 1;  // racing stores of the same value
+            if (~word) hole_s[k * 4 + (c >> 1)] = 1;  // some background (padding counts as such)
+        }
+    }
+    __syncthreads();
+    // tile occupancy: bit 0 = some foreground, bit 1 = nothing but foreground; every byte is
+    // written here, nothing for the host to clear
+    if (threadIdx.x < ROWS * 4) {
+        int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
+        if (ty < tiles_y && txo < tiles_x)
+            pj.occ[(int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] =
+                (occ_s[threadIdx.x] ? 1 : 0) | (hole_s[threadIdx.x] ? 0 : 2);
+    }
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(kBlock) void pack16_kernel(PackJob pj) {
+    pack16_block<ROWS>(pj, blockIdx.x);
+}
+
 // ---- brick form of the dense stage -------------------------------------------------------
 // A block takes a BRICK of 16 columns (along y) x 64 voxels (along z) instead of 1024 consecutive
 // voxels (bricks at the far y / z faces may stick out of the grid; any ny, nz with nz <= 4096): wavefront w owns columns 4w..4w+3, lane l the
@@ -455,7 +557,7 @@ struct DescCopy { const uint32_t *src; uint32_t *dst; uint32_t words; };
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
-    FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall) {
+    FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch) {
     __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves];
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
@@ -519,7 +621,8 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     if (nall <= 0) cand = 0;  // fullness not asked for
     if (wave != 0) return;
     const bool dead = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
-    if (valid) flags[lb] = dead ? 1 : (kept ? 2 : 0);
+    // kept by every view of the batch: FULL (2); by every view packed so far only: a candidate (3)
+    if (valid) flags[lb] = dead ? 1 : (kept ? (nall >= nbatch ? 2 : 3) : 0);
     // the bricks left go on the live list, one atomic per block
     const bool alive = valid && !dead && !kept;
     const unsigned long long m = __ballot(alive);
@@ -674,20 +777,44 @@ struct Fill {
 
 __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
                                                     const uint8_t *__restrict__ flags, uint32_t strip,
-                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
+                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill,
+                                                    const Confirm &cf) {
+    __shared__ int s_whole;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
     const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
     const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
-    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
-    if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
-    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
+    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u), cand = __ballot(f == 3u);
+    const bool mine = j < g.ny;  // a strip at the far y face may stick out of the grid
+    int32_t *col = labels + ((uint64_t)il * g.ny + (mine ? j : 0u)) * g.nz;
     const bool vec = (g.nz & 3u) == 0;
     for (uint32_t bz = 0; bz < bricks_z; ++bz) {
-        const bool isfull = (full >> bz) & 1ull;
+        bool isfull = (full >> bz) & 1ull;
+        if ((cand >> bz) & 1ull) {  // block-uniform: every wavefront read the same flags
+            if (wave == 0) {
+                const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+                bool whole = true;
+                for (int base = cf.v0; base < cf.v1; base += 64) {  // one lane per remaining view
+                    const int vi = base + (int)lane;
+                    bool keeps = true;
+                    if (vi < cf.v1) {
+                        const ViewDesc d = cf.views[vi];
+                        keeps = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x) == 2u;
+                    }
+                    whole &= __ballot(!keeps) == 0;
+                }
+                if (lane == 0) {
+                    s_whole = whole ? 1 : 0;
+                    if (!whole) cf.late[atomicAdd(&cf.ctl->nlate, 1u)] = strip * bricks_z + bz;
+                }
+            }
+            __syncthreads();
+            isfull = s_whole != 0;
+            __syncthreads();  // s_whole is free for the next candidate
+        }
         if (!((culled >> bz) & 1ull) && !isfull) continue;
         const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
-        if (k0 >= g.nz) continue;
+        if (!mine || k0 >= g.nz) continue;
         const uint32_t n = min(4u, g.nz - k0);
         if (!isfull || fill.fresh) {
             const int32_t val = isfull ? fill.kept : -1;
@@ -719,10 +846,21 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
                                                              uint32_t bricks_y, uint32_t bricks_z,
                                                              const uint8_t *__restrict__ flags,
                                                              const uint32_t *__restrict__ live,
-                                                             const ListCtl *ctl, uint32_t nwalkers) {
+                                                             const ListCtl *ctl, uint32_t nwalkers,
+                                                             uint32_t nstore, PackJob ride, int pack_rows) {
+    if (blockIdx.x >= nwalkers + nstore) {
+        // riders: the masks of the views the later stages apply are packed here, beside the walkers
+        // (this stage waits on gathers and arithmetic, the packing on HBM reads)
+        const uint32_t b = blockIdx.x - nwalkers - nstore;
+        if (pack_rows == 1) pack16_block<1>(ride, b);
+        else if (pack_rows == 2) pack16_block<2>(ride, b);
+        else if (pack_rows == 8) pack16_block<8>(ride, b);
+        else pack16_block<4>(ride, b);
+        return;
+    }
     if (blockIdx.x >= nwalkers) {
         store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
-                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0});
+                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0}, Confirm{nullptr, 0, 0, nullptr, nullptr});
         return;
     }
     const uint32_t nlive = ctl->nlive;
@@ -803,7 +941,7 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
     const uint32_t nbid = split ? gridDim.x - (cs.nstrips - cs.first) : gridDim.x;
     if (split && blockIdx.x >= nbid) {
         store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z,
-                            Fill{cs.kept, cs.fresh});
+                            Fill{cs.kept, cs.fresh}, cs.cf);
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
@@ -917,23 +1055,56 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
 
 // Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
 // nothing), a persistent grid applies the remaining views densely instead.
+struct LateBricks {           // FULL candidates that turned out not to be (see Confirm)
+    const uint32_t *late;     // null: the batch had no open candidates
+    const ViewDesc *allviews; // every view of the batch
+    const uint8_t *flags;
+    int32_t nall, init, fresh;
+    uint32_t bricks_y, bricks_z;
+};
+
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                               const ViewDesc *__restrict__ views,
                                                               int nviews, const ListCtl *ctl,
-                                                              ListCtl *next) {
+                                                              ListCtl *next, LateBricks lb) {
     // last kernel of a batch: leave the counters of the NEXT batch zeroed (the two blocks
     // alternate; nobody else touches that one now), so no memset sits on the stream
     if (next != nullptr) {
         uint32_t *z = reinterpret_cast<uint32_t *>(next);
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < sizeof(ListCtl) / 4; i += gridDim.x * kBlock) z[i] = 0u;
     }
-    if (!ctl->overflow) return;
     Append none{nullptr, nullptr, 0u, 0u};
+    if (lb.late != nullptr) {
+        // a brick some later view does not keep whole after all: every view, voxel by voxel
+        const uint32_t nlate = ctl->nlate;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const uint32_t per_plane = lb.bricks_y * lb.bricks_z;
+        for (uint32_t t = blockIdx.x; t < nlate; t += gridDim.x) {
+            const uint32_t id = lb.late[t];
+            const uint32_t il = id / per_plane;
+            const uint32_t rem = id - il * per_plane;
+            const uint32_t by = rem / lb.bricks_z, bz = rem - by * lb.bricks_z;
+            const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
+            if (lb.fresh) brick_voxels<true>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
+            else brick_voxels<false>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
+        }
+    }
+    if (!ctl->overflow) return;
     uint64_t nblk = (g.ngroups + kBlock - 1) / kBlock;
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         uint64_t grp = blk * kBlock + threadIdx.x;
-        if (grp < g.ngroups) {
+        bool skip = grp >= g.ngroups;
+        if (!skip && lb.late != nullptr) {
+            // candidates are settled elsewhere (kept whole by the store blocks, or carved above over
+            // ALL views by a block that may not have written them yet): not this pass's voxels
+            Vox4 vx;
+            decode_group(g, grp, vx);
+            const uint32_t col = (uint32_t)(vx.elem / g.nz), il = col / g.ny, j = col - il * g.ny;
+            skip = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ] == 3u;
+        }
+        // (a wavefront's lanes leave carve_group's view loop together: skipped lanes still vote)
+        if (grp < g.ngroups && !skip) {
             int4 pre = make_int4(0, 0, 0, 0);
             if (VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
             carve_group<false, VEC>(labels, g, views, nviews, 0, grp, pre, none);
@@ -1341,77 +1512,6 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
     }
 }
 
-// Mask ingest, fast form for 1-byte masks whose rows are 16-byte aligned multiples of 16 px.
-// A block turns 128-pixel x 32-row panels into 32x32 tiles.  Lane l of wavefront w loads 16
-// pixels: row 8w + l/8 of the panel, 16-byte chunk l%8 of that row's 128-byte line -- so every
-// wavefront load instruction reads 8 whole lines, and kPackRows of them are in flight per lane.
-// 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per dword), neighbouring lanes
-// join their halves with one shuffle, and the even lanes store the tile words.
-__device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
-    uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
-    return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
-}
-
-// (Measured: 44-50 us for 72 masks of 1440x1080 whatever ROWS is, and the same for a band form
-// reading whole rows contiguously.  tools/probes/read_probe.hip: a plain read of those 112 MB
-// takes 41 us when they come from HBM -- every step writes 0.5 GB of labels in between, so they
-// do -- and 19 us from the Infinity Cache.  The kernel sits on the cold-read floor.)
-template <int ROWS>  // tile rows per block: that many 16-byte loads in flight per lane
-__global__ __launch_bounds__(kBlock) void pack16_kernel(const uint8_t *__restrict__ raw,
-                                                        int64_t row_stride, int64_t view_stride,
-                                                        int W, int H, int nviews, int tiles_x,
-                                                        int tiles_y, uint32_t *__restrict__ out,
-                                                        int64_t out_view_words, uint32_t flip,
-                                                        uint8_t *__restrict__ occ) {
-    // flip: 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
-    __shared__ uint32_t occ_s[ROWS * 4], hole_s[ROWS * 4];
-    const int lane = threadIdx.x & 63;
-    const int txb = (tiles_x + 3) >> 2;            // panels per tile row
-    const int tyb = (tiles_y + ROWS - 1) / ROWS;   // block rows per view
-    int64_t b = blockIdx.x;
-    int bx = (int)(b % txb);
-    int64_t r = b / txb;
-    int by = (int)(r % tyb);
-    int view = (int)(r / tyb);
-    if (view >= nviews) return;  // block-uniform
-    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = hole_s[threadIdx.x] = 0;
-    int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
-    int c = lane & 7;                                      // 16-pixel chunk inside the panel
-    int u0 = bx * 128 + c * 16;
-    int tx = bx * 4 + (c >> 1);
-    uint4 q[ROWS];
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-        int v = (by * ROWS + k) * 32 + row;
-        q[k] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
-        if (v < H && u0 < W)  // W % 16 == 0: a 16-pixel run is inside the row or outside it
-            q[k] = *reinterpret_cast<const uint4 *>(raw + view * view_stride + (int64_t)v * row_stride + u0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-        int ty = by * ROWS + k;
-        uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
-                        (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
-        uint32_t other = __shfl_xor(half, 1);
-        uint32_t word = half | (other << 16);
-        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
-            out[view * out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
-            if (word) occ_s[k * 4 + (c >> 1)] = 1;  // racing stores of the same value
-            if (~word) hole_s[k * 4 + (c >> 1)] = 1;  // some background (padding counts as such)
-        }
-    }
-    __syncthreads();
-    // tile occupancy: bit 0 = some foreground, bit 1 = nothing but foreground; every byte is
-    // written here, nothing for the host to clear
-    if (threadIdx.x < ROWS * 4) {
-        int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
-        if (ty < tiles_y && txo < tiles_x)
-            occ[(int64_t)view * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] =
-                (occ_s[threadIdx.x] ? 1 : 0) | (hole_s[threadIdx.x] ? 0 : 2);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1486,6 +1586,16 @@ struct sc_engine {
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
+    int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
+                               // the flags kernel, the others beside the dense stage (0: all ahead)
+    int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
+    uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
+    struct DeferredBatch {     // sc_process_views_device batch whose packing waits for the flush
+        bool on = false;
+        const void *raw = nullptr;
+        int V = 0, H = 0, W = 0, dtype = 0;
+        int64_t row_stride = 0, view_stride = 0;
+    } deferred;
     int64_t flag_views = 8;    // views that may veto a brick (0 = all of the batch)
     float *lut_dev = nullptr;  // averaging: 256-entry byte -> float32 table (SC_MASK_U8_LUT)
 
@@ -1713,6 +1823,55 @@ size_t packed_words(int H, int W) {
     return tx * ty * 32;
 }
 
+PackJob make_pack_job(const void *raw_dev, int64_t row_stride, int64_t view_stride, int W, int H,
+                      uint32_t *packed, int64_t words, uint32_t flip, uint8_t *occ) {
+    PackJob pj;
+    memset(&pj, 0, sizeof pj);
+    pj.raw = static_cast<const uint8_t *>(raw_dev);
+    pj.row_stride = row_stride;
+    pj.view_stride = view_stride;
+    pj.W = W;
+    pj.H = H;
+    pj.tiles_x = (W + kTile - 1) / kTile;
+    pj.tiles_y = (H + kTile - 1) / kTile;
+    pj.out = packed;
+    pj.out_view_words = words;
+    pj.flip = flip;
+    pj.occ = occ;
+    return pj;
+}
+
+int64_t pack16_blocks(const sc_engine *e, const PackJob &pj) {
+    const int rows = (int)e->pack_rows;
+    return (int64_t)pj.nslots * ((pj.tiles_y + rows - 1) / rows) * ((pj.tiles_x + 3) / 4);
+}
+
+// slots [pj.slot0, pj.slot0 + pj.nslots) as a launch of their own
+int launch_pack16(sc_engine *e, const PackJob &pj) {
+    if (pj.nslots <= 0) return SC_OK;
+    const int rows = (int)e->pack_rows;
+    int64_t blocks = pack16_blocks(e, pj);
+    if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+#define LAUNCH_PACK16(ROWS) \
+    hipLaunchKernelGGL(pack16_kernel<ROWS>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, pj)
+    if (rows == 1) LAUNCH_PACK16(1);
+    else if (rows == 2) LAUNCH_PACK16(2);
+    else if (rows == 8) LAUNCH_PACK16(8);
+    else LAUNCH_PACK16(4);
+#undef LAUNCH_PACK16
+    HIP_TRY(hipGetLastError());
+    return SC_OK;
+}
+
+bool pack16_eligible(const void *raw_dev, int W, int dtype, int64_t row_stride, int64_t view_stride) {
+    return dtype != SC_MASK_I32 && (W % 16) == 0 && (row_stride % 16) == 0 && (view_stride % 16) == 0 &&
+           (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
+}
+
+uint32_t pack_flip(int dtype) {
+    return dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
+}
+
 // raw device pixels [V][H][W] -> packed tiles in the arena; appends V pending views
 int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const float *t,
                  const void *raw_dev, int H, int W, int dtype, int64_t row_stride,
@@ -1731,24 +1890,17 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     if (rc) return rc;
     LaunchTimer lt{e, SC_KERNEL_PACK};
     bool bytes = dtype != SC_MASK_I32;
-    uint32_t flip = dtype == SC_MASK_U8_INV ? 0xffffffffu : dtype == SC_MASK_BOOL_INV ? 0x01010101u : 0u;
-    bool fast = bytes && (W % 16) == 0 && (row_stride % 16) == 0 &&
-                (view_stride % 16) == 0 && (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
+    uint32_t flip = pack_flip(dtype);
+    bool fast = pack16_eligible(raw_dev, W, dtype, row_stride, view_stride);
     if (fast) {
-        const int rows = (int)e->pack_rows;
-        int64_t blocks = (int64_t)V * ((tiles_y + rows - 1) / rows) * ((tiles_x + 3) / 4);
-        if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+        PackJob pj = make_pack_job(raw_dev, row_stride, view_stride, W, H, static_cast<uint32_t *>(packed),
+                                   (int64_t)words, flip, occ);
+        pj.slot0 = 0;
+        pj.nslots = V;
         rc = lt.begin();
         if (rc) return rc;
-#define LAUNCH_PACK16(ROWS)                                                                      \
-    hipLaunchKernelGGL(pack16_kernel<ROWS>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,   \
-                       static_cast<const uint8_t *>(raw_dev), row_stride, view_stride, W, H, V,   \
-                       tiles_x, tiles_y, static_cast<uint32_t *>(packed), (int64_t)words, flip, occ)
-        if (rows == 1) LAUNCH_PACK16(1);
-        else if (rows == 2) LAUNCH_PACK16(2);
-        else if (rows == 8) LAUNCH_PACK16(8);
-        else LAUNCH_PACK16(4);
-#undef LAUNCH_PACK16
+        rc = launch_pack16(e, pj);
+        if (rc) return rc;
     } else {
         // the slow forms only ever set occupancy bytes
         HIP_TRY(hipMemsetAsync(occ, 0, occ_bytes * (size_t)V, e->stream));
@@ -1837,8 +1989,12 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
 // sign: opposite cameras see mirrored silhouettes).  Perpendicular silhouettes intersect in the
 // smallest volume, so almost everything is carved by the first two views.  Legal because the
 // carve state is order-independent; `average` never re-orders.
-void order_views(std::vector<ViewDesc> &v) {
+void order_views(std::vector<ViewDesc> &v, std::vector<uint32_t> *perm = nullptr) {
     size_t n = v.size();
+    if (perm) {
+        perm->resize(n);
+        for (size_t q = 0; q < n; ++q) (*perm)[q] = (uint32_t)q;
+    }
     if (n < 3 || n > 4096) return;
     std::vector<float> worst(n, 0.0f);
     std::vector<char> used(n, 0);
@@ -1848,6 +2004,7 @@ void order_views(std::vector<ViewDesc> &v) {
     for (size_t step = 0; step < n; ++step) {
         used[cur] = 1;
         out.push_back(v[cur]);
+        if (perm) (*perm)[step] = (uint32_t)cur;
         const float *a = v[cur].R + 6;
         size_t best = n;
         for (size_t q = 0; q < n; ++q) {
@@ -1881,7 +2038,7 @@ int ensure_ctl(sc_engine *e) {
         nbricks = (size_t)e->planes * (size_t)((e->ny + kBrickY - 1) / kBrickY) * (size_t)((e->nz + kBrickZ - 1) / kBrickZ);
     char *base = nullptr;
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + nbricks * sizeof(uint32_t) + 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + 2 * nbricks * sizeof(uint32_t) + 16));
     HIP_TRY(hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream));
     e->ctl2[0] = reinterpret_cast<ListCtl *>(base);
     e->ctl2[1] = e->ctl2[0] + 1;
@@ -1890,13 +2047,137 @@ int ensure_ctl(sc_engine *e) {
     e->ctl = e->ctl2[0];
     e->flags = reinterpret_cast<uint8_t *>(base + 2 * sizeof(ListCtl));
     e->live = reinterpret_cast<uint32_t *>(base + 2 * sizeof(ListCtl) + flag_bytes);
+    e->late = e->live + nbricks;
     return SC_OK;
+}
+
+// Arena storage for the deferred device batch: slot q of the packed tiles / occupancy bytes goes to
+// pending view q.  Returns the job that packs it (no slots chosen yet).
+int deferred_job(sc_engine *e, PackJob *out) {
+    const auto &db = e->deferred;
+    size_t words = packed_words(db.H, db.W);
+    void *packed = nullptr, *occ_v = nullptr;
+    int rc = arena_alloc(e, words * 4 * (size_t)db.V, &packed);
+    if (rc) return rc;
+    const size_t occ_bytes = (size_t)((db.W + kTile - 1) / kTile) * (size_t)((db.H + kTile - 1) / kTile);
+    rc = arena_alloc(e, occ_bytes * (size_t)db.V, &occ_v);
+    if (rc) return rc;
+    for (int q = 0; q < db.V; ++q) {
+        e->pending[(size_t)q].mask = static_cast<uint32_t *>(packed) + (size_t)q * words;
+        e->pending[(size_t)q].occ = static_cast<uint8_t *>(occ_v) + (size_t)q * occ_bytes;
+    }
+    *out = make_pack_job(db.raw, db.row_stride, db.view_stride, db.W, db.H, static_cast<uint32_t *>(packed),
+                         (int64_t)words, pack_flip(db.dtype), static_cast<uint8_t *>(occ_v));
+    return SC_OK;
+}
+
+// Pack the deferred batch now, in the order given, all of it ahead of any carve kernel.
+int materialize_deferred(sc_engine *e) {
+    if (!e->deferred.on) return SC_OK;
+    PackJob pj;
+    int rc = deferred_job(e, &pj);
+    if (rc) return rc;
+    e->deferred.on = false;
+    pj.slot0 = 0;
+    pj.nslots = e->deferred.V;
+    rc = step_begin(e);
+    if (rc) return rc;
+    LaunchTimer lt{e, SC_KERNEL_PACK};
+    rc = lt.begin();
+    if (rc) return rc;
+    rc = launch_pack16(e, pj);
+    if (rc) return rc;
+    return lt.end();
+}
+
+// What a fused carve of `nv` views will look like (see flush): decided before anything is launched,
+// because a deferred batch is packed according to it.
+struct FusedPlan {
+    int ndense, nstage1, s1, flag_views;
+    bool compact, brick, defer_stores;
+    uint32_t bys, bzs, nbricks, nstrips, dense_store_strips;
+};
+
+FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
+    FusedPlan p{};
+    p.ndense = (int)e->dense_views;
+    p.nstage1 = (int)e->stage1_views;
+    p.compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)p.ndense &&
+                (uint64_t)e->n < 0x80000000ull;
+    p.bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY);
+    p.bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
+    p.brick = nv > 1 && e->brick && p.bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
+              (uint64_t)e->planes * p.bys * p.bzs < 0x80000000ull && has_occ;
+    p.nbricks = p.brick ? (uint32_t)((uint64_t)e->planes * p.bys * p.bzs) : 0u;
+    p.flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
+    if (e->flag_views > 0 && e->flag_views < (int64_t)p.flag_views) p.flag_views = (int)e->flag_views;
+    p.s1 = (int)std::min<size_t>(nv, (size_t)p.ndense + (size_t)p.nstage1);
+    // the -1 fill of empty bricks rides along with the list stages when there are any: strips
+    // [0, dense_store_strips) are filled by the dense kernel's store blocks, the others by the list
+    // stages' (defer_share sixteenths of them)
+    p.nstrips = p.brick ? (uint32_t)((uint64_t)e->planes * p.bys) : 0u;
+    p.dense_store_strips = p.nstrips;
+    if (p.brick && p.compact && e->defer_stores > 0 && e->defer_share > 0)
+        p.dense_store_strips = (uint32_t)((uint64_t)p.nstrips * (uint64_t)(16 - e->defer_share) / 16u);
+    p.defer_stores = p.dense_store_strips < p.nstrips;
+    return p;
 }
 
 // Launch the first `count` pending views (count == 0: all of them).
 int flush(sc_engine *e, size_t count = 0) {
     if (e->pending.empty()) return SC_OK;
     size_t nv = count ? std::min(count, e->pending.size()) : e->pending.size();
+    // A device batch whose packing was deferred is packed here, in the order its views will be
+    // applied: the views the flags kernel, the dense stage and the first survivor stage need go
+    // ahead, the others ride beside the dense stage (brick form).  Any other shape of launch packs
+    // the whole batch first, in the order given.
+    bool ordered = false;
+    PackJob ride;
+    memset(&ride, 0, sizeof ride);
+    uint32_t ride_blocks = 0;
+    int packed_ahead = (int)nv;
+    if (e->deferred.on) {
+        const bool whole = nv == e->pending.size() && nv == (size_t)e->deferred.V && e->mode == SC_MODE_CARVE && nv > 1;
+        if (!whole) {
+            int rcd = materialize_deferred(e);
+            if (rcd) return rcd;
+        } else {
+            int rcd = step_begin(e);
+            if (rcd) return rcd;
+            std::vector<uint32_t> perm;
+            if (e->view_order == 1) order_views(e->pending, &perm);
+            else { perm.resize(nv); for (size_t q = 0; q < nv; ++q) perm[q] = (uint32_t)q; }
+            ordered = true;
+            PackJob pj;
+            rcd = deferred_job(e, &pj);
+            if (rcd) return rcd;
+            e->deferred.on = false;
+            pj.use_order = 1;
+            for (size_t q = 0; q < nv; ++q) pj.order[q] = (uint16_t)perm[q];
+            const FusedPlan fp = fused_plan(e, nv, true);
+            int ahead = (int)nv;
+            if (e->pack_ride && fp.brick && fp.compact && fp.defer_stores && fp.dense_store_strips == 0)
+                ahead = std::min<int>((int)nv, std::max(fp.flag_views, fp.s1));
+            pj.slot0 = 0;
+            pj.nslots = ahead;
+            LaunchTimer ltp{e, SC_KERNEL_PACK};
+            rcd = ltp.begin();
+            if (rcd) return rcd;
+            rcd = launch_pack16(e, pj);
+            if (rcd) return rcd;
+            rcd = ltp.end();
+            if (rcd) return rcd;
+            if (ahead < (int)nv) {
+                ride = pj;
+                ride.slot0 = ahead;
+                ride.nslots = (int)nv - ahead;
+                int64_t rb = pack16_blocks(e, ride);
+                if (rb > 0x3fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+                ride_blocks = (uint32_t)rb;
+                packed_ahead = ahead;
+            }
+        }
+    }
     GridDesc g = grid_desc(e);
     uint64_t blocks = (g.ngroups + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
@@ -1908,7 +2189,7 @@ int flush(sc_engine *e, size_t count = 0) {
         if (rcs) return rcs;
     }
     if (nv > 1) {
-        if (e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
+        if (!ordered && e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
             order_views(e->pending);
         // descriptor ring: slots are reused only after a wrap, which waits for the stream
         if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
@@ -1947,31 +2228,19 @@ int flush(sc_engine *e, size_t count = 0) {
         int32_t *st = static_cast<int32_t *>(e->state);
         int32_t init = init_bits_i32(e);
         // fused carve with survivor compaction: dense for the first `ndense` views, then lists
-        const int ndense = (int)e->dense_views, nstage1 = (int)e->stage1_views;
+        const FusedPlan fp = fused_plan(e, nv, one.occ != nullptr);
+        const int ndense = fp.ndense, nstage1 = fp.nstage1, flag_views = fp.flag_views;
         const uint32_t list_blocks = (uint32_t)e->list_blocks;
-        bool compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)ndense &&
-                       (uint64_t)e->n < 0x80000000ull;
+        const bool compact = fp.compact, brick = fp.brick, defer_stores = fp.defer_stores;
         Append ap{nullptr, nullptr, 0u, 0u};
         int dense_views = (int)nv;
-        const uint32_t bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
-        bool brick = nv > 1 && e->brick && bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
-                     (uint64_t)e->planes * bys * bzs < 0x80000000ull && one.occ != nullptr;
-        const uint32_t nbricks = brick ? (uint32_t)((uint64_t)e->planes * bys * bzs) : 0u;
-        int flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
-        if (e->flag_views > 0 && e->flag_views < (int64_t)flag_views) flag_views = (int)e->flag_views;
+        const uint32_t bys = fp.bys, bzs = fp.bzs, nbricks = fp.nbricks, nstrips = fp.nstrips;
+        const uint32_t dense_store_strips = fp.dense_store_strips;
         const bool desc_by_flags = brick && flag_views <= kFlagWaves;
         if (!desc_by_flags) {
             rc = upload_desc();
             if (rc) return rc;
         }
-        // the -1 fill of empty bricks rides along with the final list stage when there is one
-        const uint32_t nstrips = brick ? (uint32_t)((uint64_t)e->planes * bys) : 0u;
-        // strips [0, dense_store_strips) are filled by the dense kernel's store blocks, the others
-        // by the final list stage's (defer_share sixteenths of them, when there is such a stage)
-        uint32_t dense_store_strips = nstrips;
-        if (brick && compact && e->defer_stores > 0 && e->defer_share > 0)
-            dense_store_strips = (uint32_t)((uint64_t)nstrips * (uint64_t)(16 - e->defer_share) / 16u);
-        const bool defer_stores = dense_store_strips < nstrips;
         if (compact || brick) {
             rc = ensure_ctl(e);
             if (rc) return rc;
@@ -2009,8 +2278,10 @@ int flush(sc_engine *e, size_t count = 0) {
 #undef LAUNCH_CARVE1
         } else {
             if (brick) {
-                const uint32_t nwalkers = ((uint32_t)e->list_blocks + 7u) & ~7u;  // whole groups of 8 XCDs
-                dim3 bgrid(nwalkers + dense_store_strips);  // live-list walkers, then store blocks
+                // live-list walkers (whole groups of 8 XCDs), then store blocks, then packing riders; with
+                // riders the walkers leave wavefront slots free for them
+                const uint32_t nwalkers = ((uint32_t)(ride_blocks ? e->brick_walkers : e->list_blocks) + 7u) & ~7u;
+                dim3 bgrid(nwalkers + dense_store_strips + ride_blocks);
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
@@ -2026,17 +2297,19 @@ int flush(sc_engine *e, size_t count = 0) {
                 hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
                                    flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
-                                   desc_by_flags ? vpin : vd, e->full_bricks ? (int)nv : 0);
+                                   desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv);
                 rc = ltf.end();
                 if (rc) return rc;
                 rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
                 if (rc) return rc;
                 if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers);
+                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
+                                       dense_store_strips, ride, (int)e->pack_rows);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers);
+                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
+                                       dense_store_strips, ride, (int)e->pack_rows);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -2059,7 +2332,10 @@ int flush(sc_engine *e, size_t count = 0) {
             rc = lt2.begin();
             if (rc) return rc;
             int vg = (int)e->view_group;
-            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0}, cs = none;
+            // open FULL candidates exist only when packing rode beside the dense stage
+            const Confirm cf = ride_blocks ? Confirm{vd, packed_ahead, (int32_t)nv, e->late, e->ctl}
+                                           : Confirm{nullptr, 0, 0, nullptr, nullptr};
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, Confirm{nullptr, 0, 0, nullptr, nullptr}}, cs = none;
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
             dim3 fgrid(list_blocks);
@@ -2070,10 +2346,10 @@ int flush(sc_engine *e, size_t count = 0) {
                 uint32_t mid = dense_store_strips;
                 if ((size_t)s1 < nv && e->stage1_store_share > 0) {
                     mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
-                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0};
+                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf};
                     grid1 = dim3((uint32_t)e->stage1_list_blocks + (mid - dense_store_strips));
                 }
-                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0};
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf};
                 fgrid = dim3((uint32_t)e->defer_stores + (nstrips - mid));
             }
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
@@ -2097,12 +2373,13 @@ int flush(sc_engine *e, size_t count = 0) {
             }
             // the resume kernel is also what zeroes the next batch's counters
             e->ctl_clean[e->ctl_idx ^ 1] = true;
+            const LateBricks late{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
             if (vec)
                 hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1]);
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
             else
                 hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1]);
+                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
             HIP_TRY(hipGetLastError());
             rc = lt2.end();
             if (rc) return rc;
@@ -2339,6 +2616,7 @@ int sc_clear(sc_engine *e) {
     int rc = use_device(e);
     if (rc) return rc;
     e->pending.clear();
+    e->deferred.on = false;
     arena_reset(e);
     if (e->step_open) {  // the views of an open SC_KERNEL_STEP window are gone: no sample for them
         e->event_pool.push_back(e->step_start);
@@ -2411,6 +2689,13 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
                 return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
             e->pack_rows = value;
             return SC_OK;
+        case SC_OPT_PACK_RIDE:
+            e->pack_ride = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_BRICK_WALKERS:
+            if (value < 8 || value > 65536) return fail(SC_ERR_INVALID, "brick_walkers must be in [8, 65536]");
+            e->brick_walkers = value;
+            return SC_OK;
         case SC_OPT_FLAG_VIEWS:
             if (value < 0) return fail(SC_ERR_INVALID, "flag_views must be >= 0");
             e->flag_views = value;
@@ -2478,6 +2763,8 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
     rc = check_dtype(e, mask_dtype);
     if (rc) return rc;
     rc = use_device(e);
+    if (rc) return rc;
+    rc = materialize_deferred(e);  // a device batch waiting for its flush: packed now, order as given
     if (rc) return rc;
     size_t es = elem_size(mask_dtype);
     size_t row = (size_t)W * es;
@@ -2549,9 +2836,26 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
     if (rc) return rc;
     rc = use_device(e);
     if (rc) return rc;
+    rc = materialize_deferred(e);
+    if (rc) return rc;
     size_t es = elem_size(mask_dtype);
     int64_t row = (int64_t)W * (int64_t)es, view = row * H;
     if (e->mode == SC_MODE_CARVE) {
+        if (e->pack_ride && e->views_per_launch == 0 && e->pending.empty() && V >= kMinFusedViews &&
+            V <= kPackOrderMax && V < e->max_pending && pack16_eligible(masks_dev, W, mask_dtype, row, view)) {
+            // the whole batch will be one fused launch: its packing waits for the flush, which knows
+            // the order of the views (see flush)
+            e->deferred.on = true;
+            e->deferred.raw = masks_dev;
+            e->deferred.V = V; e->deferred.H = H; e->deferred.W = W; e->deferred.dtype = mask_dtype;
+            e->deferred.row_stride = row; e->deferred.view_stride = view;
+            for (int q = 0; q < V; ++q) {
+                ViewDesc d;
+                fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, nullptr, H, W, nullptr);
+                e->pending.push_back(d);
+            }
+            return SC_OK;
+        }
         // one pack launch for the whole batch, then carve launches per views_per_launch
         rc = enqueue_pack(e, V, K, R, t, masks_dev, H, W, mask_dtype, row, view);
         if (rc) return rc;

@@ -782,3 +782,89 @@ def test_random_geometry_carve_and_average(gpu_device, seed):
     for vpl in (0, 1):
         gotf = hip_average(shape, origin, vs, fviews, default_value=0.5, views_per_launch=vpl)
         assert np.array_equal(gotf.view(np.uint32), wantf.view(np.uint32)), (seed, vpl, shape)
+
+
+# -- device batches: packing at flush, riders beside the dense stage, open FULL candidates -------------
+def _device_batch_carve(shape, origin, vs, views, opts=(), default_value=0, preload=None):
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=float(default_value))
+    for k, v in opts:
+        e.set_option(k, v)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    V, H, W = stack.shape
+    if preload is not None:  # a stored (non-fresh) volume: some views applied one by one first
+        for Kq, Rq, tq, m in preload:
+            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+        e.synchronize()
+    e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+    out = e.get_values()
+    counts = e.fused_counts()
+    e.dev_free(ptr)
+    e.close()
+    return out, counts
+
+
+@pytest.mark.parametrize("ride", [1, 0])
+@pytest.mark.parametrize("kind,shape,v", [("plant", (24, 48, 128), 14), ("solid", (10, 32, 128), 16),
+                                          ("dense", (20, 48, 192), 18), ("noise", (6, 16, 64), 12),
+                                          ("plant", (9, 37, 131), 13)])
+def test_device_batch_packed_at_flush_equals_oracle(gpu_device, ride, kind, shape, v):
+    _, origin, vs, views = scene(shape, v, kind)
+    want = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    for walkers in (1024, 8):
+        got, _ = _device_batch_carve(shape, origin, vs, views,
+                                     opts=((nat.SC_OPT_PACK_RIDE, ride), (nat.SC_OPT_BRICK_WALKERS, walkers)))
+        assert np.array_equal(got, want), (kind, ride, walkers, histogram3(got), histogram3(want))
+
+
+@pytest.mark.parametrize("odd", [0, 3, 7, 11, 13])
+@pytest.mark.parametrize("default_value", [0, 5])
+def test_full_candidates_rejected_by_a_late_view(gpu_device, odd, default_value):
+    """Every view but one keeps every brick whole (all-foreground pictures); the odd one carves half
+    of the volume.  Whether it is among the views packed ahead (and seen by the flags kernel) or among
+    the riders (the store blocks' confirmation, then the resume kernel's late bricks), the labels are
+    the oracle's -- on a fresh volume and on a stored one."""
+    shape, origin, vs, views = scene((12, 48, 128), 14, "solid")
+    views = [list(v) for v in views]
+    half = views[odd][3].copy()
+    half[:, : half.shape[1] // 2] = 0
+    half[200:260, :] = 0
+    views[odd][3] = half
+    views = [tuple(v) for v in views]
+    want = oracle_c.carve(list(shape), origin, vs, views, default_value, nthreads=4)
+    assert 0 < (want == -1).sum() < want.size
+    got, _ = _device_batch_carve(shape, origin, vs, views, default_value=default_value)
+    assert np.array_equal(got, want), (odd, histogram3(got), histogram3(want))
+    # stored volume: two of the views were applied before the batch arrives
+    got, _ = _device_batch_carve(shape, origin, vs, views, default_value=default_value, preload=views[4:6])
+    assert np.array_equal(got, want), (odd, "stored")
+    # a survivor list that overflows while candidates are open
+    got, _ = _device_batch_carve(shape, origin, vs, views, default_value=default_value,
+                                 opts=((nat.SC_OPT_FULL_BRICKS, 1), (nat.SC_OPT_FLAG_VIEWS, 2)))
+    assert np.array_equal(got, want), (odd, "flag_views 2")
+
+
+def test_device_batch_then_more_views_before_the_flush(gpu_device):
+    """A deferred device batch followed by host views (or a second batch) is packed in the order
+    given and carved with them."""
+    shape, origin, vs, views = scene((16, 32, 64), 12, "plant")
+    want = oracle_c.carve(list(shape), origin, vs, views)
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views[:8]]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    e.process_views_device(K[:8], R[:8], t[:8], ptr, 8, *stack.shape[1:], nat.SC_MASK_U8)
+    for Kq, Rq, tq, m in views[8:]:
+        e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), want)
+    e.clear()
+    e.process_views_device(K[:8], R[:8], t[:8], ptr, 8, *stack.shape[1:], nat.SC_MASK_U8)
+    e.clear()  # dropped before it was ever packed
+    e.process_views_device(K[:8], R[:8], t[:8], ptr, 8, *stack.shape[1:], nat.SC_MASK_U8)
+    e.process_views_device(K[:8], R[:8], t[:8], ptr, 8, *stack.shape[1:], nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), oracle_c.carve(list(shape), origin, vs, views[:8]))
+    e.dev_free(ptr)
+    e.close()
