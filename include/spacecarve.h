@@ -97,6 +97,9 @@ extern "C" {
                                      is packed when it is launched, in the order its views are applied: the
                                      first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
 #define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
+#define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
+                                     that many persistent blocks walking the strips (512 = two per CU: a
+                                     wavefront's stores do not hold it up, so few keep the write path busy) */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

@@ -113,6 +113,7 @@ struct CullStores {
     uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
     int32_t kept, fresh;   // see Fill
     Confirm cf;
+    uint32_t fill_blocks;  // 0: one store block per strip; n: n persistent store blocks
 };
 
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
@@ -840,7 +841,7 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
 // the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
 // stage fills the others, see carve_list_kernel).
 template <bool FRESH>
-__global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
                                                              uint32_t bricks_y, uint32_t bricks_z,
@@ -850,7 +851,8 @@ __global__ __launch_bounds__(kBlock) void carve_brick_kernel(int32_t *__restrict
                                                              uint32_t nstore, PackJob ride, int pack_rows) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
-        // (this stage waits on gathers and arithmetic, the packing on HBM reads)
+        // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
+        // panel: persistent riders measured the same or slower.
         const uint32_t b = blockIdx.x - nwalkers - nstore;
         if (pack_rows == 1) pack16_block<1>(ride, b);
         else if (pack_rows == 2) pack16_block<2>(ride, b);
@@ -923,8 +925,10 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
 //     are many more items than wavefronts (no tail); groups of one chunk may run concurrently
 //     on different wavefronts, which is exact because a carve is a plain store of -1 (final,
 //     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
+// (at most 80 SGPRs: with 82-96 the CU admits 7 such blocks instead of 8, with 98+ only 6 --
+// MI355X_MICROARCH.md, "Residency" -- and the store blocks need the slots the list blocks leave)
 template <bool FINAL>
-__global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                             const ViewDesc *__restrict__ views,
                                                             int nviews,
                                                             const uint32_t *__restrict__ lin,
@@ -938,10 +942,14 @@ __global__ __launch_bounds__(kBlock) void carve_list_kernel(int32_t *__restrict_
     // kernel found empty by HBM writes, so the two run side by side instead of one after the
     // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
     const bool split = cs.flags != nullptr;
-    const uint32_t nbid = split ? gridDim.x - (cs.nstrips - cs.first) : gridDim.x;
+    const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : cs.nstrips - cs.first) : 0u;
+    const uint32_t nbid = gridDim.x - nstore;
     if (split && blockIdx.x >= nbid) {
-        store_culled_bricks(labels, g, cs.flags, cs.first + (blockIdx.x - nbid), cs.bricks_y, cs.bricks_z,
-                            Fill{cs.kept, cs.fresh}, cs.cf);
+        // one short block per strip, or (fill_blocks > 0) that many blocks walking the strips: a
+        // wavefront's stores do not hold it up, so few of them keep the write path busy and the
+        // wavefront slots go to the list blocks
+        for (uint32_t strip = cs.first + (blockIdx.x - nbid); strip < cs.nstrips; strip += nstore)
+            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh}, cs.cf);
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
@@ -1586,6 +1594,7 @@ struct sc_engine {
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
+    int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
@@ -2335,7 +2344,7 @@ int flush(sc_engine *e, size_t count = 0) {
             // open FULL candidates exist only when packing rode beside the dense stage
             const Confirm cf = ride_blocks ? Confirm{vd, packed_ahead, (int32_t)nv, e->late, e->ctl}
                                            : Confirm{nullptr, 0, 0, nullptr, nullptr};
-            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, Confirm{nullptr, 0, 0, nullptr, nullptr}}, cs = none;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, Confirm{nullptr, 0, 0, nullptr, nullptr}, 0u}, cs = none;
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
             dim3 fgrid(list_blocks);
@@ -2346,31 +2355,30 @@ int flush(sc_engine *e, size_t count = 0) {
                 uint32_t mid = dense_store_strips;
                 if ((size_t)s1 < nv && e->stage1_store_share > 0) {
                     mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
-                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf};
-                    grid1 = dim3((uint32_t)e->stage1_list_blocks + (mid - dense_store_strips));
+                    const uint32_t n1 = mid - dense_store_strips, f1 = std::min<uint32_t>((uint32_t)e->fill_blocks, n1);
+                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf, f1};
+                    grid1 = dim3((uint32_t)e->stage1_list_blocks + (f1 ? f1 : n1));
                 }
-                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf};
-                fgrid = dim3((uint32_t)e->defer_stores + (nstrips - mid));
+                const uint32_t nf = nstrips - mid, ff = std::min<uint32_t>((uint32_t)e->fill_blocks, nf);
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf, ff};
+                fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
+#define LAUNCH_LIST(FIN, GRID, ...) hipLaunchKernelGGL((carve_list_kernel<FIN>), GRID, block, 0, e->stream, __VA_ARGS__)
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
             int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
             uint32_t *nolist = nullptr;
             if ((size_t)s1 >= nv) {
-                hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs);
+                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs);
             } else {
-                hipLaunchKernelGGL(carve_list_kernel<false>, grid1, block, 0, e->stream, st,
-                                   g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1);
+                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1);
                 if (s2 > s1 && (size_t)s2 < nv) {
-                    hipLaunchKernelGGL(carve_list_kernel<false>, dim3(list_blocks), block, 0, e->stream,
-                                       st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none);
-                    hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream,
-                                       st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs);
+                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs);
                 } else {
-                    hipLaunchKernelGGL(carve_list_kernel<true>, fgrid, block, 0, e->stream,
-                                       st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs);
                 }
             }
+#undef LAUNCH_LIST
             // the resume kernel is also what zeroes the next batch's counters
             e->ctl_clean[e->ctl_idx ^ 1] = true;
             const LateBricks late{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
@@ -2688,6 +2696,10 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value != 1 && value != 2 && value != 4 && value != 8)
                 return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
             e->pack_rows = value;
+            return SC_OK;
+        case SC_OPT_FILL_BLOCKS:
+            if (value < 0 || value > 65536) return fail(SC_ERR_INVALID, "fill_blocks must be in [0, 65536]");
+            e->fill_blocks = value;
             return SC_OK;
         case SC_OPT_PACK_RIDE:
             e->pack_ride = value ? 1 : 0;

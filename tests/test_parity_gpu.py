@@ -163,6 +163,10 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_STAGE1_STORE_SHARE": 9, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_DEFER_STORES": 40},  # all three kernels fill
     {"SC_OPT_COMPACT": 0},                                                # bricks without survivor lists
     {"SC_OPT_VIEW_ORDER": 0},
+    {"SC_OPT_FILL_BLOCKS": 0},                                            # one short store block per strip
+    {"SC_OPT_FILL_BLOCKS": 3, "SC_OPT_STAGE1_STORE_SHARE": 8},            # a few persistent ones
+    {"SC_OPT_PACK_RIDE": 0},                                              # every mask packed ahead
+    {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
                                         ("plant", (7, 23, 70)),      # bricks stick out in y and z
