@@ -83,7 +83,7 @@ extern "C" {
                                      test per brick; 0: linear blocks only                       */
 #define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
 #define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
-#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1280): the -1 fill of bricks found empty is done by
+#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1024): the -1 fill of bricks found empty is done by
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
@@ -100,6 +100,7 @@ extern "C" {
 #define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
                                      that many persistent blocks walking the strips (512 = two per CU: a
                                      wavefront's stores do not hold it up, so few keep the write path busy) */
+#define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1 or 2 (default)          */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

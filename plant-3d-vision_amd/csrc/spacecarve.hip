@@ -927,7 +927,7 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
 //     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
 // (at most 80 SGPRs: with 82-96 the CU admits 7 such blocks instead of 8, with 98+ only 6 --
 // MI355X_MICROARCH.md, "Residency" -- and the store blocks need the slots the list blocks leave)
-template <bool FINAL>
+template <bool FINAL, int P>  // P voxels per lane (an item is a chunk of 64 * P entries)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                             const ViewDesc *__restrict__ views,
                                                             int nviews,
@@ -954,8 +954,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
     const uint32_t bid = blockIdx.x;
+    constexpr uint32_t CH = 64u * P;
     {
-        uint32_t c = (min(ctl->count[sin][tid].n, subcap) + 63u) / 64u;  // kSub == kBlock
+        uint32_t c = (min(ctl->count[sin][tid].n, subcap) + CH - 1u) / CH;  // kSub == kBlock
         if (tid == 0) pref[0] = 0;
         pref[tid + 1] = c;
         __syncthreads();
@@ -986,74 +987,90 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             if (pref[mid] <= c) lo = mid; else hi = mid;
         }
         const uint32_t s = lo;
-        const uint32_t e = (c - pref[s]) * 64u + lane;
         const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
         const int v0 = FINAL ? (int)vgi * vgsize : 0;
         const int v1 = FINAL ? min(nviews, v0 + vgsize) : nviews;
-        if (e < cnt) {
-            uint32_t entry = lin[(size_t)s * subcap + e];
-            uint32_t idx = entry & 0x7fffffffu;
-            bool zero = (entry >> 31) != 0;  // label is still 0
-            bool flipped = false, alive = true;
-            uint32_t col = idx / g.nz;
-            uint32_t k = idx - col * g.nz;
-            uint32_t il = col / g.ny;
-            uint32_t j = col - il * g.ny;
-            float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
-            float y = g.oy + (float)(int)j * g.vs;
-            float z = g.oz + (float)(int)k * g.vs;
-            // U views per iteration: U independent projection chains and U gathers in flight per
-            // lane.  The final stage is bound by arithmetic (U = 2); the stages before it wait on
-            // memory and most of their voxels die within a few views (U = 4).
-            constexpr int U = FINAL ? 2 : 4;
-            for (int vi = v0; vi < v1; vi += U) {
-                if (__ballot(alive) == 0) break;
-                bool ok[U], fg[U];
+        // P voxels per lane: the descriptor traffic and the scalar bookkeeping of a view are shared,
+        // and a lane has P * U independent projection chains and gathers in flight
+        uint32_t idx[P];
+        bool zero[P], flipped[P], alive[P];
+        float x[P], y[P], z[P];
 #pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const bool have = vi + q < v1;  // wave-uniform
-                    const ViewDesc d = views[have ? vi + q : vi];
-                    // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
-                    // tiles_x and the mask pointer one by one where they are first used, three
-                    // more scalar-load round trips inside each projection
-                    asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+        for (int p = 0; p < P; ++p) {
+            const uint32_t e = (c - pref[s]) * CH + (uint32_t)p * 64u + lane;
+            alive[p] = e < cnt;
+            uint32_t entry = 0;
+            if (alive[p]) entry = lin[(size_t)s * subcap + e];
+            idx[p] = entry & 0x7fffffffu;
+            zero[p] = (entry >> 31) != 0;  // label is still 0
+            flipped[p] = false;
+            const uint32_t col = idx[p] / g.nz;
+            const uint32_t k = idx[p] - col * g.nz;
+            const uint32_t il = col / g.ny;
+            const uint32_t j = col - il * g.ny;
+            x[p] = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+            y[p] = g.oy + (float)(int)j * g.vs;
+            z[p] = g.oz + (float)(int)k * g.vs;
+        }
+        // U views per iteration.  The final stage is bound by arithmetic (U = 2); the stages before
+        // it wait on memory and most of their voxels die within a few views (U = 4).
+        constexpr int U = FINAL ? 2 : 4;
+        for (int vi = v0; vi < v1; vi += U) {
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) any |= alive[p];
+            if (__ballot(any) == 0) break;
+            bool ok[U][P], fg[U][P];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const bool have = vi + q < v1;  // wave-uniform
+                const ViewDesc d = views[have ? vi + q : vi];
+                // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
+                // tiles_x and the mask pointer one by one where they are first used, three
+                // more scalar-load round trips inside each projection
+                asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
                     int uu, vv;
-                    ok[q] = project(d.R[0] * x + d.R[1] * y, d.R[3] * x + d.R[4] * y,
-                                    d.R[6] * x + d.R[7] * y, z, d, uu, vv) & alive & have;
+                    ok[q][p] = project(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
+                                       d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv) & alive[p] & have;
                     uint32_t w = 0;
-                    if (ok[q]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
-                    fg[q] = ((w >> (uu & 31)) & 1u) != 0;
+                    if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
+                    fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
                 }
-                // U applications of backprojection.c:79-83; a zero pixel in any of the views wins
+            }
+            // U applications of backprojection.c:79-83; a zero pixel in any of the views wins
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
                 bool carve = false, keep = false;
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
-                    carve |= ok[q] & !fg[q];
-                    keep |= ok[q] & fg[q];
+                    carve |= ok[q][p] & !fg[q][p];
+                    keep |= ok[q][p] & fg[q][p];
                 }
                 if (carve) {
-                    alive = false;
-                    labels[idx] = -1;
-                } else if (zero & keep) {
-                    zero = false;
-                    if (FINAL) atomicCAS(&labels[idx], 0, 1); else flipped = true;
+                    alive[p] = false;
+                    labels[idx[p]] = -1;
+                } else if (zero[p] & keep) {
+                    zero[p] = false;
+                    if (FINAL) atomicCAS(&labels[idx[p]], 0, 1); else flipped[p] = true;
                 }
             }
-            if (!FINAL) {
-                if (alive && flipped) labels[idx] = 1;
-                unsigned long long b = __ballot(alive);
+        }
+        if (!FINAL) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (alive[p] && flipped[p]) labels[idx[p]] = 1;
+                unsigned long long b = __ballot(alive[p]);
                 if (b != 0) {
-                    unsigned long long act = __ballot(1);
-                    int leader = __ffsll((long long)act) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader)
-                        base = atomicAdd(&ctl->count[sout][s].n, (uint32_t)__popcll(b));
-                    base = __shfl(base, leader);
+                    if (lane == 0) base = atomicAdd(&ctl->count[sout][s].n, (uint32_t)__popcll(b));
+                    base = __shfl(base, 0);
                     // survivors of sub-list s never outnumber its entries: no overflow here
-                    if (alive) {
+                    if (alive[p]) {
                         unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
                         lout[(size_t)s * subcap + base + (uint32_t)__popcll(b & below)] =
-                            idx | (zero ? 0x80000000u : 0u);
+                            idx[p] | (zero[p] ? 0x80000000u : 0u);
                     }
                 }
             }
@@ -1592,8 +1609,9 @@ struct sc_engine {
     int64_t stage1_store_share = 4;  // sixteenths of the deferred strips filled beside the FIRST list stage
     int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
-    int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
+    int64_t defer_stores = 1024;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
+    int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
     int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
@@ -2363,7 +2381,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf, ff};
                 fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
-#define LAUNCH_LIST(FIN, GRID, ...) hipLaunchKernelGGL((carve_list_kernel<FIN>), GRID, block, 0, e->stream, __VA_ARGS__)
+#define LAUNCH_LIST(FIN, GRID, ...)                                                                      \
+    do {                                                                                                 \
+        if (FIN && e->final_voxels == 2) hipLaunchKernelGGL((carve_list_kernel<FIN, FIN ? 2 : 1>), GRID, block, 0, e->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((carve_list_kernel<FIN, 1>), GRID, block, 0, e->stream, __VA_ARGS__);     \
+    } while (0)
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
             int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
             uint32_t *nolist = nullptr;
@@ -2696,6 +2718,10 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value != 1 && value != 2 && value != 4 && value != 8)
                 return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
             e->pack_rows = value;
+            return SC_OK;
+        case SC_OPT_FINAL_VOXELS:
+            if (value != 1 && value != 2) return fail(SC_ERR_INVALID, "final_voxels must be 1 or 2");
+            e->final_voxels = value;
             return SC_OK;
         case SC_OPT_FILL_BLOCKS:
             if (value < 0 || value > 65536) return fail(SC_ERR_INVALID, "fill_blocks must be in [0, 65536]");

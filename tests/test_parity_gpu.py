@@ -166,6 +166,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_FILL_BLOCKS": 0},                                            # one short store block per strip
     {"SC_OPT_FILL_BLOCKS": 3, "SC_OPT_STAGE1_STORE_SHARE": 8},            # a few persistent ones
     {"SC_OPT_PACK_RIDE": 0},                                              # every mask packed ahead
+    {"SC_OPT_FINAL_VOXELS": 1},                                           # one survivor per lane in the final stage
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
@@ -871,4 +872,47 @@ def test_device_batch_then_more_views_before_the_flush(gpu_device):
     e.process_views_device(K[:8], R[:8], t[:8], ptr, 8, *stack.shape[1:], nat.SC_MASK_U8)
     assert np.array_equal(e.get_values(), oracle_c.carve(list(shape), origin, vs, views[:8]))
     e.dev_free(ptr)
+    e.close()
+
+
+def test_device_batches_back_to_back_and_mixed_with_other_launches(gpu_device):
+    """Consecutive device batches without a wait in between, batches onto a stored volume, per-view
+    launches after a batch, a batch after per-view launches, different masks per batch -- always the
+    oracle's labels."""
+    shape, origin, vs, views = scene((20, 48, 128), 12, "plant")
+    _, _, _, views_b = scene((20, 48, 128), 12, "dense")
+    want_a = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    want_b = oracle_c.carve(list(shape), origin, vs, views_b, nthreads=4)
+    want_ab = oracle_c.carve(list(shape), origin, vs, list(views) + list(views_b), nthreads=4)
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    bufs = []
+    for vv in (views, views_b):
+        stack = np.ascontiguousarray(np.stack([m for _, _, _, m in vv]))
+        ptr = e.dev_alloc(stack.nbytes)
+        e.dev_upload(ptr, stack)
+        bufs.append((ptr, stack.shape, np.stack([v[0] for v in vv]), np.stack([v[1] for v in vv]), np.stack([v[2] for v in vv])))
+
+    def batch(q):
+        ptr, (V, H, W), K, R, t = bufs[q]
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+
+    for _ in range(3):  # a, b, a, b ... only the last result is read
+        e.clear(); batch(0); e.flush()
+        e.clear(); batch(1); e.flush()
+    assert np.array_equal(e.get_values(), want_b)
+    e.clear(); batch(0); e.flush(); batch(1)  # second batch onto the stored volume of the first
+    assert np.array_equal(e.get_values(), want_ab)
+    e.clear(); batch(0); e.flush()
+    for Kq, Rq, tq, m in views_b:
+        e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+    assert np.array_equal(e.get_values(), want_ab)
+    e.clear()
+    for Kq, Rq, tq, m in views_b[:3]:
+        e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+    e.flush(); batch(0); e.flush(); batch(1)
+    assert np.array_equal(e.get_values(), want_ab)
+    e.clear(); batch(0)
+    assert np.array_equal(e.get_values(), want_a)
+    for ptr, *_ in bufs:
+        e.dev_free(ptr)
     e.close()
