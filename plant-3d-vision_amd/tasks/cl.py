@@ -15,24 +15,33 @@ import numpy as np
 
 logger = logging.getLogger(__name__)
 
+#: the class ``voxels_run`` (and so ``Voxels.run``) instantiates; ``None`` = ``plant3dvision_amd.cl.Backprojection``
+#: (the HIP engine).  A seam for callers that bring their own device layer -- the CPU tests put the
+#: oracle-backed class here; the product never sets it.
+BACKPROJECTION_CLS = None
+
 #: parameter defaults of the reference task (tasks/cl.py:83-91)
 VOXELS_DEFAULTS = dict(query={}, camera_metadata="colmap_camera", voxel_size=1.0, type="carving",
                        log=True, invert=False, labels=[], bounding_box=None)
 
 
 def grid_from_bounding_box(bounding_box, voxel_size, displacement=None):
-    """tasks/cl.py:127-147: ``n = int((max - min) / voxel_size) + 1`` per axis, origin = mins,
-    both shifted by the scan's ``displacement`` metadata when present."""
+    """tasks/cl.py:125-147: ``n = int((max - min) / voxel_size) + 1`` per axis, origin = mins, both
+    shifted by the scan's ``displacement`` metadata.  The shifts are applied one by one inside a
+    ``try`` like the reference's (:129-140): no metadata (``None``) shifts nothing, a dictionary
+    lacking a key shifts the bounds before it and warns."""
     x_min, x_max = bounding_box["x"]
     y_min, y_max = bounding_box["y"]
     z_min, z_max = bounding_box["z"]
-    if displacement is not None:
+    try:
         x_min += displacement["dx"]
         x_max += displacement["dx"]
         y_min += displacement["dy"]
         y_max += displacement["dy"]
         z_min += displacement["dz"]
         z_max += displacement["dz"]
+    except Exception:  # the reference's bare except (:139)
+        logger.warning("No 'displacement' found in scan metadata!")
     nx = int((x_max - x_min) / voxel_size) + 1
     ny = int((y_max - y_min) / voxel_size) + 1
     nz = int((z_max - z_min) / voxel_size) + 1
@@ -80,14 +89,14 @@ def voxels_run(masks_files, bounding_box, voxel_size=1.0, type="carving", log=Tr
     array (``write_volume``, :184) -- and ``metadata = {'voxel_size', 'origin'}`` (:186).
     """
     if backprojection_cls is None:
+        backprojection_cls = BACKPROJECTION_CLS
+    if backprojection_cls is None:
         from ..cl import Backprojection as backprojection_cls
     logger.info(f"Processing a list of {len(masks_files)} mask files...")
     if bounding_box is None:
         logger.critical("Could not obtain valid bounding-box!")
         sys.exit("Error with bounding-box definition!")
     logger.info(f"Bounding-box to use: {bounding_box}")
-    if displacement is None:
-        logger.warning("No 'displacement' found in scan metadata!")
     shape, origin_list = grid_from_bounding_box(bounding_box, voxel_size, displacement)
     origin = np.array(origin_list)
 
@@ -120,53 +129,80 @@ def voxels_run(masks_files, bounding_box, voxel_size=1.0, type="carving", log=Tr
     return volume, use_labels, metadata
 
 
-try:  # the luigi task proper, only where the reference's runtime exists
+try:  # the luigi task proper, where the reference's runtime (or the test stubs) can be imported
     import luigi  # type: ignore
     from romitask import RomiTask  # type: ignore
+    from romitask.task import ImagesFilesetExists  # type: ignore
 except ImportError:
     Voxels = None
 else:
-    class Voxels(RomiTask):  # pragma: no cover - needs romitask/plantdb, absent here
-        """``plant3dvision.tasks.cl.Voxels`` with the MI355X back-projection (same
-        parameters and defaults, tasks/cl.py:79-91)."""
-        upstream_task = None
-        upstream_mask = luigi.TaskParameter()
-        upstream_colmap = luigi.TaskParameter()
-        query = luigi.DictParameter(default={})
-        camera_metadata = luigi.Parameter(default="colmap_camera")
-        voxel_size = luigi.FloatParameter(default=1.0)
-        type = luigi.Parameter(default="carving")
-        log = luigi.BoolParameter(default=True)
-        invert = luigi.BoolParameter(default=False)
-        labels = luigi.ListParameter(default=[])
-        bounding_box = luigi.DictParameter(default=None)
+    try:  # the reference's own upstream tasks are the parameter defaults (tasks/cl.py:79-80)
+        from plant3dvision.tasks.colmap import Colmap  # type: ignore
+        from plant3dvision.tasks.proc2d import Masks  # type: ignore
+    except ImportError:
+        Colmap = Masks = None
+
+    def _task_parameter(default):
+        return luigi.TaskParameter(default=default) if default is not None else luigi.TaskParameter()
+
+    class Voxels(RomiTask):
+        """``plant3dvision.tasks.cl.Voxels`` with the MI355X back-projection: same parameters and
+        defaults (tasks/cl.py:78-91), same ``requires`` (:93-97), same sources of the bounding box in
+        the same order (:106-122), same output (:176-186)."""
+        upstream_task = None  # override default attribute from ``RomiTask``   (:78)
+        upstream_mask = _task_parameter(Masks)      # :79
+        upstream_colmap = _task_parameter(Colmap)   # :80
+
+        query = luigi.DictParameter(default={})                      # :82
+        camera_metadata = luigi.Parameter(default='colmap_camera')   # :83
+        voxel_size = luigi.FloatParameter(default=1.0)               # :84
+        type = luigi.Parameter(default="carving")                    # :85
+        log = luigi.BoolParameter(default=True)                      # :86
+
+        invert = luigi.BoolParameter(default=False)                  # :88
+        labels = luigi.ListParameter(default=[])                     # :89
+        bounding_box = luigi.DictParameter(default=None)             # :90
 
         def requires(self):
-            if self.upstream_colmap.get_task_family() == "Colmap":
-                return {"masks": self.upstream_mask(), "colmap": self.upstream_colmap()}
-            return {"masks": self.upstream_mask()}
+            if self.upstream_colmap.get_task_family() == 'Colmap':
+                return {'masks': self.upstream_mask(), 'colmap': self.upstream_colmap()}
+            else:
+                return {'masks': self.upstream_mask()}
 
         def run(self):
             from plantdb import io  # type: ignore
-            masks_fileset = self.input()["masks"].get()
+            masks_fileset = self.input()['masks'].get()
             masks_files = masks_fileset.get_files(query=self.query)
-            bbox = self.bounding_box
-            if bbox is None:
-                bbox = self.output().get().scan.get_metadata("bounding_box")
-            if bbox is None and self.upstream_colmap.get_task_family() == "Colmap":
-                bbox = self.input()["colmap"].get().get_metadata("bounding_box")
-            try:
+
+            # - the bounding box, from (1) the parameter, (2) the scan metadata, (3) the Colmap
+            #   fileset, (4) the 'images' fileset (:106-118)
+            if self.bounding_box is None:
+                self.bounding_box = self.output().get().scan.get_metadata("bounding_box")
+                logger.debug(f"Bounding-box from scan metadata: {self.bounding_box}")
+            if self.bounding_box is None and self.upstream_colmap.get_task_family() == 'Colmap':
+                colmap_fileset = self.input()['colmap'].get()
+                if self.bounding_box is None:
+                    self.bounding_box = colmap_fileset.get_metadata("bounding_box")
+                logger.debug(f"Bounding-box from Colmap fileset: {self.bounding_box}")
+            if self.bounding_box is None:
+                self.bounding_box = ImagesFilesetExists().output().get().get_metadata("bounding_box")
+            if self.bounding_box is None:
+                logger.critical(f"Could not obtain valid bounding-box for {self.scan_id}!")
+
+            try:  # :129-140 -- any failure means "no displacement"
                 displacement = masks_fileset.scan.get_metadata("displacement")
             except Exception:
                 displacement = None
             volume, labels, md = voxels_run(
-                masks_files, bbox, voxel_size=self.voxel_size, type=self.type, log=self.log,
-                invert=self.invert, labels=self.labels, camera_metadata=self.camera_metadata,
-                displacement=displacement,
+                masks_files, None if self.bounding_box is None else dict(self.bounding_box),
+                voxel_size=self.voxel_size, type=self.type, log=self.log, invert=self.invert,
+                labels=self.labels, camera_metadata=self.camera_metadata, displacement=displacement,
                 fileset_label_names=masks_fileset.get_metadata("label_names", default=None))
+
             outfile = self.output_file()
             if labels is not None:
-                io.write_npz(outfile, volume)
+                logger.debug(f"Writing NPZ volume for label: {labels}")
+                io.write_npz(outfile, volume)   # :176-182
             else:
-                io.write_volume(outfile, volume)
-            outfile.set_metadata(md)
+                io.write_volume(outfile, volume)  # :184
+            outfile.set_metadata(md)  # :186
