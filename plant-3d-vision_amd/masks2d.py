@@ -16,22 +16,98 @@ import numpy as np
 from . import _native as nat
 
 
+#: 3x3 footprints of skimage's series decomposition of a disk (skimage/morphology/footprints.py,
+#: ``_nsphere_series_decomposition`` after Park & Chin 1995): the four T-shaped elements, the
+#: "diamond" (3x3 cross) and the square, as lists of (dy, dx) offsets of their set pixels.
+_T0 = ((-1, -1), (-1, 0), (-1, 1), (0, 0), (1, 0))
+_FOOTPRINTS = {
+    "t0": _T0,
+    "t90": tuple((-dx, dy) for dy, dx in _T0),    # np.rot90(t0, 1)
+    "t180": tuple((-dy, -dx) for dy, dx in _T0),  # np.rot90(t0, 2)
+    "t270": tuple((dx, -dy) for dy, dx in _T0),   # np.rot90(t0, 3)
+    "diamond": ((-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)),
+    "square": tuple((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)),
+}
+
+
+def _compose(counts):
+    """The footprint a series (n_t_series, n_diamond, n_square) amounts to, as a boolean array."""
+    import numpy as np
+    a, b, c = counts
+    r = 4 * a + b + c
+    img = np.zeros((2 * r + 1, 2 * r + 1), dtype=bool)
+    img[r, r] = True
+    for name, reps in (("t0", a), ("t90", a), ("t180", a), ("t270", a), ("diamond", b), ("square", c)):
+        for _ in range(reps):
+            out = np.zeros_like(img)
+            for dy, dx in _FOOTPRINTS[name]:
+                out[max(dy, 0):img.shape[0] + min(dy, 0), max(dx, 0):img.shape[1] + min(dx, 0)] |= \
+                    img[max(-dy, 0):img.shape[0] + min(-dy, 0), max(-dx, 0):img.shape[1] + min(-dx, 0)]
+            img = out
+    return img
+
+
+def disk_series(n):
+    """``skimage.morphology.disk(n, decomposition='sequence')`` as (footprint name, repetitions)
+    pairs: for n = 1 the 3x3 cross; for n > 1 a series of T-shaped, diamond and square 3x3 elements
+    whose composition is closest to ``disk(n, strict_radius=False)``.
+
+    scikit-image (unpinned in the reference's requirements.txt:17) ships the series counts as a
+    precomputed table (``disk_decompositions.npy``) that is not available in this image; the counts
+    are regenerated here by the procedure that table was made with (exhaustive search over
+    (n_t_series, n_diamond, n_square) with 4 a + b + c = n, least sum of absolute differences, first
+    minimum in that order).  PARITY UNPINNED for n > 1: identical footprints by construction of the
+    same search, not by comparison with the table.  Every shipped ML configuration uses n = 1."""
+    import numpy as np
+    n = int(n)
+    if n < 1:
+        return ()
+    if n == 1:
+        return (("diamond", 1),)
+    if n > 32:
+        raise ValueError("dilation radius beyond 32 is not supported")
+    yy, xx = np.mgrid[-n:n + 1, -n:n + 1]
+    desired = (xx * xx + yy * yy) <= (n + 0.5) ** 2  # disk(n, strict_radius=False)
+    best, best_err = None, None
+    for a in range(n // 4 + 1):
+        for b in range(n - 4 * a + 1):
+            c = n - 4 * a - b
+            err = int(np.sum(desired != _compose((a, b, c))))
+            if best_err is None or err < best_err:
+                best, best_err = (a, b, c), err
+    a, b, c = best
+    seq = []
+    if a:
+        seq += [("t0", a), ("t90", a), ("t180", a), ("t270", a)]
+    if b:
+        seq.append(("diamond", b))
+    if c:
+        seq.append(("square", c))
+    return tuple(seq)
+
+
+def dilate3x3(mask, offsets):
+    """``scipy.ndimage.binary_dilation(mask, structure)`` for a 3x3 structure given by the (dy, dx)
+    offsets of its set pixels, on bool tensors ``[..., H, W]``: out[p] = OR_o mask[p - o]; pixels
+    beyond the border count as background (nothing wraps)."""
+    import torch
+    H, W = mask.shape[-2], mask.shape[-1]
+    out = torch.zeros_like(mask)
+    for dy, dx in offsets:
+        out[..., max(dy, 0):H + min(dy, 0), max(dx, 0):W + min(dx, 0)] |= \
+            mask[..., max(-dy, 0):H + min(-dy, 0), max(-dx, 0):W + min(-dx, 0)]
+    return out
+
+
 def dilate_cross(mask, n):
     """``proc2d.dilation(img, n)`` (``plant3dvision/proc2d.py:172-220``) for bool tensors
-    ``[..., H, W]``: ``binary_dilation`` with ``disk(n, decomposition='sequence')``.  For n = 1
-    (every shipped config) that footprint is the 3x3 cross; larger radii use skimage's series
-    table, which is not reproduced here."""
-    import torch
-    if n == 0:
-        return mask
-    if n != 1:
-        raise NotImplementedError("only dilation 0 or 1 (3x3 cross) is mirrored exactly")
-    out = mask.clone()
-    out[..., 1:, :] |= mask[..., :-1, :]
-    out[..., :-1, :] |= mask[..., 1:, :]
-    out[..., :, 1:] |= mask[..., :, :-1]
-    out[..., :, :-1] |= mask[..., :, 1:]
-    return out
+    ``[..., H, W]``: ``binary_dilation`` with ``disk(n, decomposition='sequence')``, i.e. one 3x3
+    footprint after the other, each repeated as the series says (``disk_series``).  n = 1 -- every
+    shipped ML configuration -- is the 3x3 cross."""
+    for name, reps in disk_series(n):
+        for _ in range(reps):
+            mask = dilate3x3(mask, _FOOTPRINTS[name])
+    return mask
 
 
 def masks_from_predictions(pred, label_names, labels=None, inverted_labels=("background",),
@@ -67,6 +143,44 @@ def masks_from_predictions(pred, label_names, labels=None, inverted_labels=("bac
             m = 255 - m  # :378-379
         out[name] = m.contiguous()
     return out
+
+
+def mask_files_layout(label_names, images_metadata, id_im, labels=None):
+    """The files ``Segmentation2D.run`` writes and their metadata (``tasks/proc2d.py:362-393``), without
+    writing them: for every image, for every label of the filtered list, the file id
+    ``'%03d_%s' % (img_id, label)`` (:366) with metadata ``{'image_id': id_im[img_id][0], **original,
+    'channel': label}`` (:383-390); and the fileset metadata ``{'label_names': [...]}`` (:392-393).
+    What ``Voxels`` later reads from a mask file -- ``channel`` (cl.py:284) and the camera entry copied
+    from the image's own metadata (cl.py:286-296) -- comes from here.
+
+    Returns ``(files, fileset_metadata)`` with ``files = [(file_id, img_id, label, metadata), ...]``."""
+    if labels:
+        label_range = [label_names.index(x) for x in labels]  # :342-343 (ValueError for an unknown label)
+    else:
+        label_range = range(len(label_names))
+    files = []
+    for img_id in range(len(images_metadata)):
+        for label_id in label_range:
+            name = label_names[label_id]
+            md = {"image_id": id_im[img_id][0], **images_metadata[img_id]}
+            md["channel"] = name
+            files.append(("%03d_%s" % (img_id, name), img_id, name, md))
+    return files, {"label_names": [label_names[j] for j in label_range]}
+
+
+def cameras_for_label(files, label, camera_metadata="colmap_camera"):
+    """The camera dictionaries ``Backprojection.process_label`` would use for ``label`` (cl.py:282-296):
+    files of that channel, in order, skipping those without the camera entry."""
+    cams, img_ids = [], []
+    for _, img_id, name, md in files:
+        if name != label:
+            continue
+        cam = md.get(camera_metadata)
+        if cam is None:
+            continue
+        cams.append(cam)
+        img_ids.append(img_id)
+    return cams, img_ids
 
 
 def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging", log=True,

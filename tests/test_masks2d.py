@@ -44,9 +44,79 @@ def test_masks_from_predictions_matches_reference_chain(binarize, dilation):
     assert list(sub) == ["stem"]
 
 
-def test_unsupported_dilation_radius_is_loud():
-    with pytest.raises(NotImplementedError):
-        masks2d.dilate_cross(torch.zeros(4, 4, dtype=torch.bool), 2)
+def test_mask_files_layout_carries_the_image_metadata_and_the_label_names():
+    """tasks/proc2d.py:362-393: file ids, per-file metadata (image_id, the image's own metadata, the
+    channel) and the fileset's label_names, in the reference's loop order."""
+    names = ["background", "flower", "stem"]
+    imd = [{"colmap_camera": {"rotmat": q}, "shot_id": f"{q:03d}"} for q in range(2)]
+    id_im = [("00000_rgb", 0), ("00001_rgb", 1)]
+    files, fsmd = masks2d.mask_files_layout(names, imd, id_im)
+    assert [f[0] for f in files] == ["000_background", "000_flower", "000_stem", "001_background", "001_flower", "001_stem"]
+    assert files[4][3] == {"image_id": "00001_rgb", "colmap_camera": {"rotmat": 1}, "shot_id": "001", "channel": "flower"}
+    assert fsmd == {"label_names": names}
+    files, fsmd = masks2d.mask_files_layout(names, imd, id_im, labels=["stem", "flower"])  # the order of `labels`
+    assert [f[0] for f in files] == ["000_stem", "000_flower", "001_stem", "001_flower"]
+    assert fsmd == {"label_names": ["stem", "flower"]}
+    cams, ids = masks2d.cameras_for_label(files, "flower")
+    assert cams == [{"rotmat": 0}, {"rotmat": 1}] and ids == [0, 1]
+    imd[1].pop("colmap_camera")  # a file without camera metadata is skipped (cl.py:288-291)
+    files, _ = masks2d.mask_files_layout(names, imd, id_im)
+    assert masks2d.cameras_for_label(files, "stem")[1] == [0]
+    with pytest.raises(ValueError):
+        masks2d.mask_files_layout(names, imd, id_im, labels=["leaf"])
+
+
+T0 = np.array([[1, 1, 1], [0, 1, 0], [0, 1, 0]], dtype=bool)  # skimage _t_shaped_element_series, 2-D
+STRUCTURES = {"t0": T0, "t90": np.rot90(T0, 1), "t180": np.rot90(T0, 2), "t270": np.rot90(T0, 3),
+              "diamond": CROSS, "square": np.ones((3, 3), dtype=bool)}
+
+
+def test_3x3_footprint_dilation_is_scipy_binary_dilation():
+    """Every element of the series, orientation of the T shapes included, against SciPy -- which is
+    what skimage.morphology.binary_dilation calls per footprint of a sequence."""
+    rng = np.random.default_rng(1)
+    img = rng.random((37, 53)) < 0.08
+    img[0, :5] = True; img[-1, -3:] = True; img[:4, 0] = True  # structure at the borders
+    for name, st in STRUCTURES.items():
+        offs = masks2d._FOOTPRINTS[name]
+        assert sorted(offs) == sorted((int(y) - 1, int(x) - 1) for y, x in zip(*np.nonzero(st))), name
+        got = masks2d.dilate3x3(torch.from_numpy(img), offs).numpy()
+        assert np.array_equal(got, ndimage.binary_dilation(img, structure=st)), name
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 6, 8])
+def test_dilation_by_a_disk_series(n):
+    """proc2d.dilation(img, n > 1): the footprints of the series one after the other, each as often as
+    the series says (what binary_dilation does with a footprint sequence); the series itself is the
+    one closest to disk(n, strict_radius=False) among 4a + b + c = n."""
+    series = masks2d.disk_series(n)
+    rng = np.random.default_rng(n)
+    img = rng.random((64, 80)) < 0.01
+    want = img
+    for name, reps in series:
+        for _ in range(reps):
+            want = ndimage.binary_dilation(want, structure=STRUCTURES[name])
+    got = masks2d.dilate_cross(torch.from_numpy(img), n).numpy()
+    assert np.array_equal(got, want)
+    # a single pixel grows into the composed footprint: radius n along the axes, a disk within 1 px
+    one = np.zeros((2 * n + 5, 2 * n + 5), dtype=bool)
+    one[n + 2, n + 2] = True
+    fp = masks2d.dilate_cross(torch.from_numpy(one), n).numpy()
+    yy, xx = np.mgrid[-n - 2:n + 3, -n - 2:n + 3]
+    disk = xx * xx + yy * yy <= (n + 0.5) ** 2
+    assert fp[n + 2, 2] and fp[2, n + 2] and not fp[n + 2, 1] and not fp[1, n + 2]
+    assert (fp != disk).sum() <= 0.12 * disk.sum()
+    assert sum(r * (4 if k == "t0" else 0 if k.startswith("t") else 1) for k, r in series) == n
+
+
+def test_out_of_range_predictions_follow_numpy_astype_uint8():
+    """`(im * 255).astype(np.uint8)` (tasks/proc2d.py:376) outside [0, 1]: x86 NumPy wraps through
+    int32; the device chain does the same instead of torch's undefined float -> uint8 cast."""
+    pred = torch.tensor([[[[-0.5, 0.0, 0.25, 1.0, 1.5, 2.0, -1.0, 0.999]]]], dtype=torch.float32)
+    out = masks2d.masks_from_predictions(pred, ["stem"], binarize=False)["stem"].numpy().ravel()
+    with np.errstate(invalid="ignore"):
+        want = (pred.numpy().ravel() * 255).astype(np.int32).astype(np.uint8)  # wrap, as the reference's CPU does
+    assert np.array_equal(out, want)
 
 
 @pytest.mark.gpu
