@@ -372,13 +372,27 @@ def main():
         live, s0, s1n, ovf = eng.fused_counts()
         breakdown["fused_counts"] = {"live_bricks": live, "alive_after_dense_stage": s0,
                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}
-    res_other = None
+    res_other = per_view = None
+    eng.set_option(nat.SC_OPT_VIEW_BRICK, 0)  # "stream" is the streaming kernel: every view reads the whole state
     if not a.skip_other_path:
         osteps = max(2, a.steps // 4) if other == "stream" else a.steps
         run_steps(eng, nat, *call, 1, vpl[other])
         eng.synchronize()
         dto, statso = timed(eng, nat, torch, dist, call, osteps, vpl[other], world)
         res_other = (dto, statso, osteps)
+        # the same cadence (one launch per view) in its brick form: dead bricks are skipped
+        eng.set_option(nat.SC_OPT_VIEW_BRICK, 1)
+        psteps = max(2, a.steps // 4)
+        run_steps(eng, nat, *call, 1, 1)
+        eng.synchronize()
+        dtp, _ = timed(eng, nat, torch, dist, call, psteps, 1, world)
+        _, pvk = timed(eng, nat, torch, dist, call, 2, 1, world, time_kernels=1)  # events around every kernel
+        per_view = {"value": n_total * V * psteps / dtp / 1e6, "unit": "Mvoxel*views/s", "steps": psteps,
+                    "ms_per_step": dtp / psteps * 1e3, "launches_per_step": 2 * V,
+                    "device_ms_per_step": sum(pvk[k]["total_ms"] for k in ("carve", "flags", "pack", "fill")) / 2,
+                    "note": "one launch (+ its verdict kernel) per view, the reference's cadence cl.py:223-226, brick "
+                            "verdicts and dead-brick skipping (SC_OPT_VIEW_BRICK 1, the default)"}
+    eng.set_option(nat.SC_OPT_VIEW_BRICK, 1)
 
     # N > 1: carve + assembly, always (t_device + collective)
     asm = None
@@ -487,6 +501,8 @@ def main():
             out[other] = {"value": n_total * V * osteps / dto / 1e6, "unit": "Mvoxel*views/s",
                           "steps": osteps, "ms_per_step": dto / osteps * 1e3,
                           "roofline": roof(other, statso, traffic_for(other)), "kernels": statso}
+        if per_view is not None:
+            out["per_view"] = per_view
         if asm is not None:
             out["value_with_assembly"] = asm["value_with_assembly"]
             out["assembly"] = asm

@@ -93,9 +93,12 @@ struct alignas(128) ListCounter {
 struct ListCtl {
     ListCounter count[3][kSub];  // entries appended per sub-list, one set per list stage
     uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
-    uint32_t nlive;              // brick form: bricks no view found empty (entries of the live list)
+    uint32_t nlive[2];           // brick form: bricks no view found empty (entries of the live list); the flags
+                                 // kernel of launch q counts in word q & 1 and zeroes the other one, so launches
+                                 // that keep the same block (fewer than 6 views: no survivor stages) need no memset
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
-    uint32_t pad[29];
+    uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
+    uint32_t pad[26];
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
@@ -558,13 +561,22 @@ struct DescCopy { const uint32_t *src; uint32_t *dst; uint32_t words; };
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
-    FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch) {
+    FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch,
+    uint8_t *__restrict__ dead, uint32_t parity, uint32_t *__restrict__ fill_list) {
     __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves];
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
+        if (threadIdx.x == 0) ctl->nlive[parity ^ 1u] = ctl->nfill[parity ^ 1u] = 0u;  // the next launch's counters
+    }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t lb = blockIdx.x * 64u + lane;
-    const bool valid = lb < nbricks;
+    // DEAD bricks: an earlier launch found the brick empty, every voxel is -1 and stays so whatever
+    // is carved later (backprojection.c:67) -- until the next clear.  They get no verdict, no fill and
+    // no place on the live list (flag 4): the reference's cadence of one launch per view touches a few
+    // per cent of the volume after the first views instead of streaming all of it through.
+    const bool inb = lb < nbricks;
+    const bool isdead = inb && dead != nullptr && dead[lb] != 0;
+    const bool valid = inb && !isdead;
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t il = lb / per_plane;
     const uint32_t rem = lb - il * per_plane;
@@ -621,18 +633,30 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     }
     if (nall <= 0) cand = 0;  // fullness not asked for
     if (wave != 0) return;
-    const bool dead = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
+    const bool gone = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
     // kept by every view of the batch: FULL (2); by every view packed so far only: a candidate (3)
-    if (valid) flags[lb] = dead ? 1 : (kept ? (nall >= nbatch ? 2 : 3) : 0);
+    if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? 2 : 3) : 0));
+    if (valid && gone && dead != nullptr) dead[lb] = 1;
     // the bricks left go on the live list, one atomic per block
-    const bool alive = valid && !dead && !kept;
+    const bool alive = valid && !gone && !kept;
     const unsigned long long m = __ballot(alive);
     if (m != 0) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl->nlive, (uint32_t)__popcll(m));
+        if (lane == 0) base = atomicAdd(&ctl->nlive[parity], (uint32_t)__popcll(m));
         base = __shfl(base, 0);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         if (alive) live[base + (uint32_t)__popcll(m & below)] = lb;
+    }
+    if (fill_list != nullptr) {  // launches whose dense kernel fills from a list (see carve_brick_light_kernel)
+        const bool fillme = valid && (gone || kept);
+        const unsigned long long mf = __ballot(fillme);
+        if (mf != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->nfill[parity], (uint32_t)__popcll(mf));
+            base = __shfl(base, 0);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (fillme) fill_list[base + (uint32_t)__popcll(mf & below)] = lb | (gone ? 0u : 0x80000000u);
+        }
     }
 }
 
@@ -848,7 +872,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              const uint8_t *__restrict__ flags,
                                                              const uint32_t *__restrict__ live,
                                                              const ListCtl *ctl, uint32_t nwalkers,
-                                                             uint32_t nstore, PackJob ride, int pack_rows) {
+                                                             uint32_t nstore, PackJob ride, int pack_rows,
+                                                             uint32_t parity) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
@@ -865,7 +890,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                             Fill{init == 0 ? 1 : init, FRESH ? 1 : 0}, Confirm{nullptr, 0, 0, nullptr, nullptr});
         return;
     }
-    const uint32_t nlive = ctl->nlive;
+    const uint32_t nlive = ctl->nlive[parity];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t per_plane = bricks_y * bricks_z;
     // block b of XCD (b & 7) takes entries  run * kXcdRun + i  of the runs dealt to that XCD
@@ -880,6 +905,70 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
         const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
         brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4, lb, lane);
+    }
+}
+
+// The dense kernel of a launch WITHOUT survivor stages (fewer than 6 views; a single view in the
+// reference's cadence, cl.py:223-226): walkers on the live list as above, and persistent FILLERS on
+// the fill list the flags kernel wrote (settled bricks that are not dead yet) instead of one store
+// block per strip of the grid -- after the first views nearly every brick is dead and a launch costs
+// what its few live and newly settled bricks cost, not a pass over the grid.
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_light_kernel(
+    int32_t *__restrict__ labels, GridDesc g, const ViewDesc *__restrict__ views, int nviews, int32_t init,
+    uint32_t bricks_y, uint32_t bricks_z, const uint32_t *__restrict__ live, const uint32_t *__restrict__ fill_list,
+    const ListCtl *ctl, uint32_t nwalkers, uint32_t parity) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    if (blockIdx.x >= nwalkers) {
+        const uint32_t nfill = ctl->nfill[parity], nfillers = gridDim.x - nwalkers;
+        const bool vec = (g.nz & 3u) == 0;
+        const int32_t kept = init == 0 ? 1 : init;
+        // 64 entries per load (one per lane), handed out with v_readlane: one round trip per 64 bricks
+        for (uint32_t base = (blockIdx.x - nwalkers) * 64u; base < nfill; base += nfillers * 64u) {
+            const uint32_t mine = (base + lane < nfill) ? fill_list[base + lane] : 0u;
+            const uint32_t n = min(64u, nfill - base);
+            for (uint32_t q = 0; q < n; ++q) {
+                const uint32_t ent = __builtin_amdgcn_readlane(mine, q);
+                const bool isfull = (ent >> 31) != 0;
+                const uint32_t lb = ent & 0x7fffffffu;
+                const uint32_t il = lb / per_plane;
+                const uint32_t rem = lb - il * per_plane;
+                const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+                const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
+                if (j >= g.ny || k0 >= g.nz) continue;
+                int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nz + k0;
+                const uint32_t nv4 = min(4u, g.nz - k0);
+                if (!isfull || FRESH) {
+                    const int32_t val = isfull ? kept : -1;
+                    if (vec) {
+                        typedef int v4i __attribute__((ext_vector_type(4)));
+                        v4i vv = {val, val, val, val};
+                        __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(p));
+                    } else {
+                        for (uint32_t e = 0; e < nv4; ++e) p[e] = val;
+                    }
+                } else {  // kept whole: 0 -> 1, the rest as it is (backprojection.c:81)
+                    for (uint32_t e = 0; e < nv4; ++e)
+                        if (p[e] == 0) p[e] = 1;
+                }
+            }
+        }
+        return;
+    }
+    const uint32_t nlive = ctl->nlive[parity];
+    const Append none{nullptr, nullptr, 0u, 0u};
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3, per_xcd = nwalkers >> 3;
+    for (uint32_t t = seq; ; t += per_xcd) {
+        const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
+        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
+        if (entry >= nlive) continue;
+        const uint32_t lb = live[entry];
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+        brick_voxels<FRESH>(labels, g, views, nviews, init, none, il, j, bz * kBrickZ + (lane & 15) * 4, lb, lane);
     }
 }
 
@@ -1611,12 +1700,18 @@ struct sc_engine {
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1024;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
+    int64_t view_brick = 1;    // a single-view carve launch goes through the brick kernels too (0: streaming kernel)
+    uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
+    bool dead_clean = false;   // `dead` is known to be all zero
     int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
     int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
+    uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
+    uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
+    uint32_t last_parity = 0;
     struct DeferredBatch {     // sc_process_views_device batch whose packing waits for the flush
         bool on = false;
         const void *raw = nullptr;
@@ -2065,7 +2160,7 @@ int ensure_ctl(sc_engine *e) {
         nbricks = (size_t)e->planes * (size_t)((e->ny + kBrickY - 1) / kBrickY) * (size_t)((e->nz + kBrickZ - 1) / kBrickZ);
     char *base = nullptr;
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + 2 * nbricks * sizeof(uint32_t) + 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + 3 * nbricks * sizeof(uint32_t) + 16));
     HIP_TRY(hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream));
     e->ctl2[0] = reinterpret_cast<ListCtl *>(base);
     e->ctl2[1] = e->ctl2[0] + 1;
@@ -2075,6 +2170,7 @@ int ensure_ctl(sc_engine *e) {
     e->flags = reinterpret_cast<uint8_t *>(base + 2 * sizeof(ListCtl));
     e->live = reinterpret_cast<uint32_t *>(base + 2 * sizeof(ListCtl) + flag_bytes);
     e->late = e->live + nbricks;
+    e->fill_list = e->late + nbricks;
     return SC_OK;
 }
 
@@ -2133,7 +2229,7 @@ FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
                 (uint64_t)e->n < 0x80000000ull;
     p.bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY);
     p.bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
-    p.brick = nv > 1 && e->brick && p.bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
+    p.brick = (nv > 1 || e->view_brick) && e->brick && p.bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
               (uint64_t)e->planes * p.bys * p.bzs < 0x80000000ull && has_occ;
     p.nbricks = p.brick ? (uint32_t)((uint64_t)e->planes * p.bys * p.bzs) : 0u;
     p.flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
@@ -2215,7 +2311,11 @@ int flush(sc_engine *e, size_t count = 0) {
         int rcs = step_begin(e);
         if (rcs) return rcs;
     }
-    if (nv > 1) {
+    // a single view in brick form goes through the same kernels as a batch: it needs its descriptor
+    // in the device array too
+    const bool single_brick = nv == 1 && e->mode == SC_MODE_CARVE &&
+                              fused_plan(e, nv, e->pending[0].occ != nullptr).brick;
+    if (nv > 1 || single_brick) {
         if (!ordered && e->mode == SC_MODE_CARVE && e->view_order == 1 && nv == e->pending.size())
             order_views(e->pending);
         // descriptor ring: slots are reused only after a wrap, which waits for the stream
@@ -2273,11 +2373,16 @@ int flush(sc_engine *e, size_t count = 0) {
             if (rc) return rc;
             // list counters, overflow flag, live-brick count: this batch takes the block the previous
             // batch's final stage left zeroed (a memset only if there was no such stage)
-            e->ctl_idx ^= 1;
-            e->ctl = e->ctl2[e->ctl_idx];
-            if (!e->ctl_clean[e->ctl_idx]) HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
+            if (compact) {
+                e->ctl_idx ^= 1;
+                e->ctl = e->ctl2[e->ctl_idx];
+                if (!e->ctl_clean[e->ctl_idx]) HIP_TRY(hipMemsetAsync(e->ctl, 0, sizeof(ListCtl), e->stream));
+            }
+            // (a launch without survivor stages keeps the block: its two counters alternate, see ListCtl)
             e->ctl_clean[e->ctl_idx] = false;
         }
+        const uint32_t parity = (uint32_t)(e->flag_launches & 1u);
+        if (brick) ++e->flag_launches;
         if (compact) {
             rc = ensure_lists(e);
             if (rc) return rc;
@@ -2291,7 +2396,7 @@ int flush(sc_engine *e, size_t count = 0) {
             rc = lt.begin();
             if (rc) return rc;
         }
-        if (nv == 1) {
+        if (nv == 1 && !brick) {
             // kStreamGroups groups per lane when the state is streamed through (see kernel)
             uint32_t per_block = (!e->fresh && vec) ? kBlock * kStreamGroups : kBlock;
             dim3 grid1((uint32_t)((g.ngroups + per_block - 1) / per_block));
@@ -2309,6 +2414,14 @@ int flush(sc_engine *e, size_t count = 0) {
                 // riders the walkers leave wavefront slots free for them
                 const uint32_t nwalkers = ((uint32_t)(ride_blocks ? e->brick_walkers : e->list_blocks) + 7u) & ~7u;
                 dim3 bgrid(nwalkers + dense_store_strips + ride_blocks);
+                if (!e->dead) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dead), (size_t)nbricks));
+                    e->dead_clean = false;
+                }
+                if (!e->dead_clean) {
+                    HIP_TRY(hipMemsetAsync(e->dead, 0, (size_t)nbricks, e->stream));
+                    e->dead_clean = true;
+                }
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
@@ -2324,19 +2437,30 @@ int flush(sc_engine *e, size_t count = 0) {
                 hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
                                    flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
-                                   desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv);
+                                   desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv, e->dead,
+                                   parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list);
+                e->last_parity = parity;
                 rc = ltf.end();
                 if (rc) return rc;
                 rc = lt.begin();  // SC_KERNEL_CARVE times the dense kernel alone
                 if (rc) return rc;
-                if (e->fresh)
+                if (!compact) {
+                    // no survivor stages: walkers on the live list, fillers on the fill list
+                    const dim3 lgrid(nwalkers + (uint32_t)std::max<int64_t>(e->fill_blocks, 64));
+                    if (e->fresh)
+                        hipLaunchKernelGGL((carve_brick_light_kernel<true>), lgrid, block, 0, e->stream, st, g, vd,
+                                           dense_views, init, bys, bzs, e->live, e->fill_list, e->ctl, nwalkers, parity);
+                    else
+                        hipLaunchKernelGGL((carve_brick_light_kernel<false>), lgrid, block, 0, e->stream, st, g, vd,
+                                           dense_views, init, bys, bzs, e->live, e->fill_list, e->ctl, nwalkers, parity);
+                } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows);
+                                       dense_store_strips, ride, (int)e->pack_rows, parity);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows);
+                                       dense_store_strips, ride, (int)e->pack_rows, parity);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -2429,6 +2553,7 @@ int flush(sc_engine *e, size_t count = 0) {
             if (need > e->verd_cap) {
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 if (e->verd) (void)hipFree(e->verd);
+    if (e->dead) (void)hipFree(e->dead);
                 e->verd = nullptr;
                 e->verd_cap = 0;
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->verd), need));
@@ -2647,6 +2772,7 @@ int sc_clear(sc_engine *e) {
     if (rc) return rc;
     e->pending.clear();
     e->deferred.on = false;
+    e->dead_clean = false;  // the labels go back to default_value: no brick is known to be all -1
     arena_reset(e);
     if (e->step_open) {  // the views of an open SC_KERNEL_STEP window are gone: no sample for them
         e->event_pool.push_back(e->step_start);
@@ -2718,6 +2844,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value != 1 && value != 2 && value != 4 && value != 8)
                 return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
             e->pack_rows = value;
+            return SC_OK;
+        case SC_OPT_VIEW_BRICK:
+            e->view_brick = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_FINAL_VOXELS:
             if (value != 1 && value != 2) return fail(SC_ERR_INVALID, "final_voxels must be 1 or 2");
@@ -2993,7 +3122,7 @@ int sc_fused_counts(sc_engine *e, int64_t out[4]) {
     if (!e->ctl) return SC_OK;  // no fused carve launched yet
     std::vector<ListCtl> host(1);
     HIP_TRY(hipMemcpy(host.data(), e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
-    out[0] = host[0].nlive;
+    out[0] = host[0].nlive[e->last_parity];
     for (int s = 0; s < kSub; ++s) {
         out[1] += host[0].count[0][s].n;
         out[2] += host[0].count[1][s].n;

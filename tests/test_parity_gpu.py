@@ -916,3 +916,88 @@ def test_device_batches_back_to_back_and_mixed_with_other_launches(gpu_device):
     for ptr, *_ in bufs:
         e.dev_free(ptr)
     e.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cx=1.0e4, cy=-7.0e3),                                   # principal point 10^4 px off the picture
+    dict(fx=1.0e5, fy=1.0e5),                                    # telephoto: a brick spans thousands of pixels
+    dict(fx=1.0e5, fy=1.0e5, radius_factor=40.0),                # ... or a fraction of one
+    dict(radius_factor=0.3),                                     # cameras inside the grid: bricks straddle p_z = 0
+    dict(radius_factor=0.55, tilt_deg=35.0),
+    dict(voxel_size=1.0e-3),                                     # coordinates 375.0xx: float32 steps of 3e-5
+    dict(voxel_size=1.0e3),
+    dict(voxel_size=1.0e-3, fx=1.0e5, fy=1.0e5),
+    dict(width=64, height=48, fx=30.0, fy=30.0, cx=32.0, cy=24.0),  # fisheye-like: most bricks leave the picture
+    dict(offaxis=1.0e4),                                         # principal point 10^4 px off AND the grid in the picture:
+    dict(offaxis=-3.0e3, radius_factor=0.8),                     # q * f and c nearly cancel in every pixel coordinate
+])
+@pytest.mark.parametrize("kind", ["plant", "solid", "empty", "dense"])
+def test_brick_verdicts_on_adversarial_cameras(gpu_device, kw, kind):
+    """The conservative brick verdicts (DESIGN.md 4b gives the bound) must never settle a voxel the
+    reference arithmetic would treat differently: device batches and host masks against the oracle
+    on rigs that stress every term of the bound."""
+    shape = (5, 48, 192)
+    kw = dict(kw)
+    off = kw.pop("offaxis", None)
+    _, origin, vs, views = scene(shape, 10, kind, **kw)
+    if off is not None:
+        # turn every camera about its own y axis and move the principal point so that the old optical
+        # axis still lands on the picture's centre: same pictures in view, a skewed projective camera
+        turned = []
+        for K, R, t, m in views:
+            th = np.arctan2(off, float(K[0]))
+            rot = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]])
+            R2 = (rot @ R.reshape(3, 3).astype(np.float64)).reshape(9).astype(np.float32)
+            t2 = (rot @ t.astype(np.float64)).astype(np.float32)
+            K2 = K.copy()
+            K2[2] = np.float32(float(K[2]) + off)
+            turned.append((K2, R2, t2, m))
+        views = turned
+    want = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    if off is not None and kind in ("solid", "dense"):
+        assert (want != 0).mean() > 0.03  # part of the grid really is in the picture
+    got, _ = _device_batch_carve(shape, origin, vs, views)
+    assert np.array_equal(got, want), (kw, kind, "device batch", histogram3(got), histogram3(want))
+    got = hip_carve(shape, origin, vs, views)
+    assert np.array_equal(got, want), (kw, kind, "host masks")
+    table = img_as_float32(np.arange(256, dtype=np.uint8))
+    wantf = oracle_c.average(list(shape), origin, vs, [(K, R, t, table[m]) for K, R, t, m in views])
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE)
+    e.set_lut(table)
+    for K, R, t, m in views:
+        e.process_view(K, R, t, m, nat.SC_MASK_U8_LUT)
+    assert np.array_equal(e.get_values().view(np.uint32), wantf.view(np.uint32)), (kw, kind, "average brick form")
+    e.close()
+
+
+@pytest.mark.parametrize("kind,shape,v", [("plant", (24, 48, 128), 9), ("solid", (6, 32, 128), 7), ("dense", (12, 48, 192), 8),
+                                          ("noise", (6, 16, 64), 6), ("empty", (5, 20, 70), 4), ("plant", (7, 37, 131), 7)])
+@pytest.mark.parametrize("default_value", [0, 1, -1, 7])
+def test_one_view_per_launch_brick_and_streaming_forms(gpu_device, kind, shape, v, default_value):
+    """The reference's cadence (one launch per view, cl.py:223-226) in both forms the engine has: brick
+    verdicts with dead-brick skipping (default) and the streaming kernel (SC_OPT_VIEW_BRICK 0); mixed
+    with fused batches and clears in between, the labels are always the oracle's."""
+    _, origin, vs, views = scene(shape, v, kind)
+    want = oracle_c.carve(list(shape), origin, vs, views, default_value, nthreads=4)
+    for vb in (1, 0):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=float(default_value))
+        e.set_option(nat.SC_OPT_VIEW_BRICK, vb)
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 1)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (kind, vb, "fresh")
+        for K, R, t, m in views[::-1]:  # again, on the stored volume, other order: idempotent
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (kind, vb, "stored")
+        e.clear()  # dead bricks are forgotten with the labels
+        half = len(views) // 2
+        for K, R, t, m in views[:half]:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)  # the rest as one fused batch on the stored volume
+        for K, R, t, m in views[half:]:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        e.flush()
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 1)
+        e.process_view(*views[0][:3], views[0][3], nat.SC_MASK_U8)  # and one more single view after it
+        assert np.array_equal(e.get_values(), want), (kind, vb, "mixed")
+        e.close()

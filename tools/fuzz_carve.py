@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep (GPU box): random grid shapes, scenes, camera set-ups, default values
-and pipeline knobs; every volume must equal the oracle's, fresh and on a second batch.
-Usage: timeout -k 10 300 tools/fuzz_carve.py [cases] [seed]     (diagnostic, not part of the test suite;
-prints each case before it runs so that a fault can be traced to its parameters).
-Round 1 note: the one attempt to run it ended with the GPU box lost -- scenes.make_scene then asked for
-a lattice of ~10^10 sample points for camera rings at 0.8 x the extent (host memory), fixed since;
-it has not been run again in round 1 (one more lost box would have closed the GPU pool)."""
+"""Randomised parity sweep (GPU box): random grid shapes, scenes, camera set-ups (rings inside the grid,
+principal points thousands of pixels off the picture, focal lengths up to 1e5, voxel sizes from 1e-3
+to 1e3), default values and pipeline knobs; every volume must equal the oracle's, fresh and on a
+second batch, through host masks or a device batch.
+Usage: timeout -k 10 900 python tools/fuzz_carve.py [cases] [seed] [summary.json]
+(diagnostic, not part of the test suite; prints each case before it runs so that a fault can be traced
+to its parameters; the summary of the round's run is kept under profiles/)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +15,11 @@ from oracle import oracle_c
 KNOBS = {
     "SC_OPT_FLAG_VIEWS": [0, 1, 3, 8, 11], "SC_OPT_DENSE_VIEWS": [1, 2, 3], "SC_OPT_STAGE1_VIEWS": [1, 4, 8, 64],
     "SC_OPT_STAGE2_VIEWS": [0, 2], "SC_OPT_VIEW_GROUP": [1, 5, 16], "SC_OPT_LIST_BLOCKS": [8, 64, 2048],
-    "SC_OPT_DEFER_STORES": [0, 8, 1280], "SC_OPT_DEFER_SHARE": [0, 5, 16], "SC_OPT_FULL_BRICKS": [0, 1],
+    "SC_OPT_DEFER_STORES": [0, 8, 1024], "SC_OPT_DEFER_SHARE": [0, 5, 16], "SC_OPT_FULL_BRICKS": [0, 1],
     "SC_OPT_BRICK": [0, 1, 1, 1], "SC_OPT_COMPACT": [0, 1, 1, 1], "SC_OPT_VIEW_ORDER": [0, 1],
     "SC_OPT_PACK_ROWS": [1, 2, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5],
+    "SC_OPT_PACK_RIDE": [0, 1], "SC_OPT_BRICK_WALKERS": [8, 1024], "SC_OPT_FILL_BLOCKS": [0, 1, 512],
+    "SC_OPT_FINAL_VOXELS": [1, 2], "SC_OPT_STAGE1_STORE_SHARE": [0, 4, 16], "SC_OPT_STAGE1_LIST_BLOCKS": [8, 1280],
 }
 
 def main():
@@ -26,13 +28,19 @@ def main():
     bad = 0
     for c in range(cases):
         shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
-        kind = str(rng.choice(["plant", "noise", "solid", "empty"]))
+        kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
         nviews = int(rng.integers(1, 16))
-        kw = dict(radius_factor=float(rng.choice([0.3, 0.8, 1.5, 3.0])), tilt_deg=float(rng.choice([0.0, 0.0, 25.0, 50.0])))
-        if rng.random() < 0.3:
-            w, h = int(rng.integers(20, 400)), int(rng.integers(20, 300))
+        kw = dict(radius_factor=float(rng.choice([0.3, 0.8, 1.5, 3.0])), tilt_deg=float(rng.choice([0.0, 0.0, 25.0, 50.0])),
+                  voxel_size=float(rng.choice([1e-3, 0.5, 0.5, 0.5, 1.7, 1e3])))
+        if rng.random() < 0.4:
+            w, h = int(rng.integers(2, 26)) * 16 if rng.random() < 0.6 else int(rng.integers(20, 400)), int(rng.integers(20, 300))
             kw.update(width=w, height=h, fx=float(rng.uniform(0.3, 3.0) * w), fy=float(rng.uniform(0.3, 3.0) * w),
                       cx=float(rng.uniform(0.2, 0.8) * w), cy=float(rng.uniform(0.2, 0.8) * h))
+            r = rng.random()
+            if r < 0.15:    # principal point far outside the picture
+                kw.update(cx=float(rng.choice([-1, 1]) * 1e4), cy=float(rng.choice([-1, 1]) * 7e3))
+            elif r < 0.3:   # telephoto
+                kw.update(fx=1e5, fy=1e5)
         sh, origin, vs, views = scenes.make_scene(shape, nviews, kind, **kw)
         dv = int(rng.choice([0, 0, 0, 1, -1, 5]))
         opts = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
@@ -60,6 +68,12 @@ def main():
         e.dev_free(ptr); e.close()
         bad += 0 if ok else 1
     print(f"{cases} cases, {bad} with mismatches")
+    if len(sys.argv) > 3:
+        import json
+        json.dump({"tool": "tools/fuzz_carve.py", "cases": cases, "seed": int(sys.argv[2]), "cases_with_mismatches": bad,
+                   "knobs": sorted(KNOBS), "scenes": ["plant", "noise", "solid", "empty", "dense"],
+                   "checked": "HIP carve (host masks or device batch, fresh volume and a second batch on the stored one) "
+                              "== oracle/spacecarve_oracle.c, every voxel"}, open(sys.argv[3], "w"), indent=1)
     return 1 if bad else 0
 
 if __name__ == "__main__":
