@@ -41,10 +41,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# non-packed f32 VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (one wave-instruction of
-# 64 lanes per 4 cycles per SIMD; packed f32 issues no faster on gfx950)
-VALU_PEAK_TLANEOPS = 39.3
-LANE_OPS_PER_VOXEL_VIEW = 50.0  # SURVEY 8d "VALU side": ~50 lane-ops per in-image voxel.view
+# f32 VALU issue.  Spec: 157.3 TFLOP/s FP32 vector = 78.6 T FMA lane-ops/s (guide: a wave64 v_fma_f32 issues in 2
+# cycles when at least two wavefronts share the SIMD; one wavefront alone issues every 4 cycles = 39.3 T).  The
+# averaging kernel has been measured ABOVE the 4-cycle figure on this chip (44 T lane-ops/s, 3.5 cycles per VALU
+# instruction per SIMD, profiles/r02_avg_sq_counters.json), so the 2-cycle figure is the ceiling used here.
+VALU_PEAK_TLANEOPS = 78.6
+# VALU lane-ops the `average` kernel executes per voxel.view: SQ_INSTS_VALU x 64 / (N x V) of a run in which
+# every (brick, view) pair is projected (profiles/r02_avg_sq_counters.json); SURVEY 8d estimated ~50
+LANE_OPS_PER_VOXEL_VIEW = 52.7
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
 # x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
@@ -224,7 +228,7 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
 def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
     """The `average` kernel (backprojection.c:36-55) on the three mask forms the host hands over
     (cl.py:205-215): uint8 binary and uint8 grey (bytes + 256-entry table, SC_MASK_U8_LUT) and
-    float32.  Bound: VALU issue -- every in-image voxel.view costs the projection (~50 lane-ops,
+    float32 (the binary masks converted, and random grey values).  Bound: VALU issue -- every in-image voxel.view costs the projection (~50 lane-ops,
     SURVEY 8d) whatever the mask holds; HBM traffic is 4 B per voxel once."""
     from plant3dvision_amd.cl import averaging_table, img_as_float32
     eng = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, device=device)
@@ -238,7 +242,8 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
     n = eng.num_voxels()
     out = {}
     for name, data, code in (("u8_binary", binary, nat.SC_MASK_U8_LUT), ("u8_grey", grey, nat.SC_MASK_U8_LUT),
-                             ("f32", img_as_float32(binary), nat.SC_MASK_F32)):
+                             ("f32", img_as_float32(binary), nat.SC_MASK_F32),
+                             ("f32_grey", img_as_float32(grey), nat.SC_MASK_F32)):
         eng.dev_upload(buf, data)
 
         def step():
@@ -253,8 +258,9 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
                "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
                             "frac": ach / VALU_PEAK_TLANEOPS,
                             "lane_ops_per_step": lane_ops,
-                            "model": "%.0f lane-ops per voxel.view (SURVEY 8d) x N x V" % LANE_OPS_PER_VOXEL_VIEW}}
-        if name == "u8_binary":
+                            "model": "%.1f VALU lane-ops per voxel.view (SQ_INSTS_VALU, profiles/r02_avg_sq_counters.json) "
+                                     "x N x V" % LANE_OPS_PER_VOXEL_VIEW}}
+        if name in ("u8_binary", "f32"):
             # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
             # projecting: the model above counts work the kernel did not do
             ent["roofline"]["frac"] = None

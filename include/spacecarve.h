@@ -89,8 +89,12 @@ extern "C" {
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
 #define SC_OPT_FULL_BRICKS 19     /* 1 (default): a brick EVERY view of the batch sees whole, in-image, over
                                      foreground only gets its labels (0 -> 1) without projecting a voxel */
-#define SC_OPT_AVG_BRICK 20       /* averaging with uint8 masks + table. 1 (default): bricks whose footprint in a
-                                     view is all 0 or all 255 add table[0] / table[255] without projecting */
+#define SC_OPT_AVG_BRICK 20       /* averaging. 1 (default): bricks whose footprint in a view is flat (all 0 / all 255 bytes,
+                                     or one float32 value) add that view's value without projecting          */
+#define SC_OPT_AVG_TILE_F32 29     /* averaging with float32 masks. 1 (default): the masks are re-laid in 8x4-pixel tiles
+                                     (one 128-byte line each) with per-region uniformity, and take the brick
+                                     form too (a footprint over ONE value adds it without projecting);
+                                     0: gathered row-major as handed over                                  */
 #define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
 #define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
 #define SC_OPT_PACK_RIDE 22        /* 1 (default): a batch of device-resident 1-byte masks (sc_process_views_device)

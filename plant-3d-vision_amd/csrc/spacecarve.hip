@@ -479,8 +479,13 @@ constexpr int kBrickY = 16, kBrickZ = 64;
 // every corner in front of the camera its image is the convex hull of the images of its four
 // corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
 // corners hold for every voxel of the brick.
-__device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
-                                                  int k0, int occ_tx) {
+struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == false: no verdict possible
+    int tx0, tx1, ty0, ty1;
+    bool ok;
+};
+
+__device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0) {
+    Footprint fpr{0, 0, 0, 0, false};
     float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
     float pzmin = INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
@@ -510,7 +515,7 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
     }
-    if (nan) return 0u;
+    if (nan) return fpr;
     bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
     // pixel-space slack: 2 px + propagated dot-product error + 8 ulp of the largest magnitude in
     // q * f + c (quotient estimate above, the voxel kernels' own division, product and sum
@@ -524,12 +529,19 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
     // a NaN anywhere makes a comparison false -> no culling
     bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
-    if (!inside) return 0u;
-    int tx0 = (int)umin >> 5, tx1 = (int)umax >> 5, ty0 = (int)vmin >> 5, ty1 = (int)vmax >> 5;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) return 0u;
+    if (!inside) return fpr;
+    fpr.tx0 = (int)umin >> 5; fpr.tx1 = (int)umax >> 5; fpr.ty0 = (int)vmin >> 5; fpr.ty1 = (int)vmax >> 5;
+    fpr.ok = (fpr.tx1 - fpr.tx0 + 1) * (fpr.ty1 - fpr.ty0 + 1) <= 64;
+    return fpr;
+}
+
+__device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
+                                                  int k0, int occ_tx) {
+    const Footprint fpr = brick_footprint(d, g, x, j0, k0);
+    if (!fpr.ok) return 0u;
     uint32_t any = 0, all = 3;
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
+    for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
+        for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
             uint32_t o = d.occ[ty * occ_tx + tx];
             any |= o;
             all &= o;
@@ -537,6 +549,26 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     // every voxel of the brick lands in-image on a pixel of these tiles: all of them background
     // (EMPTY: the view carves the whole brick) or all of them foreground (FULL: the view keeps it)
     return (any & 1u) == 0 ? 1u : ((all & 2u) != 0 ? 2u : 0u);
+}
+
+// float32 masks of the averaging kernel (tiled form, ViewDesc::pad == 2): behind the per-region flags
+// (d.occ: 1 = every pixel of the 32x32 region holds the same float, bit for bit) come the regions'
+// values.  A footprint over regions that all hold ONE value adds that value to every voxel of the brick
+// (backprojection.c:54) without projecting any: returns 3 and the value's bits, else 0.
+__device__ __forceinline__ uint32_t brick_flat_f32(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0,
+                                                   uint32_t &bits) {
+    const Footprint fpr = brick_footprint(d, g, x, j0, k0);
+    bits = 0u;
+    if (!fpr.ok) return 0u;
+    const int otx = (d.W + 31) >> 5, oty = (d.H + 31) >> 5;
+    const uint32_t *val = reinterpret_cast<const uint32_t *>(d.occ + (((size_t)otx * oty + 3) & ~(size_t)3));
+    const uint32_t first = val[fpr.ty0 * otx + fpr.tx0];
+    bool flat = true;
+    for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
+        for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx)
+            flat &= d.occ[ty * otx + tx] != 0 && val[ty * otx + tx] == first;
+    bits = first;
+    return flat ? 3u : 0u;
 }
 
 // The emptiness verdict of every brick ahead of the dense kernel: flags[brick] = 1 when ANY of the
@@ -1234,6 +1266,11 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
 //      makes of byte b, so table[mask] is the same float32 the reference would upload, at
 //      a quarter of the bytes and with tile-coherent gathers.  The table sits in LDS.
 constexpr int kATileW = 16, kATileH = 8;
+//   2  float32 in 8x4-pixel tiles (32 floats = one 128-byte line per tile; tilef_kernel)
+constexpr int kFTileW = 8, kFTileH = 4;
+__device__ __forceinline__ uint32_t ftile_offset(int u, int v, int tiles_x) {
+    return (__umul24((uint32_t)(v >> 2), (uint32_t)tiles_x) + (uint32_t)(u >> 3)) * 32u + (uint32_t)((v & 3) * 8 + (u & 7));
+}
 
 template <bool FRESH, bool VEC>
 __device__ __forceinline__ void average_body(float *__restrict__ values, const GridDesc &g,
@@ -1283,6 +1320,15 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
                 uint32_t b = 0;
                 if (ok[e]) b = m[off];
                 add[e] = lut_s[b];
+            }
+        } else if (d.pad == 2) {  // float32 in 8x4 tiles
+            const float *m = static_cast<const float *>(d.mask);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
+                add[e] = 0.0f;
+                if (ok[e]) add[e] = m[ftile_offset(u, v, d.tiles_x)];
             }
         } else {
             const float *m = static_cast<const float *>(d.mask);
@@ -1371,6 +1417,61 @@ __global__ __launch_bounds__(kBlock) void uniform_tiles_kernel(const uint8_t *__
     if (lane == 0) uni[tile] = (uint8_t)((anynz ? 1u : 0u) | (anyhole ? 0u : 2u));
 }
 
+// float32 [V][H][W] row-major -> 8x4-pixel tiles (32 floats = one 128-byte line per tile): the voxels a
+// wavefront projects land on a short image segment of any orientation, i.e. on a handful of lines,
+// where row-major floats give one line per 32 pixels of ONE row.  Fast form: W % 4 == 0 and 16-byte
+// aligned rows -- every lane moves four floats.
+__global__ __launch_bounds__(kBlock) void tilef_kernel(const float *__restrict__ raw, int64_t row_stride,
+                                                       int64_t view_stride, int W, int H, int nviews,
+                                                       int tiles_x, int tiles_y, float *__restrict__ out, int fast) {
+    int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int chunks = (W + 3) >> 2;
+    int64_t total = (int64_t)nviews * H * chunks;
+    if (idx >= total) return;
+    int c = (int)(idx % chunks);
+    int64_t r = idx / chunks;
+    int v = (int)(r % H);
+    int view = (int)(r / H);
+    const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(raw) + view * view_stride +
+                                                       (int64_t)v * row_stride) + c * 4;
+    float *dst = out + (int64_t)view * tiles_y * tiles_x * 32 + ftile_offset(c * 4, v, tiles_x);
+    if (fast) {
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+    } else {
+        int n = min(4, W - c * 4);
+        for (int k = 0; k < n; ++k) dst[k] = src[k];
+    }
+}
+
+// Per 32x32-pixel region of a tiled float mask: is it one value, bit for bit (pixels beyond the
+// picture do not count)?  flag byte + the value of its first pixel.  One wavefront per region.
+__global__ __launch_bounds__(kBlock) void uniform_f32_kernel(const float *__restrict__ tiled, int W, int H, int nviews,
+                                                             int tiles_x, int tiles_y, uint8_t *__restrict__ uni,
+                                                             size_t uni_view_bytes) {
+    const int otx = (W + 31) >> 5, oty = (H + 31) >> 5;
+    const int64_t reg = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (reg >= (int64_t)nviews * otx * oty) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int rx = (int)(reg % otx), ry = (int)((reg / otx) % oty), view = (int)(reg / ((int64_t)otx * oty));
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(tiled) + (int64_t)view * tiles_y * tiles_x * 32;
+    const uint32_t first = base[ftile_offset(rx * 32, ry * 32, tiles_x)];
+    bool same = true;
+    // lane l: row ry*32 + l/2, half l & 1 of the 32 columns
+    const int v = ry * 32 + (lane >> 1);
+    if (v < H) {
+        for (int q = 0; q < 16; ++q) {
+            const int u = rx * 32 + (lane & 1) * 16 + q;
+            if (u < W) same &= base[ftile_offset(u, v, tiles_x)] == first;
+        }
+    }
+    const unsigned long long differ = __ballot(!same);
+    if (lane == 0) {
+        uint8_t *f = uni + (size_t)view * uni_view_bytes;
+        f[ry * otx + rx] = differ == 0 ? 1 : 0;
+        reinterpret_cast<uint32_t *>(f + (((size_t)otx * oty + 3) & ~(size_t)3))[ry * otx + rx] = first;
+    }
+}
+
 // ---- brick form of the averaging kernel (uint8 masks + table) ---------------------------------
 // Masks out of a segmentation are mostly flat: background 0, foreground 255.  Where a brick's
 // footprint in a view (same conservative box as the carve's brick_verdict) lies over tiles of
@@ -1380,7 +1481,8 @@ __global__ __launch_bounds__(kBlock) void uniform_tiles_kernel(const uint8_t *__
 // footprint is mixed are projected voxel by voxel.
 __global__ __launch_bounds__(kBlock) void avg_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
                                                            int nviews, uint32_t bricks_y, uint32_t bricks_z,
-                                                           uint32_t nbricks, uint8_t *__restrict__ verd) {
+                                                           uint32_t nbricks, uint8_t *__restrict__ verd,
+                                                           uint32_t *__restrict__ verdf) {
     const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t vi = blockIdx.y;  // block-uniform view: scalar descriptor
     if (lb >= nbricks) return;
@@ -1390,6 +1492,13 @@ __global__ __launch_bounds__(kBlock) void avg_flags_kernel(GridDesc g, const Vie
     const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     const ViewDesc d = views[vi];
+    if (d.pad == 2) {  // tiled float32 mask: flat when every region under the brick holds one value
+        uint32_t bits;
+        const uint32_t v = brick_flat_f32(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), bits);
+        verd[(size_t)lb * (uint32_t)nviews + vi] = (uint8_t)v;
+        if (verdf != nullptr) verdf[(size_t)lb * (uint32_t)nviews + vi] = bits;
+        return;
+    }
     verd[(size_t)lb * (uint32_t)nviews + vi] =
         (uint8_t)brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), (d.W + 31) >> 5);
 }
@@ -1399,9 +1508,10 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
                                                                const ViewDesc *__restrict__ views, int nviews,
                                                                float init, const float *__restrict__ lut,
                                                                uint32_t bricks_y, uint32_t bricks_z,
-                                                               const uint8_t *__restrict__ verd) {
+                                                               const uint8_t *__restrict__ verd,
+                                                               const uint32_t *__restrict__ verdf) {
     __shared__ float lut_s[256];
-    lut_s[threadIdx.x] = lut[threadIdx.x];  // kBlock == 256
+    lut_s[threadIdx.x] = lut != nullptr ? lut[threadIdx.x] : 0.0f;  // kBlock == 256
     __syncthreads();
     const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
     const uint32_t per_plane = bricks_y * bricks_z;
@@ -1435,20 +1545,34 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;
     const float add0 = lut_s[0], add255 = lut_s[255];
     const uint8_t *myverd = verd + (size_t)lb * (uint32_t)nviews;
+    const uint32_t *myverdf = verdf != nullptr ? verdf + (size_t)lb * (uint32_t)nviews : nullptr;
     for (int v0 = 0; v0 < nviews; v0 += 64) {
         // the verdicts of up to 64 views, one per lane, handed out with v_readlane
         const int nv = min(64, nviews - v0);
         const uint32_t mine = ((int)lane < nv) ? myverd[v0 + (int)lane] : 0u;
+        const uint32_t minef = (myverdf != nullptr && (int)lane < nv) ? myverdf[v0 + (int)lane] : 0u;
         for (int q = 0; q < nv; ++q) {
             const uint32_t c = __builtin_amdgcn_readlane(mine, q);  // wave-uniform (brick-uniform)
             if (c != 0u) {
-                const float add = c == 1u ? add0 : add255;
+                const float add = c == 1u ? add0 : (c == 2u ? add255 : __uint_as_float(__builtin_amdgcn_readlane(minef, q)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = val[e] + add;  // :54, every voxel is in-image
                 continue;
             }
             const ViewDesc d = views[v0 + q];
             const float ax = d.R[0] * x + d.R[1] * y, ay = d.R[3] * x + d.R[4] * y, az = d.R[6] * x + d.R[7] * y;
+            if (d.pad == 2) {  // tiled float32 mask (wave-uniform)
+                const float *mf = static_cast<const float *>(d.mask);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int u, v;
+                    const bool ok = project(ax, ay, az, z[e], d, u, v);
+                    float add = 0.0f;
+                    if (ok) add = mf[ftile_offset(u, v, d.tiles_x)];
+                    if (ok) val[e] = val[e] + add;  // :54
+                }
+                continue;
+            }
             const uint8_t *m = static_cast<const uint8_t *>(d.mask);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1692,9 +1816,12 @@ struct sc_engine {
     bool ctl_clean[2] = {false, false};     // known to be all zero
     int ctl_idx = 0;
     int64_t full_bricks = 1;      // bricks every view sees whole over foreground get their label without projections
-    int64_t avg_brick = 1;        // averaging, uint8 + table: brick form with uniform-footprint verdicts
+    int64_t avg_brick = 1;        // averaging: brick form with uniform-footprint verdicts
+    int64_t avg_tile_f32 = 1;     // averaging: float32 masks are re-laid in 8x4-pixel tiles (0: read row-major)
     uint8_t *verd = nullptr;      // ... its [bricks][views] verdicts
     size_t verd_cap = 0;
+    uint32_t *verdf = nullptr;    // ... and, for tiled float32 masks, the value a flat footprint adds
+    size_t verdf_cap = 0;
     int64_t stage1_store_share = 4;  // sixteenths of the deferred strips filled beside the FIRST list stage
     int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
@@ -2101,6 +2228,48 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
                   uni ? uni + (size_t)q * uni_per_view : nullptr);
         d.tiles_x = tiles_x;
         d.pad = 1;
+        e->pending.push_back(d);
+    }
+    return SC_OK;
+}
+
+// averaging, float32 masks: raw device floats [V][H][W] -> 8x4 tiles + per-region uniformity; appends V
+// pending views (ViewDesc::pad == 2)
+int enqueue_tilef32(sc_engine *e, int V, const float *K, const float *R, const float *t, const void *raw_dev,
+                    int H, int W, int64_t row_stride, int64_t view_stride) {
+    const int tiles_x = (W + kFTileW - 1) / kFTileW, tiles_y = (H + kFTileH - 1) / kFTileH;
+    const size_t per_view = (size_t)tiles_x * tiles_y * 128;
+    void *tiled = nullptr;
+    int rc = arena_alloc(e, per_view * (size_t)V, &tiled);
+    if (rc) return rc;
+    const int fast = (W % 4) == 0 && (row_stride % 16) == 0 && (view_stride % 16) == 0 &&
+                     (reinterpret_cast<uintptr_t>(raw_dev) % 16) == 0;
+    const int64_t total = (int64_t)V * H * ((W + 3) / 4);
+    const int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
+    const size_t nreg = (size_t)((W + 31) / 32) * (size_t)((H + 31) / 32);
+    const size_t uni_view = ((nreg + 3) & ~(size_t)3) + nreg * 4;  // flags, then the regions' values
+    void *u = nullptr;
+    rc = arena_alloc(e, uni_view * (size_t)V, &u);
+    if (rc) return rc;
+    uint8_t *uni = static_cast<uint8_t *>(u);
+    LaunchTimer lt{e, SC_KERNEL_PACK};
+    rc = lt.begin();
+    if (rc) return rc;
+    hipLaunchKernelGGL(tilef_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, static_cast<const float *>(raw_dev),
+                       row_stride, view_stride, W, H, V, tiles_x, tiles_y, static_cast<float *>(tiled), fast);
+    const int64_t regs = (int64_t)V * (int64_t)nreg;
+    hipLaunchKernelGGL(uniform_f32_kernel, dim3((uint32_t)((regs + 3) / 4)), dim3(kBlock), 0, e->stream,
+                       static_cast<const float *>(tiled), W, H, V, tiles_x, tiles_y, uni, uni_view);
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    for (int q = 0; q < V; ++q) {
+        ViewDesc d;
+        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<char *>(tiled) + (size_t)q * per_view, H, W,
+                  uni + (size_t)q * uni_view);
+        d.tiles_x = tiles_x;
+        d.pad = 2;
         e->pending.push_back(d);
     }
     return SC_OK;
@@ -2544,26 +2713,39 @@ int flush(sc_engine *e, size_t count = 0) {
         if (rc) return rc;
         // brick form: uint8 masks with uniformity flags on every view of the batch, a table, a grid it fits
         const uint32_t abys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), abzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
-        bool abrick = nv > 1 && e->avg_brick && e->lut_dev != nullptr && (uint64_t)e->n < 0x80000000ull &&
+        bool abrick = nv > 1 && e->avg_brick && (uint64_t)e->n < 0x80000000ull &&
                       (uint64_t)e->planes * abys * abzs < 0x80000000ull;
-        for (size_t q = 0; q < nv && abrick; ++q) abrick = e->pending[q].pad == 1 && e->pending[q].occ != nullptr;
+        bool any_f32 = false;
+        for (size_t q = 0; q < nv && abrick; ++q) {
+            const ViewDesc &pd = e->pending[q];
+            abrick = (pd.pad == 1 && e->lut_dev != nullptr && pd.occ != nullptr) || (pd.pad == 2 && pd.occ != nullptr);
+            any_f32 |= pd.pad == 2;
+        }
         if (abrick) {
             const uint32_t anb = (uint32_t)((uint64_t)e->planes * abys * abzs);
             const size_t need = (size_t)anb * nv;
             if (need > e->verd_cap) {
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 if (e->verd) (void)hipFree(e->verd);
-    if (e->dead) (void)hipFree(e->dead);
                 e->verd = nullptr;
                 e->verd_cap = 0;
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->verd), need));
                 e->verd_cap = need;
             }
+            if (any_f32 && need > e->verdf_cap) {  // the flat values of float32 views
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (e->verdf) (void)hipFree(e->verdf);
+                e->verdf = nullptr;
+                e->verdf_cap = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->verdf), need * 4));
+                e->verdf_cap = need;
+            }
+            uint32_t *verdf = any_f32 ? e->verdf : nullptr;
             LaunchTimer ltf{e, SC_KERNEL_FLAGS};
             rc = ltf.begin();
             if (rc) return rc;
             hipLaunchKernelGGL(avg_flags_kernel, dim3((anb + kBlock - 1) / kBlock, (uint32_t)nv), block, 0, e->stream,
-                               g, vd, (int)nv, abys, abzs, anb, e->verd);
+                               g, vd, (int)nv, abys, abzs, anb, e->verd, verdf);
             rc = ltf.end();
             if (rc) return rc;
             LaunchTimer lta{e, SC_KERNEL_AVERAGE};
@@ -2571,10 +2753,10 @@ int flush(sc_engine *e, size_t count = 0) {
             if (rc) return rc;
             if (e->fresh)
                 hipLaunchKernelGGL(average_brick_kernel<true>, dim3(anb), block, 0, e->stream, st, g, vd, (int)nv,
-                                   e->default_value, e->lut_dev, abys, abzs, e->verd);
+                                   e->default_value, e->lut_dev, abys, abzs, e->verd, verdf);
             else
                 hipLaunchKernelGGL(average_brick_kernel<false>, dim3(anb), block, 0, e->stream, st, g, vd, (int)nv,
-                                   e->default_value, e->lut_dev, abys, abzs, e->verd);
+                                   e->default_value, e->lut_dev, abys, abzs, e->verd, verdf);
             HIP_TRY(hipGetLastError());
             rc = lta.end();
             if (rc) return rc;
@@ -2758,6 +2940,8 @@ void sc_destroy(sc_engine *e) {
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->verd) (void)hipFree(e->verd);
+    if (e->verdf) (void)hipFree(e->verdf);
+    if (e->dead) (void)hipFree(e->dead);
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
@@ -2820,6 +3004,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             return SC_OK;
         case SC_OPT_FULL_BRICKS:
             e->full_bricks = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_AVG_TILE_F32:
+            e->avg_tile_f32 = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_AVG_BRICK:
             e->avg_brick = value ? 1 : 0;
@@ -2966,6 +3153,12 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
         e->slot_armed[s] = true;
         rc = enqueue_tile8(e, 1, K, R, t, e->raw[s], H, W, (int64_t)row, (int64_t)bytes);
         if (rc) return rc;
+    } else if (e->avg_tile_f32) {
+        HIP_TRY(hipMemcpyAsync(e->raw[s], e->pin[s], bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->slot_ev[s], e->stream));
+        e->slot_armed[s] = true;
+        rc = enqueue_tilef32(e, 1, K, R, t, e->raw[s], H, W, (int64_t)row, (int64_t)bytes);
+        if (rc) return rc;
     } else {
         void *dst = nullptr;
         rc = arena_alloc(e, bytes, &dst);
@@ -3030,6 +3223,11 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
     }
     if (mask_dtype == SC_MASK_U8_LUT) {
         rc = enqueue_tile8(e, V, K, R, t, masks_dev, H, W, row, view);
+        if (rc) return rc;
+        return after_enqueue(e);
+    }
+    if (e->avg_tile_f32) {
+        rc = enqueue_tilef32(e, V, K, R, t, masks_dev, H, W, row, view);
         if (rc) return rc;
         return after_enqueue(e);
     }

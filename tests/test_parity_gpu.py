@@ -1001,3 +1001,46 @@ def test_one_view_per_launch_brick_and_streaming_forms(gpu_device, kind, shape, 
         e.process_view(*views[0][:3], views[0][3], nat.SC_MASK_U8)  # and one more single view after it
         assert np.array_equal(e.get_values(), want), (kind, vb, "mixed")
         e.close()
+
+
+@pytest.mark.parametrize("shape,kw", [((6, 32, 128), dict()), ((5, 37, 131), dict(width=330, height=207, fx=260.0, fy=260.0, cx=165.0, cy=103.0)),
+                                      ((4, 20, 70), dict(radius_factor=0.6))])
+@pytest.mark.parametrize("kind", ["plant", "solid", "grey"])
+@pytest.mark.parametrize("log", [False, True])
+def test_average_float32_masks_tiled_and_brick_form(gpu_device, shape, kw, kind, log):
+    """float32 masks (what cl.py:205-215 hands the kernel): re-laid in 8x4 tiles, flat footprints add
+    their one value without projecting -- bit-identical to the oracle's view-ordered float sum, in every
+    form the engine has (tiled + bricks, tiled linear, row-major), fused, in batches of 3 and per view,
+    through host masks and a device batch."""
+    _, origin, vs, views = scene(shape, 7, "plant" if kind == "grey" else kind, **kw)
+    rng = np.random.default_rng(4)
+    fviews = []
+    for K, R, t, m in views:
+        if kind == "grey":
+            f = rng.random(m.shape, dtype=np.float32)
+        else:
+            f = img_as_float32(m)
+            if log:
+                f = np.log(EPS + f).astype(np.float32)  # two values: flat nearly everywhere
+        fviews.append((K, R, t, np.ascontiguousarray(f, dtype=np.float32)))
+    want = oracle_c.average(list(shape), origin, vs, fviews, default_value=0.25)
+    stack = np.ascontiguousarray(np.stack([f for _, _, _, f in fviews]))
+    K = np.stack([v[0] for v in fviews]); R = np.stack([v[1] for v in fviews]); t = np.stack([v[2] for v in fviews])
+    for tile, brick in ((1, 1), (1, 0), (0, 1)):
+        for vpl in (0, 3, 1):
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, default_value=0.25)
+            e.set_option(nat.SC_OPT_AVG_TILE_F32, tile)
+            e.set_option(nat.SC_OPT_AVG_BRICK, brick)
+            e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+            for Kq, Rq, tq, f in fviews:
+                e.process_view(Kq, Rq, tq, f, nat.SC_MASK_F32)
+            got = e.get_values()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, log, tile, brick, vpl, "host masks")
+            e.clear()
+            ptr = e.dev_alloc(stack.nbytes)
+            e.dev_upload(ptr, stack)
+            e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_F32)
+            got = e.get_values()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, log, tile, brick, vpl, "device batch")
+            e.dev_free(ptr)
+            e.close()
