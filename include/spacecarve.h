@@ -214,6 +214,13 @@ int sc_synchronize(sc_engine *e);
  */
 int sc_get_values(sc_engine *e, void *out);
 
+/*
+ * The same read-back for carve labels as int8 (labels are -1 / 0 / 1, or default_value where no view
+ * reached; SC_ERR_STATE if default_value does not fit): a quarter of the bytes cross PCIe; the host
+ * mirror widens them back to the int32 array cl.py:229-232 returns.  (i1-i0)*ny*nz bytes.
+ */
+int sc_get_values_i8(sc_engine *e, int8_t *out);
+
 /* Flush and return the device pointer of the state slab (valid until sc_destroy);
  * work may still be running on the engine's stream. */
 int sc_values_device_ptr(sc_engine *e, void **ptr);

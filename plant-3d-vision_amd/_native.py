@@ -55,6 +55,7 @@ _SIGNATURES = {
     "sc_flush": ("i", ["p"]),
     "sc_synchronize": ("i", ["p"]),
     "sc_get_values": ("i", ["p", "p"]),
+    "sc_get_values_i8": ("i", ["p", "p"]),
     "sc_values_device_ptr": ("i", ["p", "p"]),
     "sc_num_voxels": ("q", ["p"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
@@ -231,14 +232,44 @@ def pinned_empty(shape, dtype, device=0):
     return np.frombuffer(owner, dtype=dtype).reshape(shape)
 
 
+def host_workers(limit=16):
+    """Threads for host-side helpers (decode-ahead, page touching, widening): the CPUs this process
+    may run on, at most ``limit`` (a GPU box gives 16 CPUs to one GPU)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(int(limit), avail))
+
+
+def widen_i8(dst, src, workers=None):
+    """``dst[...] = src`` (int8 -> int32, same shape) slab by slab on a few threads."""
+    import threading
+    flat_d, flat_s = dst.reshape(-1), src.reshape(-1)
+    n = flat_d.size
+    workers = workers or host_workers()
+    parts = max(1, min(workers, n // (1 << 20) or 1))
+    bounds = [n * q // parts for q in range(parts + 1)]
+
+    def work(a, b):
+        np.copyto(flat_d[a:b], flat_s[a:b], casting="unsafe")  # releases the GIL
+
+    ths = [threading.Thread(target=work, args=(bounds[q], bounds[q + 1])) for q in range(parts)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+
+
 class TouchedEmpty:
     """``np.empty(shape, dtype)`` whose pages are being touched on a few host threads (no HIP calls
     on them): a 512 MiB read-back into a fresh array spends 40 ms in first-touch page faults, into
     touched pages 10 ms.  Start it before the device work, call ``result()`` when the array is
     needed."""
 
-    def __init__(self, shape, dtype, threads=4):
+    def __init__(self, shape, dtype, threads=None):
         import threading
+        threads = threads or host_workers()
         self._arr = np.empty(shape, dtype=dtype)
         flat = self._arr.reshape(-1)
         step = max(1, 4096 // self._arr.itemsize)
@@ -407,6 +438,15 @@ class Engine:
                 or not out.flags["C_CONTIGUOUS"]:
             raise ValueError("output buffer has the wrong dtype/size/layout")
         self._call("sc_get_values", addr(out))
+        return out
+
+    def get_values_i8(self, out=None):
+        """Carve labels as int8 (a quarter of the bytes over PCIe)."""
+        if out is None:
+            out = np.empty(self.slab_shape, dtype=np.int8)
+        if out.dtype != np.int8 or out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("output buffer has the wrong dtype/size/layout")
+        self._call("sc_get_values_i8", addr(out))
         return out
 
     def values_device_ptr(self):

@@ -1700,6 +1700,25 @@ __global__ __launch_bounds__(kBlock) void project_selftest_kernel(uint64_t count
     }
 }
 
+// int32 labels -> int8 (sc_get_values_i8): 16 labels per lane, 4 coalesced 16-byte loads in flight,
+// one 16-byte store.
+__global__ __launch_bounds__(kBlock) void narrow_i8_kernel(const int32_t *__restrict__ src, int8_t *__restrict__ dst,
+                                                           uint64_t n) {
+    const uint64_t base = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+    if (base + 16 <= n && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = *reinterpret_cast<const int4 *>(src + base + 4 * q);
+            w[q] = ((uint32_t)v.x & 0xffu) | (((uint32_t)v.y & 0xffu) << 8) | (((uint32_t)v.z & 0xffu) << 16) |
+                   (((uint32_t)v.w & 0xffu) << 24);
+        }
+        *reinterpret_cast<uint4 *>(dst + base) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (uint64_t i = base; i < n && i < base + 16; ++i) dst[i] = (int8_t)src[i];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
                                                       uint32_t bits) {
     uint64_t idx = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -1835,6 +1854,7 @@ struct sc_engine {
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
+    int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
     uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
     uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
@@ -2939,6 +2959,7 @@ void sc_destroy(sc_engine *e) {
     }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
+    if (e->narrow) (void)hipFree(e->narrow);
     if (e->verd) (void)hipFree(e->verd);
     if (e->verdf) (void)hipFree(e->verdf);
     if (e->dead) (void)hipFree(e->dead);
@@ -3263,6 +3284,26 @@ int sc_get_values(sc_engine *e, void *out) {
     rc = materialize(e);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, e->state, (size_t)e->n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SC_OK;
+}
+
+int sc_get_values_i8(sc_engine *e, int8_t *out) {
+    if (!e || !out) return fail(SC_ERR_INVALID, "null argument");
+    if (e->mode != SC_MODE_CARVE) return fail(SC_ERR_STATE, "int8 read-back is for carve labels");
+    const int32_t init = init_bits_i32(e);
+    if (init < -128 || init > 127) return fail(SC_ERR_STATE, "default_value %d does not fit int8", init);
+    int rc = sc_flush(e);
+    if (rc) return rc;
+    rc = materialize(e);
+    if (rc) return rc;
+    if (!e->narrow) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->narrow), (size_t)e->n));
+    const uint64_t n = (uint64_t)e->n;
+    const uint64_t blocks = (n + (uint64_t)kBlock * 16 - 1) / ((uint64_t)kBlock * 16);
+    hipLaunchKernelGGL(narrow_i8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                       static_cast<const int32_t *>(e->state), e->narrow, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, e->narrow, (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return SC_OK;
 }

@@ -1044,3 +1044,38 @@ def test_average_float32_masks_tiled_and_brick_form(gpu_device, shape, kw, kind,
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, log, tile, brick, vpl, "device batch")
             e.dev_free(ptr)
             e.close()
+
+
+def test_int8_read_back_of_carve_labels(gpu_device):
+    """sc_get_values_i8: the labels as bytes (a quarter of the PCIe traffic); the class widens them back
+    to the int32 array of cl.py:229-232 for volumes large enough to pay."""
+    shape, origin, vs, views = scene((40, 33, 70), 6, "plant")
+    for dv in (0, 1, -1, 7, -128, 127):
+        want = oracle_c.carve(list(shape), origin, vs, views, dv)
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=float(dv))
+        assert np.array_equal(e.get_values_i8(), np.full(shape, dv, dtype=np.int8))  # before any view
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        got = e.get_values_i8()
+        assert got.dtype == np.int8 and np.array_equal(got.astype(np.int32), want), dv
+        assert np.array_equal(e.get_values(), want)
+        e.close()
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=300.0)
+    with pytest.raises(nat.SpaceCarveError, match="does not fit int8"):
+        e.get_values_i8()
+    e.close()
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE)
+    with pytest.raises(nat.SpaceCarveError):
+        e.get_values_i8()
+    e.close()
+    # the class: a volume of 2^24+ voxels goes through the int8 path and comes back int32
+    big, origin, vs, views = scene((64, 512, 512), 8, "plant")
+    want = oracle_c.carve(list(big), origin, vs, views, nthreads=8)
+    bp = Backprojection(big, origin, vs)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    got = bp.get_values()  # first read-back: int32, the byte buffers are prepared meanwhile
+    assert got.dtype == np.int32 and np.array_equal(got, want) and bp._narrow_h is not None
+    again = bp.get_values()  # second: through int8
+    assert again.dtype == np.int32 and np.array_equal(again, want) and isinstance(bp._narrow_h, np.ndarray)
+    bp.close()
