@@ -104,11 +104,12 @@ extern "C" {
 #define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
                                      that many persistent blocks walking the strips (512 = two per CU: a
                                      wavefront's stores do not hold it up, so few keep the write path busy) */
-#define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1 or 2 (default)          */
+#define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1, 2 (default) or 4         */
 #define SC_OPT_VIEW_BRICK 26        /* 1 (default): a launch of ONE view (the reference's cadence, cl.py:223-226)
                                      uses the brick verdicts too: bricks the view sees whole over background
                                      are carved blind and skipped by later views; 0: the streaming kernel
                                      (every view reads the whole state: the north star's formulation)          */
+#define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1 (default), 2 or 4                  */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

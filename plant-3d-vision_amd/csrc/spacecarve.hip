@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         }
         // U views per iteration.  The final stage is bound by arithmetic (U = 2); the stages before
         // it wait on memory and most of their voxels die within a few views (U = 4).
-        constexpr int U = FINAL ? 2 : 4;
+        constexpr int U = P >= 4 ? 1 : (FINAL ? 2 : 4);
         for (int vi = v0; vi < v1; vi += U) {
             bool any = false;
 #pragma unroll
@@ -1850,6 +1850,7 @@ struct sc_engine {
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
     bool dead_clean = false;   // `dead` is known to be all zero
     int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
+    int64_t stage1_voxels = 1; // ... in the stages before it
     int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
@@ -2696,7 +2697,8 @@ int flush(sc_engine *e, size_t count = 0) {
             }
 #define LAUNCH_LIST(FIN, GRID, ...)                                                                      \
     do {                                                                                                 \
-        if (FIN && e->final_voxels == 2) hipLaunchKernelGGL((carve_list_kernel<FIN, FIN ? 2 : 1>), GRID, block, 0, e->stream, __VA_ARGS__); \
+        if ((FIN ? e->final_voxels : e->stage1_voxels) == 4) hipLaunchKernelGGL((carve_list_kernel<FIN, 4>), GRID, block, 0, e->stream, __VA_ARGS__); \
+        else if ((FIN ? e->final_voxels : e->stage1_voxels) == 2) hipLaunchKernelGGL((carve_list_kernel<FIN, 2>), GRID, block, 0, e->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((carve_list_kernel<FIN, 1>), GRID, block, 0, e->stream, __VA_ARGS__);     \
     } while (0)
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
@@ -3056,8 +3058,12 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_VIEW_BRICK:
             e->view_brick = value ? 1 : 0;
             return SC_OK;
+        case SC_OPT_STAGE1_VOXELS:
+            if (value != 1 && value != 2 && value != 4) return fail(SC_ERR_INVALID, "stage1_voxels must be 1, 2 or 4");
+            e->stage1_voxels = value;
+            return SC_OK;
         case SC_OPT_FINAL_VOXELS:
-            if (value != 1 && value != 2) return fail(SC_ERR_INVALID, "final_voxels must be 1 or 2");
+            if (value != 1 && value != 2 && value != 4) return fail(SC_ERR_INVALID, "final_voxels must be 1, 2 or 4");
             e->final_voxels = value;
             return SC_OK;
         case SC_OPT_FILL_BLOCKS:

@@ -167,6 +167,8 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_FILL_BLOCKS": 3, "SC_OPT_STAGE1_STORE_SHARE": 8},            # a few persistent ones
     {"SC_OPT_PACK_RIDE": 0},                                              # every mask packed ahead
     {"SC_OPT_FINAL_VOXELS": 1},                                           # one survivor per lane in the final stage
+    {"SC_OPT_FINAL_VOXELS": 4, "SC_OPT_STAGE1_VOXELS": 2},                # four, one view per turn; two in the first stage
+    {"SC_OPT_STAGE1_VOXELS": 4, "SC_OPT_VIEW_GROUP": 3},
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
