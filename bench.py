@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=512, help="per-GPU grid edge (voxels)")
     ap.add_argument("--views", type=int, default=72)
-    ap.add_argument("--scene", default="plant", choices=["plant", "solid", "noise"])
+    ap.add_argument("--scene", default="plant", choices=["plant", "solid", "noise", "dense"])
     ap.add_argument("--path", default="fused", choices=["fused", "stream"],
                     help="schedule reported as `value` (the other is reported beside it)")
     ap.add_argument("--gather", default="none", choices=["none", "allgather", "allgather8", "allreduce"],

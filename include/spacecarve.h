@@ -109,7 +109,7 @@ extern "C" {
                                      uses the brick verdicts too: bricks the view sees whole over background
                                      are carved blind and skipped by later views; 0: the streaming kernel
                                      (every view reads the whole state: the north star's formulation)          */
-#define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1 (default), 2 or 4                  */
+#define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1, 2 (default) or 4                  */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

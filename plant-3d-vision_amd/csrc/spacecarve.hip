@@ -102,20 +102,10 @@ struct ListCtl {
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
-// FULL candidates the flags kernel left open (flag 3: every view it could see keeps the brick whole,
-// but the masks of views [v0, v1) were not packed yet -- they are packed beside the dense stage): the
-// store blocks, which run after that, put the question to the remaining views.
-struct Confirm {
-    const ViewDesc *views;  // the batch's descriptors
-    int32_t v0, v1;
-    uint32_t *late;         // bricks some later view does not keep whole: carved by the resume kernel
-    ListCtl *ctl;
-};
 struct CullStores {
     const uint8_t *flags;  // null: nothing deferred
     uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
     int32_t kept, fresh;   // see Fill
-    Confirm cf;
     uint32_t fill_blocks;  // 0: one store block per strip; n: n persistent store blocks
 };
 
@@ -834,44 +824,20 @@ struct Fill {
 
 __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
                                                     const uint8_t *__restrict__ flags, uint32_t strip,
-                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill,
-                                                    const Confirm &cf) {
-    __shared__ int s_whole;
+                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
     const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
     const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
-    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u), cand = __ballot(f == 3u);
-    const bool mine = j < g.ny;  // a strip at the far y face may stick out of the grid
-    int32_t *col = labels + ((uint64_t)il * g.ny + (mine ? j : 0u)) * g.nz;
+    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
+    if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
     const bool vec = (g.nz & 3u) == 0;
     for (uint32_t bz = 0; bz < bricks_z; ++bz) {
-        bool isfull = (full >> bz) & 1ull;
-        if ((cand >> bz) & 1ull) {  // block-uniform: every wavefront read the same flags
-            if (wave == 0) {
-                const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-                bool whole = true;
-                for (int base = cf.v0; base < cf.v1; base += 64) {  // one lane per remaining view
-                    const int vi = base + (int)lane;
-                    bool keeps = true;
-                    if (vi < cf.v1) {
-                        const ViewDesc d = cf.views[vi];
-                        keeps = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x) == 2u;
-                    }
-                    whole &= __ballot(!keeps) == 0;
-                }
-                if (lane == 0) {
-                    s_whole = whole ? 1 : 0;
-                    if (!whole) cf.late[atomicAdd(&cf.ctl->nlate, 1u)] = strip * bricks_z + bz;
-                }
-            }
-            __syncthreads();
-            isfull = s_whole != 0;
-            __syncthreads();  // s_whole is free for the next candidate
-        }
+        const bool isfull = (full >> bz) & 1ull;
         if (!((culled >> bz) & 1ull) && !isfull) continue;
         const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
-        if (!mine || k0 >= g.nz) continue;
+        if (k0 >= g.nz) continue;
         const uint32_t n = min(4u, g.nz - k0);
         if (!isfull || fill.fresh) {
             const int32_t val = isfull ? fill.kept : -1;
@@ -888,6 +854,53 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
             for (uint32_t e = 0; e < n; ++e)
                 if (col[k0 + e] == 0) col[k0 + e] = 1;
         }
+    }
+}
+
+// FULL candidates (flag 3: every view the flags kernel could see keeps the brick whole, but the masks
+// of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
+// views: same organisation as the flags kernel's own FULL rounds (64 bricks per block, one view per
+// wavefront and round, verdicts joined in LDS).  Kept by all: flag 2, filled like any FULL brick.
+// Otherwise flag 5 and a place on the LATE list: the resume kernel carves such a brick over all the
+// views of the batch, voxel by voxel.  A block without candidates leaves at once.
+__global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
+    GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
+    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
+    __shared__ unsigned long long s_full[kFlagWaves];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t lb = blockIdx.x * 64u + lane;
+    const bool isc = lb < nbricks && flags[lb] == 3u;
+    unsigned long long cand = __ballot(isc);
+    if (cand == 0) return;  // block-uniform: every wavefront read the same 64 flags
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
+        const int vi = base + (int)wave;
+        bool keeps = true;
+        if (vi < v1 && ((cand >> lane) & 1ull)) {
+            const ViewDesc d = views[vi];
+            keeps = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x) == 2u;
+        }
+        const unsigned long long mf = __ballot(keeps);
+        __syncthreads();  // the previous round's masks have been read by everybody
+        if (lane == 0) s_full[wave] = mf;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kFlagWaves; ++w) cand &= s_full[w];
+    }
+    if (wave != 0) return;
+    if (isc) flags[lb] = ((cand >> lane) & 1ull) ? 2 : 5;
+    const bool failed = isc && !((cand >> lane) & 1ull);
+    const unsigned long long m = __ballot(failed);
+    if (m != 0) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctl->nlate, (uint32_t)__popcll(m));
+        pos = __shfl(pos, 0);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (failed) late[pos + (uint32_t)__popcll(m & below)] = lb;
     }
 }
 
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     if (blockIdx.x >= nwalkers) {
         store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
-                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0}, Confirm{nullptr, 0, 0, nullptr, nullptr});
+                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0});
         return;
     }
     const uint32_t nlive = ctl->nlive[parity];
@@ -1070,7 +1083,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         // wavefront's stores do not hold it up, so few of them keep the write path busy and the
         // wavefront slots go to the list blocks
         for (uint32_t strip = cs.first + (blockIdx.x - nbid); strip < cs.nstrips; strip += nstore)
-            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh}, cs.cf);
+            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh});
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
@@ -1201,7 +1214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
 
 // Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
 // nothing), a persistent grid applies the remaining views densely instead.
-struct LateBricks {           // FULL candidates that turned out not to be (see Confirm)
+struct LateBricks {           // FULL candidates that turned out not to be (see brick_confirm_kernel)
     const uint32_t *late;     // null: the batch had no open candidates
     const ViewDesc *allviews; // every view of the batch
     const uint8_t *flags;
@@ -1242,12 +1255,13 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
         uint64_t grp = blk * kBlock + threadIdx.x;
         bool skip = grp >= g.ngroups;
         if (!skip && lb.late != nullptr) {
-            // candidates are settled elsewhere (kept whole by the store blocks, or carved above over
-            // ALL views by a block that may not have written them yet): not this pass's voxels
+            // bricks every view keeps whole have nothing to gain from this pass, and late bricks are carved
+            // above over ALL views by a block that may not have written them yet: not this pass's voxels
             Vox4 vx;
             decode_group(g, grp, vx);
             const uint32_t col = (uint32_t)(vx.elem / g.nz), il = col / g.ny, j = col - il * g.ny;
-            skip = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ] == 3u;
+            const uint32_t fl = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ];
+            skip = fl == 5u || fl == 2u;
         }
         // (a wavefront's lanes leave carve_group's view loop together: skipped lanes still vote)
         if (grp < g.ngroups && !skip) {
@@ -1850,7 +1864,7 @@ struct sc_engine {
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
     bool dead_clean = false;   // `dead` is known to be all zero
     int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
-    int64_t stage1_voxels = 1; // ... in the stages before it
+    int64_t stage1_voxels = 2; // ... in the stages before it
     int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
@@ -2674,9 +2688,12 @@ int flush(sc_engine *e, size_t count = 0) {
             if (rc) return rc;
             int vg = (int)e->view_group;
             // open FULL candidates exist only when packing rode beside the dense stage
-            const Confirm cf = ride_blocks ? Confirm{vd, packed_ahead, (int32_t)nv, e->late, e->ctl}
-                                           : Confirm{nullptr, 0, 0, nullptr, nullptr};
-            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, Confirm{nullptr, 0, 0, nullptr, nullptr}, 0u}, cs = none;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u}, cs = none;
+            if (ride_blocks) {
+                // the riders have packed the rest of the masks: open FULL candidates get their answer
+                hipLaunchKernelGGL(brick_confirm_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0, e->stream, g,
+                                   vd, packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
+            }
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
             dim3 fgrid(list_blocks);
@@ -2688,11 +2705,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 if ((size_t)s1 < nv && e->stage1_store_share > 0) {
                     mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
                     const uint32_t n1 = mid - dense_store_strips, f1 = std::min<uint32_t>((uint32_t)e->fill_blocks, n1);
-                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf, f1};
+                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, f1};
                     grid1 = dim3((uint32_t)e->stage1_list_blocks + (f1 ? f1 : n1));
                 }
                 const uint32_t nf = nstrips - mid, ff = std::min<uint32_t>((uint32_t)e->fill_blocks, nf);
-                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, cf, ff};
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff};
                 fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
 #define LAUNCH_LIST(FIN, GRID, ...)                                                                      \
@@ -3373,6 +3390,7 @@ int sc_fused_counts(sc_engine *e, int64_t out[4]) {
         out[2] += host[0].count[1][s].n;
     }
     out[3] = host[0].overflow;
+
     return SC_OK;
 }
 

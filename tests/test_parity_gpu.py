@@ -172,6 +172,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
+                                        ("dense", (14, 48, 192)),    # a bulky object: whole-brick masks at work
                                         ("plant", (7, 23, 70)),      # bricks stick out in y and z
                                         ("plant", (5, 37, 131))])    # ... and nz % 4 != 0: element accesses
 def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape):
