@@ -309,6 +309,31 @@ int sc_dev_free(sc_engine *e, void *ptr);
 int sc_dev_upload(sc_engine *e, void *dst_dev, const void *src_host, int64_t bytes);
 int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t bytes);
 
+/*
+ * Several GPUs from ONE process (SURVEY.md 8b `sc_create_sharded`; the reference drives a single
+ * device, cl.py:29-30): one engine per entry of `devices` (HIP ordinals; an ordinal may repeat), the
+ * x-planes of the grid dealt round-robin over them (partition 0; every device then holds the same share
+ * of the object) or in contiguous slabs (partition 1), voxel coordinates from the GLOBAL plane index as
+ * in sc_create_cyclic / sc_create_slab.  Every view goes to every engine; sc_group_get_values writes
+ * the whole [nx][ny][nz] grid in global order (one strided device-to-host copy per device).  The
+ * one-process-per-GPU form of the same sharding is plant-3d-vision_amd/sharded.py over RCCL.
+ */
+typedef struct sc_group sc_group;
+int sc_create_sharded(sc_group **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],
+                      float voxel_size, int mode, float default_value, const int *devices, int ndev,
+                      int partition);
+void sc_group_destroy(sc_group *g);
+int sc_group_size(const sc_group *g);
+sc_engine *sc_group_engine(sc_group *g, int i);  /* for per-engine calls (options, statistics, device batches) */
+int sc_group_clear(sc_group *g);
+int sc_group_set_option(sc_group *g, int key, int64_t value);
+int sc_group_set_lut(sc_group *g, const float *lut256);
+int sc_group_process_view(sc_group *g, const float K[4], const float R[9], const float t[3], const void *mask,
+                          int H, int W, int mask_dtype, int64_t row_stride_bytes);
+int sc_group_flush(sc_group *g);
+int sc_group_synchronize(sc_group *g);
+int sc_group_get_values(sc_group *g, void *out);
+
 #ifdef __cplusplus
 }
 #endif

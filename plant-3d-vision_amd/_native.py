@@ -68,6 +68,17 @@ _SIGNATURES = {
     "sc_free_host": ("v", ["p"]),
     "sc_label_points": ("i", ["p", "q", "i", "i", "p", "p", "p", "p", "i", "i", "i", "i", "p", "p"]),
     "sc_label_points_last_error": ("s", []),
+    "sc_create_sharded": ("i", ["p", "q", "q", "q", "p", "f", "i", "f", "p", "i", "i"]),
+    "sc_group_destroy": ("v", ["p"]),
+    "sc_group_size": ("i", ["p"]),
+    "sc_group_engine": ("p", ["p", "i"]),
+    "sc_group_clear": ("i", ["p"]),
+    "sc_group_set_option": ("i", ["p", "i", "q"]),
+    "sc_group_set_lut": ("i", ["p", "p"]),
+    "sc_group_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
+    "sc_group_flush": ("i", ["p"]),
+    "sc_group_synchronize": ("i", ["p"]),
+    "sc_group_get_values": ("i", ["p", "p"]),
     "sc_host_alloc": ("i", ["i", "q", "p"]),
     "sc_host_free": ("v", ["p"]),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
@@ -520,3 +531,84 @@ class Engine:
     def dev_download(self, dst, src_dev):
         assert dst.flags["C_CONTIGUOUS"]
         self._call("sc_dev_download", addr(dst), int(src_dev), int(dst.nbytes))
+
+
+class EngineGroup:
+    """Several devices driven from this process (``sc_create_sharded``): same surface as ``Engine``
+    for what ``Backprojection`` needs; the grid comes back whole, in global order."""
+
+    def __init__(self, shape, origin, voxel_size, mode, devices, default_value=0.0, partition="cyclic"):
+        self._b = backend()
+        self._h = 0
+        nx, ny, nz = (int(s) for s in shape)
+        devs = np.ascontiguousarray(np.asarray(list(devices), dtype=np.int32))
+        origin32 = np.ascontiguousarray(np.asarray(origin, dtype=np.float32).reshape(3))
+        out = np.zeros(1, dtype=np.uintp)
+        if partition not in ("cyclic", "slab"):
+            raise ValueError("partition must be 'cyclic' or 'slab'")
+        check(self._b.call("sc_create_sharded", addr(out), nx, ny, nz, addr(origin32), float(np.float32(voxel_size)),
+                           int(mode), float(default_value), addr(devs), int(devs.size),
+                           0 if partition == "cyclic" else 1), "sc_create_sharded")
+        self._h = int(out[0])
+        self.mode = int(mode)
+        self.shape = self.slab_shape = (nx, ny, nz)
+        self.dtype = np.int32 if mode == SC_MODE_CARVE else np.float32
+        self.devices = [int(d) for d in devs]
+
+    def close(self):
+        if self._h:
+            self._b.call("sc_group_destroy", self._h)
+            self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        if not self._h:
+            raise SpaceCarveError("engine group is closed")
+        check(self._b.call(name, self._h, *args), name)
+
+    def set_option(self, key, value):
+        self._call("sc_group_set_option", int(key), int(value))
+
+    def set_lut(self, lut):
+        lut = np.ascontiguousarray(np.asarray(lut, dtype=np.float32).reshape(-1))
+        if lut.size != 256:
+            raise ValueError("the table has 256 entries")
+        self._call("sc_group_set_lut", addr(lut))
+
+    def clear(self):
+        self._call("sc_group_clear")
+
+    def process_view(self, K, R, t, mask, mask_dtype):
+        K, R, t = Engine._pose(K, R, t)
+        if K.size != 4 or R.size != 9 or t.size != 3:
+            raise ValueError("need intrinsics[4], rot[9], tvec[3]")
+        if mask.ndim != 2:
+            raise ValueError("mask must be 2-D (H, W)")
+        mask = np.ascontiguousarray(mask)
+        H, W = mask.shape
+        self._call("sc_group_process_view", addr(K), addr(R), addr(t), addr(mask), H, W, int(mask_dtype), 0)
+
+    def flush(self):
+        self._call("sc_group_flush")
+
+    def synchronize(self):
+        self._call("sc_group_synchronize")
+
+    def get_values(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        if out.dtype != self.dtype or out.size != int(np.prod(self.shape)) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("output buffer has the wrong dtype/size/layout")
+        self._call("sc_group_get_values", addr(out))
+        return out
+
+    def values_device_ptr(self):
+        return None  # the grid lives on several devices
+
+    def num_voxels(self):
+        return int(np.prod(self.shape))

@@ -163,7 +163,8 @@ def _assign_and_return(dst, src):
 class Backprojection(object):
     """Back-projection onto a voxel volume (drop-in for ``plant3dvision.cl.Backprojection``).
 
-    Parameters are the reference's (cl.py:118); ``device`` and ``views_per_launch`` are
+    Parameters are the reference's (cl.py:118); ``device`` (an ordinal, or a list of ordinals to
+    shard the grid's x-planes over several GPUs from this one process) and ``views_per_launch`` are
     additions with neutral defaults.
 
     Attributes
@@ -223,8 +224,13 @@ class Backprojection(object):
         consumers; the device state starts as ``default_value`` everywhere."""
         if self._engine is not None:
             self._engine.close()
-        self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
-                                  default_value=float(self.default_value), device=self.device)
+        if isinstance(self.device, (list, tuple)):
+            # several GPUs from this process: x-planes dealt round-robin (sc_create_sharded)
+            self._engine = nat.EngineGroup(self.shape, self.origin, self.voxel_size, self._mode, self.device,
+                                           default_value=float(self.default_value))
+        else:
+            self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
+                                      default_value=float(self.default_value), device=self.device)
         self._lut = None
         if self.views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(self.views_per_launch))

@@ -3514,4 +3514,119 @@ int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t b
     return SC_OK;
 }
 
+// ---- several devices from one process (sc_create_sharded) ----------------------------
+// One engine per device, the x-planes dealt round-robin (or in contiguous slabs) exactly as the
+// one-process-per-GPU path deals them to ranks; every view goes to every engine; the read-back lands
+// each engine's planes at their global x positions with one strided copy per device.
+
+}  // extern "C"
+
+struct sc_group {
+    std::vector<sc_engine *> eng;
+    int64_t nx = 0, ny = 0, nz = 0;
+    int partition = 0;
+};
+
+extern "C" {
+
+int sc_create_sharded(sc_group **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],
+                      float voxel_size, int mode, float default_value, const int *devices, int ndev,
+                      int partition) {
+    if (!out) return fail(SC_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!devices || ndev < 1 || ndev > nx) return fail(SC_ERR_INVALID, "need 1..nx devices");
+    if (partition != 0 && partition != 1) return fail(SC_ERR_INVALID, "partition: 0 plane-cyclic, 1 slabs");
+    sc_group *g = new (std::nothrow) sc_group();
+    if (!g) return fail(SC_ERR_NOMEM, "host allocation failed");
+    g->nx = nx; g->ny = ny; g->nz = nz; g->partition = partition;
+    for (int r = 0; r < ndev; ++r) {
+        sc_engine *e = nullptr;
+        int rc = partition == 0
+                     ? sc_create_cyclic(&e, nx, ny, nz, r, ndev, origin, voxel_size, mode, default_value, devices[r])
+                     : sc_create_slab(&e, nx, ny, nz, nx * r / ndev, nx * (r + 1) / ndev, origin, voxel_size, mode,
+                                      default_value, devices[r]);
+        if (rc) {
+            for (auto *q : g->eng) sc_destroy(q);
+            delete g;
+            return rc;
+        }
+        g->eng.push_back(e);
+    }
+    *out = g;
+    return SC_OK;
+}
+
+void sc_group_destroy(sc_group *g) {
+    if (!g) return;
+    for (auto *e : g->eng) sc_destroy(e);
+    delete g;
+}
+
+int sc_group_size(const sc_group *g) { return g ? (int)g->eng.size() : 0; }
+
+sc_engine *sc_group_engine(sc_group *g, int i) {
+    return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[(size_t)i] : nullptr;
+}
+
+#define SC_GROUP_EACH(call)                                   \
+    do {                                                      \
+        if (!g) return fail(SC_ERR_INVALID, "null group");    \
+        for (auto *e : g->eng) {                              \
+            int rc_ = (call);                                 \
+            if (rc_) return rc_;                              \
+        }                                                     \
+        return SC_OK;                                         \
+    } while (0)
+
+int sc_group_clear(sc_group *g) { SC_GROUP_EACH(sc_clear(e)); }
+int sc_group_flush(sc_group *g) { SC_GROUP_EACH(sc_flush(e)); }
+int sc_group_set_option(sc_group *g, int key, int64_t value) { SC_GROUP_EACH(sc_set_option(e, key, value)); }
+int sc_group_set_lut(sc_group *g, const float *lut256) { SC_GROUP_EACH(sc_set_lut(e, lut256)); }
+int sc_group_process_view(sc_group *g, const float K[4], const float R[9], const float t[3], const void *mask,
+                          int H, int W, int mask_dtype, int64_t row_stride_bytes) {
+    SC_GROUP_EACH(sc_process_view(e, K, R, t, mask, H, W, mask_dtype, row_stride_bytes));
+}
+
+int sc_group_synchronize(sc_group *g) {
+    if (!g) return fail(SC_ERR_INVALID, "null group");
+    for (auto *e : g->eng) {  // every device launches before any is waited for
+        int rc = sc_flush(e);
+        if (rc) return rc;
+    }
+    for (auto *e : g->eng) {
+        int rc = sc_synchronize(e);
+        if (rc) return rc;
+    }
+    return SC_OK;
+}
+
+int sc_group_get_values(sc_group *g, void *out) {
+    if (!g || !out) return fail(SC_ERR_INVALID, "null argument");
+    const size_t plane = (size_t)g->ny * (size_t)g->nz * 4;
+    const int ndev = (int)g->eng.size();
+    for (auto *e : g->eng) {  // launch everywhere first: the devices work side by side
+        int rc = sc_flush(e);
+        if (rc) return rc;
+        rc = use_device(e);
+        if (rc) return rc;
+        rc = materialize(e);
+        if (rc) return rc;
+    }
+    for (int r = 0; r < ndev; ++r) {
+        sc_engine *e = g->eng[(size_t)r];
+        int rc = use_device(e);
+        if (rc) return rc;
+        char *dst = static_cast<char *>(out) + (size_t)e->i0 * plane;
+        // the engine's planes are contiguous on the device and istride planes apart in the grid
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)e->istride * plane, e->state, plane, plane, (size_t)e->planes,
+                                 hipMemcpyDeviceToHost, e->stream));
+    }
+    for (auto *e : g->eng) {
+        int rc = use_device(e);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return SC_OK;
+}
+
 }  // extern "C"

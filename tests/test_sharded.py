@@ -181,3 +181,36 @@ def test_two_ranks_over_hip_engines_sharing_the_gpu(gpu_device, partition, shape
             assert res["host"].dtype == np.int32 and np.array_equal(res["host"], want)
         else:
             assert res["host"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition,ndev", [("cyclic", 3), ("slab", 2), ("cyclic", 1)])
+def test_several_engines_from_one_process(gpu_device, partition, ndev):
+    """sc_create_sharded: one engine per listed device (here the one GPU, several times), x-planes dealt
+    as the ranks of the multi-process path get them, the grid read back whole in global order."""
+    from plant3dvision_amd import _native as nat
+    from plant3dvision_amd.cl import Backprojection, img_as_float32
+    shape, origin, vs, views = scene((37, 48, 128), 9, "plant")
+    want = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    g = nat.EngineGroup(shape, origin, vs, nat.SC_MODE_CARVE, [0] * ndev, partition=partition)
+    for vpl in (0, 1):
+        g.clear()
+        g.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+        for K, R, t, m in views:
+            g.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(g.get_values(), want), (partition, ndev, vpl)
+    g.close()
+    # the class with a list of devices; averaging through the table path
+    bp = Backprojection(shape, origin, vs, device=[0] * ndev)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    assert np.array_equal(bp.get_values(), want)
+    bp.close()
+    wantf = oracle_c.average(list(shape), origin, vs, [(K, R, t, img_as_float32(m)) for K, R, t, m in views])
+    bp = Backprojection(shape, origin, vs, type="averaging", device=[0] * ndev)
+    for K, R, t, m in views:
+        bp.process_view(K, R, t, m)
+    assert np.array_equal(bp.get_values().view(np.uint32), wantf.view(np.uint32))
+    bp.close()
+    with pytest.raises(ValueError):
+        nat.EngineGroup(shape, origin, vs, nat.SC_MODE_CARVE, [])
