@@ -243,9 +243,11 @@ def pinned_empty(shape, dtype, device=0):
     return np.frombuffer(owner, dtype=dtype).reshape(shape)
 
 
-def host_workers(limit=16):
-    """Threads for host-side helpers (decode-ahead, page touching, widening): the CPUs this process
-    may run on, at most ``limit`` (a GPU box gives 16 CPUs to one GPU)."""
+def host_workers(limit=8):
+    """Threads for host-side helpers (decode-ahead, widening): the CPUs this process may run on, at
+    most ``limit``.  Measured on the GPU box (256 hardware threads visible): PNG decoding through PIL
+    stops scaling at ~3x whatever the thread count (32 ms for 72 masks with 8, 16 or 32 threads), and
+    16 decoders beside the page-touching threads made the whole read slower than 8."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -280,7 +282,7 @@ class TouchedEmpty:
 
     def __init__(self, shape, dtype, threads=None):
         import threading
-        threads = threads or host_workers()
+        threads = threads or min(4, host_workers())  # first-touch faults do not scale past a few threads
         self._arr = np.empty(shape, dtype=dtype)
         flat = self._arr.reshape(-1)
         step = max(1, 4096 // self._arr.itemsize)

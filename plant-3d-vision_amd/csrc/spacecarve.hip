@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
     FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch,
-    uint8_t *__restrict__ dead, uint32_t parity, uint32_t *__restrict__ fill_list) {
+    uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list) {
     __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves];
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
@@ -597,7 +597,9 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     // no place on the live list (flag 4): the reference's cadence of one launch per view touches a few
     // per cent of the volume after the first views instead of streaming all of it through.
     const bool inb = lb < nbricks;
-    const bool isdead = inb && dead != nullptr && dead[lb] != 0;
+    // (dead_stale: the labels went back to default_value since the flags were written -- nothing is dead,
+    // and this launch rewrites every flag instead of a memset on the stream)
+    const bool isdead = inb && dead != nullptr && !dead_stale && dead[lb] != 0;
     const bool valid = inb && !isdead;
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t il = lb / per_plane;
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     const bool gone = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
     // kept by every view of the batch: FULL (2); by every view packed so far only: a candidate (3)
     if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? 2 : 3) : 0));
-    if (valid && gone && dead != nullptr) dead[lb] = 1;
+    if (valid && dead != nullptr && (gone || dead_stale)) dead[lb] = gone ? 1 : 0;
     // the bricks left go on the live list, one atomic per block
     const bool alive = valid && !gone && !kept;
     const unsigned long long m = __ballot(alive);
@@ -1862,7 +1864,7 @@ struct sc_engine {
     int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
     int64_t view_brick = 1;    // a single-view carve launch goes through the brick kernels too (0: streaming kernel)
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
-    bool dead_clean = false;   // `dead` is known to be all zero
+    bool dead_clean = false;   // `dead` describes the labels (false after a clear: the next flags kernel rewrites it)
     int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
     int64_t stage1_voxels = 2; // ... in the stages before it
     int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
@@ -2622,10 +2624,8 @@ int flush(sc_engine *e, size_t count = 0) {
                     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dead), (size_t)nbricks));
                     e->dead_clean = false;
                 }
-                if (!e->dead_clean) {
-                    HIP_TRY(hipMemsetAsync(e->dead, 0, (size_t)nbricks, e->stream));
-                    e->dead_clean = true;
-                }
+                const int dead_stale = e->dead_clean ? 0 : 1;  // the flags kernel rewrites them all
+                e->dead_clean = true;
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
@@ -2642,7 +2642,7 @@ int flush(sc_engine *e, size_t count = 0) {
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
                                    flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
                                    desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv, e->dead,
-                                   parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list);
+                                   dead_stale, parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list);
                 e->last_parity = parity;
                 rc = ltf.end();
                 if (rc) return rc;
