@@ -2351,7 +2351,10 @@ constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
 
 int ensure_lists(sc_engine *e) {
     if (e->lists) return SC_OK;
-    uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4, (uint64_t)kSub * 1024);
+    // room for 5/16 of the voxels: two views of coin-flip masks leave a quarter alive, which the hashed
+    // sub-lists must hold with a margin for their unevenness (an overflow sends the batch down the dense
+    // resume path, 10 x slower)
+    uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4 + (uint64_t)e->n / 16, (uint64_t)kSub * 1024);
     e->subcap = (uint32_t)((total + kSub - 1) / kSub);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lists), (size_t)2 * kSub * e->subcap * sizeof(uint32_t)));
     return SC_OK;
