@@ -310,6 +310,18 @@ int sc_dev_upload(sc_engine *e, void *dst_dev, const void *src_host, int64_t byt
 int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t bytes);
 
 /*
+ * Mask ingest (cl.py:298, `io.read_image`): decoder for 8-bit greyscale, non-interlaced PNG -- the files a
+ * `Masks` / `Segmentation2D` fileset holds -- callable from the decode-ahead threads with the interpreter
+ * lock released (the Python decoders stop scaling at ~3 threads).  sc_png_info returns SC_OK and the
+ * size for a file this decoder takes, SC_ERR_INVALID (reason: sc_png_last_error) for anything else
+ * (other colour types, bit depths, interlacing, palette or transparency chunks): the caller then uses
+ * its usual reader.  sc_png_decode_gray8 writes H*W bytes, row-major.  Host code only (zlib).
+ */
+int sc_png_info(const void *data, int64_t len, int *W, int *H);
+int sc_png_decode_gray8(const void *data, int64_t len, uint8_t *out, int W, int H);
+const char *sc_png_last_error(void);
+
+/*
  * Several GPUs from ONE process (SURVEY.md 8b `sc_create_sharded`; the reference drives a single
  * device, cl.py:29-30): one engine per entry of `devices` (HIP ordinals; an ordinal may repeat), the
  * x-planes of the grid dealt round-robin over them (partition 0; every device then holds the same share

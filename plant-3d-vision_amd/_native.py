@@ -79,6 +79,9 @@ _SIGNATURES = {
     "sc_group_flush": ("i", ["p"]),
     "sc_group_synchronize": ("i", ["p"]),
     "sc_group_get_values": ("i", ["p", "p"]),
+    "sc_png_info": ("i", ["p", "q", "p", "p"]),
+    "sc_png_decode_gray8": ("i", ["p", "q", "p", "i", "i"]),
+    "sc_png_last_error": ("s", []),
     "sc_host_alloc": ("i", ["i", "q", "p"]),
     "sc_host_free": ("v", ["p"]),
     "sc_dev_alloc": ("i", ["p", "q", "p"]),
@@ -102,7 +105,7 @@ class SpaceCarveError(RuntimeError):
 def build(force=False):
     """Compile ``csrc/spacecarve.hip`` for gfx950 into ``libspacecarve.so`` (in-tree)."""
     csrc = os.path.join(_PKG_DIR, "csrc")
-    deps = [os.path.join(csrc, f) for f in ("spacecarve.hip", "vol2pcd.hip", "label_points.hip", "Makefile")]
+    deps = [os.path.join(csrc, f) for f in ("spacecarve.hip", "vol2pcd.hip", "label_points.hip", "pngdec.cpp", "Makefile")]
     deps.append(HEADER_PATH)
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
@@ -322,6 +325,22 @@ def pose_records(entries):
         if shape is not None:
             i[q, 22:25] = [int(x) for x in shape]
     return rec
+
+
+def png_decode_gray8(raw):
+    """``(H, W)`` uint8 array of an 8-bit greyscale, non-interlaced PNG given as bytes, or ``None`` when
+    the file is anything else (the caller then uses its usual reader).  The foreign call releases the
+    interpreter lock: decode-ahead threads really run side by side."""
+    b = backend()
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    wh = np.zeros(2, dtype=np.int32)
+    if b.call("sc_png_info", addr(buf), int(buf.size), addr(wh), addr(wh) + 4) != SC_OK:
+        return None
+    W, H = int(wh[0]), int(wh[1])
+    out = np.empty((H, W), dtype=np.uint8)
+    if b.call("sc_png_decode_gray8", addr(buf), int(buf.size), addr(out), W, H) != SC_OK:
+        return None
+    return out
 
 
 def device_count():

@@ -224,3 +224,47 @@ def test_clear_never_reuses_an_array_the_caller_holds_unless_recycled():
     bp.recycle(np.zeros(shape, dtype=np.float32)) # wrong dtype: ignored
     bp.clear()
     assert bp.get_values().dtype == np.int32
+
+
+def test_native_png_decoder_matches_pil_and_refuses_what_it_does_not_know():
+    """The ingest decoder (sc_png_decode_gray8) on 8-bit greyscale PNGs of every zlib level and size
+    parity, against the pixels they were written from; other kinds of PNG are refused (None) so that
+    the caller's usual reader takes them; read_image() prefers it for files that hand out bytes."""
+    import io
+    from PIL import Image
+    from plant3dvision_amd import _native as nat
+    from plant3dvision_amd.cl import read_image
+    rng = np.random.default_rng(0)
+    pics = [rng.integers(0, 256, (37, 53), dtype=np.uint8), (rng.random((128, 160)) < 0.1).astype(np.uint8) * 255,
+            np.zeros((1, 1), np.uint8), np.tile(np.arange(256, dtype=np.uint8), (300, 5))]
+    for m in pics:
+        for lvl in (0, 1, 6, 9):
+            bio = io.BytesIO()
+            Image.fromarray(m).save(bio, format="PNG", compress_level=lvl)
+            got = nat.png_decode_gray8(bio.getvalue())
+            assert got is not None and got.dtype == np.uint8 and np.array_equal(got, m), (m.shape, lvl)
+    m = pics[1]
+    for convert in ("RGB", "LA", "P", "1"):
+        bio = io.BytesIO()
+        Image.fromarray(m).convert(convert).save(bio, format="PNG")
+        assert nat.png_decode_gray8(bio.getvalue()) is None, convert
+    bio = io.BytesIO()
+    Image.fromarray(m.astype(np.uint16) * 257).save(bio, format="PNG")  # 16-bit grey
+    assert nat.png_decode_gray8(bio.getvalue()) is None
+    bio = io.BytesIO()
+    Image.fromarray(m).save(bio, format="PNG")
+    good = bio.getvalue()
+    assert nat.png_decode_gray8(good[:60]) is None and nat.png_decode_gray8(b"x" * 100) is None
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0xff  # corrupted stream: refused, not decoded wrongly
+    assert nat.png_decode_gray8(bytes(bad)) is None
+
+    class RawFile:
+        def __init__(self, raw, array):
+            self._raw, self.array = raw, array
+
+        def read_raw(self):
+            return self._raw
+
+    assert np.array_equal(read_image(RawFile(good, None)), m)           # the native decoder
+    rgb = io.BytesIO(); Image.fromarray(m).convert("RGB").save(rgb, format="PNG")
+    assert read_image(RawFile(rgb.getvalue(), m)) is m                   # refused -> the usual reader

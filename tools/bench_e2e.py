@@ -25,6 +25,10 @@ class PngFile:
     def get_metadata(self, key=None, default=None):
         return self._md if key is None else self._md.get(key, default)
 
+    def read_raw(self):  # plantdb's File.read_raw(): the bytes io.read_image decodes
+        with open(self.path, "rb") as f:
+            return f.read()
+
     def read_image(self):
         from PIL import Image
         with Image.open(self.path) as im:
@@ -60,22 +64,27 @@ def main():
 
     res = {}
     vols = {}
+    class PilFile(PngFile):  # a file without read_raw: the Python decoder, as in round 1
+        read_raw = None
+
+    pil_files = [PilFile(f.id, f.path, f._md) for f in files]
     for name, cls, kw in (("serial", SerialBackprojection, dict(decode_workers=1, views_per_launch=1)),
+                          ("pil", Backprojection, dict()),
                           ("default", Backprojection, dict())):
         best = None
         for _ in range(a.reps):
             bp = cls(shape, origin, vs, **kw)
             t0 = time.perf_counter()
-            vol = bp.process_fileset(files, "colmap_camera")
+            vol = bp.process_fileset(pil_files if name != "default" else files, "colmap_camera")
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
             vols[name] = vol.copy()
             bp.close()
         res[name] = best
-    assert np.array_equal(vols["serial"], vols["default"])
+    assert np.array_equal(vols["serial"], vols["default"]) and np.array_equal(vols["pil"], vols["default"])
     n_vv = int(np.prod(shape)) * len(views)
     print(json.dumps({"workload": f"{a.n}^3 x {len(views)} PNG masks {views[0][3].shape[1]}x{views[0][3].shape[0]} -> volume in host memory",
-                      "decode_only_s": t_decode, "serial_s": res["serial"], "default_s": res["default"],
+                      "decode_only_s": t_decode, "serial_s": res["serial"], "python_decoder_s": res["pil"], "default_s": res["default"],
                       "speedup": res["serial"] / res["default"],
                       "default_Mvoxel_views_per_s": n_vv / res["default"] / 1e6,
                       "serial_Mvoxel_views_per_s": n_vv / res["serial"] / 1e6,
