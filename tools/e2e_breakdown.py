@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.bench_e2e import PngFile
 from PIL import Image
 from plant3dvision_amd import scenes, _native as nat
-from plant3dvision_amd.cl import Backprojection
+from plant3dvision_amd.cl import Backprojection, read_image
 from concurrent.futures import ThreadPoolExecutor
 
 shape, origin, vs, views = scenes.make_scene(512, 72, "plant")
@@ -17,13 +17,14 @@ for q, (K, R, t, m) in enumerate(views):
     Image.fromarray(m).save(path, compress_level=1)
     files.append(PngFile(f"{q:05d}_mask", path, {"colmap_camera": scenes.camera_dict(K, R, t)}))
 T = time.perf_counter
-for workers in (8, 16, 32):
+for workers, decoder in ((8, 'native'), (16, 'native'), (8, 'pil'), (16, 'pil')):
     for rep in range(3):
+        vol = buf = masks = None  # freed outside the timed phases (munmap of a 512 MiB array: 25 ms)
         t0 = T()
         bp = Backprojection(shape, origin, vs, decode_workers=workers)
         t1 = T()
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            futs = [pool.submit(f.read_image) for f in files]
+            futs = [pool.submit(read_image if decoder == 'native' else PngFile.read_image, f) for f in files]
             masks = [f.result() for f in futs]
         t2 = T()
         for (K, R, t, _), m in zip(views, masks):
@@ -37,7 +38,7 @@ for workers in (8, 16, 32):
         vol = bp.get_values()
         t6 = T()
         bp.close()
-    print(f"workers {workers}: ctor {1e3*(t1-t0):.1f}  decode-all {1e3*(t2-t1):.1f}  submit {1e3*(t3-t2):.1f}  sync {1e3*(t4-t3):.1f}  "
+    print(f"workers {workers} ({decoder} decoder): ctor {1e3*(t1-t0):.1f}  decode-all {1e3*(t2-t1):.1f}  submit {1e3*(t3-t2):.1f}  sync {1e3*(t4-t3):.1f}  "
           f"take_buffer {1e3*(t5-t4):.1f}  get_values {1e3*(t6-t5):.1f} ms")
 # read-back variants alone
 bp = Backprojection(shape, origin, vs)
