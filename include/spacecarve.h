@@ -17,7 +17,9 @@
  *   - arithmetic: IEEE binary32, no contraction, correctly rounded divide,
  *     (int) cast rejecting NaN/inf/out-of-range
  *
- * Threading: one engine per host thread; engines are not shared.  Every call
+ * Threading: an engine is driven by one host thread at a time (calls on it may come from different
+ * threads one after the other -- every entry selects the engine's device first); different engines
+ * may be driven from different threads at once.  Every call
  * returns SC_OK (0) or a negative code; sc_last_error() gives the thread-local
  * message of the most recent failure.
  */

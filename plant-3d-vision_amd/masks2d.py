@@ -184,15 +184,20 @@ def cameras_for_label(files, label, camera_metadata="colmap_camera"):
 
 
 def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging", log=True,
-                      invert=False, device=None):
+                      invert=False, device=None, overlap=True):
     """``Voxels`` on device-resident masks: one volume per label.
 
     masks   : ``{label: uint8 cuda tensor [n_img, Sy, Sx]}`` (``masks_from_predictions``)
     cameras : list of ``n_img`` camera dicts (the ``colmap_camera`` metadata schema, cl.py:293-296)
+    overlap : with several labels, two engines (two device volumes) take the labels in turn: while one
+        label's volume crosses PCIe and gets its ``exp`` / clip on a helper thread, the device already
+        works on the next label.  ``False`` = one engine, one label after the other (cl.py:248-255).
+        Same volumes either way.
     Returns ``{label: ndarray}`` -- float32 for "averaging" (after ``exp`` / clip when ``log``,
     tasks/cl.py:172-174), int32 for "carving".
     """
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from .cl import EPS, img_as_float32
     first = next(iter(masks.values()))
     if not first.is_cuda:
@@ -207,44 +212,80 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
     mode = nat.SC_MODE_AVERAGE if type == "averaging" else nat.SC_MODE_CARVE
     if type not in ("averaging", "carving"):
         raise ValueError(f"Unknown kernel type {type}, valid values are 'averaging' or 'carving'!")
-    eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)
-    # The engine keeps its own (non-blocking) stream and is ordered explicitly behind torch's:
-    # torch's default stream has handle 0, which is NOT a stream the engine could adopt (0 means
-    # "own stream" to sc_set_stream) and which a non-blocking stream does not synchronise with.
-    producer = torch.cuda.current_stream(dev).cuda_stream
+    for m in masks.values():
+        if m.dtype != torch.uint8 or tuple(m.shape) != (n_img, H, W) or not m.is_contiguous():
+            raise ValueError("masks must be contiguous uint8 [n_img, Sy, Sx]")
+    lut = None
     if mode == nat.SC_MODE_AVERAGE:
         lut = img_as_float32(np.arange(256, dtype=np.uint8))
         if log:
             with np.errstate(divide="ignore"):
                 lut = np.log(EPS + lut)
-        eng.set_lut(lut)
+    # The engines keep their own (non-blocking) streams and are ordered explicitly behind torch's:
+    # torch's default stream has handle 0, which is NOT a stream the engine could adopt (0 means
+    # "own stream" to sc_set_stream) and which a non-blocking stream does not synchronise with.
+    producer = torch.cuda.current_stream(dev).cuda_stream
+    vol_dtype = np.float32 if mode == nat.SC_MODE_AVERAGE else np.int32
+    vol_shape = tuple(int(s) for s in shape)
+    engines = []
+
+    narrow = mode == nat.SC_MODE_CARVE and int(np.prod(vol_shape)) >= (1 << 24)
+
+    def finish(eng, dest, dest8, src):
+        if dest8 is not None:
+            # labels cross PCIe as bytes and are widened on host threads (as Backprojection.get_values)
+            small = eng.get_values_i8(dest8.result())
+            vol = np.empty(vol_shape, vol_dtype)  # its pages are faulted in by the widening threads
+            nat.widen_i8(vol, small)
+        else:
+            vol = eng.get_values(dest.result())  # flushes and waits: `src` may go now
+        del src
+        if mode == nat.SC_MODE_AVERAGE and log:
+            from .tasks.cl import _exp_clip
+            # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174), over the array just read back
+            vol = _exp_clip(vol, inplace=True)
+        return vol
+
     out = {}
     try:
-        for q, (label, m) in enumerate(masks.items()):
-            if m.dtype != torch.uint8 or tuple(m.shape) != (n_img, H, W) or not m.is_contiguous():
-                raise ValueError("masks must be contiguous uint8 [n_img, Sy, Sx]")
-            if q:
-                eng.clear()  # cl.py:252-253
-            # the label's host array: pages touched on host threads while the device works
-            dest = nat.TouchedEmpty(tuple(int(s) for s in shape),
-                                    np.float32 if mode == nat.SC_MODE_AVERAGE else np.int32)
-            if mode == nat.SC_MODE_AVERAGE:
-                src = (255 - m) if invert else m
+        for _ in range(2 if overlap and len(masks) > 1 else 1):
+            eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)
+            engines.append(eng)
+            if lut is not None:
+                eng.set_lut(lut)
+        pending = [None] * len(engines)  # per engine: (label, future of its volume)
+        with ThreadPoolExecutor(max_workers=1) as helper:
+            for q, (label, m) in enumerate(masks.items()):
+                k = q % len(engines)
+                eng = engines[k]
+                if pending[k] is not None:
+                    out[pending[k][0]] = pending[k][1].result()
+                if q >= len(engines):
+                    eng.clear()  # cl.py:252-253
+                # the label's host array: pages touched on host threads while the device works
+                dest = None if narrow else nat.TouchedEmpty(vol_shape, vol_dtype)
+                dest8 = nat.TouchedEmpty(vol_shape, np.int8) if narrow else None
+                if mode == nat.SC_MODE_AVERAGE:
+                    src = (255 - m) if invert else m
+                    code = nat.SC_MASK_U8_LUT
+                else:
+                    src = m
+                    code = nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8
                 eng.order_after(producer)  # `m` / `src` are complete before the engine reads them
-                eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, nat.SC_MASK_U8_LUT)
-            else:
-                code = nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8
-                src = m
-                eng.order_after(producer)
                 eng.process_views_device(K, R, t, src.data_ptr(), n_img, H, W, code)
-            vol = eng.get_values(dest.result())  # flushes and waits: `src` may go now
-            del src
-            if mode == nat.SC_MODE_AVERAGE and log:
-                from .tasks.cl import _exp_clip
-                vol = _exp_clip(vol)  # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174)
-            out[label] = vol
+                if len(engines) > 1:
+                    eng.flush()  # the label's kernels are queued now, behind nothing of the other engine
+                    pending[k] = (label, helper.submit(finish, eng, dest, dest8, src))
+                else:
+                    out[label] = finish(eng, dest, dest8, src)
+                del src
+            for entry in pending:
+                if entry is not None:
+                    out[entry[0]] = entry[1].result()
+        out = {label: out[label] for label in masks}  # in label order
     finally:
-        eng.close()
+        for eng in engines:
+            eng.close()
     return out
 
 

@@ -61,14 +61,39 @@ def _single_valued(vol):
     return bool((flat[:4096] == first).all() and (flat == first).all())
 
 
-def _exp_clip(vol):
+def _exp_clip(vol, workers=None, inplace=False):
     """``vol = np.exp(vol); vol[vol > 1] = 1.0`` (tasks/cl.py:172-174) with ``np.minimum`` in place of
     the boolean-mask assignment: same values (NaN stays NaN, inf becomes 1), a third of the time on a
-    512^3 volume -- the mask and the fancy store cost more than the exponential."""
-    out = np.exp(np.asarray(vol))
-    if out.ndim == 0:
+    512^3 volume -- the mask and the fancy store cost more than the exponential.  Volumes of 2^22
+    elements and more are done slab by slab on a few host threads (elementwise, so the same bits).
+    ``inplace`` (for a caller that owns ``vol``) writes the result over the input: no second
+    volume-sized array to fault in, none to hand back to the OS (25 ms for 512 MiB on the GPU box)."""
+    src = np.asarray(vol)
+    if src.ndim == 0:
+        out = np.exp(src)
         return out if not out > 1 else out.dtype.type(1.0)
-    np.minimum(out, out.dtype.type(1.0), out=out)
+    inplace = bool(inplace) and src.dtype.kind == "f" and src.flags.writeable
+    if src.size < (1 << 22) or not src.flags.c_contiguous or src.dtype.kind != "f":
+        out = np.exp(src, out=src) if inplace else np.exp(src)
+        np.minimum(out, out.dtype.type(1.0), out=out)
+        return out
+    import threading
+    from .. import _native as nat
+    out = src if inplace else np.empty_like(src)
+    fs, fo = src.reshape(-1), out.reshape(-1)
+    parts = max(1, min(int(workers or nat.host_workers()), src.size >> 20))
+    bounds = [src.size * q // parts for q in range(parts + 1)]
+    one = out.dtype.type(1.0)
+
+    def work(a, b):
+        np.exp(fs[a:b], out=fo[a:b])  # NumPy releases the interpreter lock in both loops
+        np.minimum(fo[a:b], one, out=fo[a:b])
+
+    threads = [threading.Thread(target=work, args=(bounds[q], bounds[q + 1])) for q in range(parts)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
     return out
 
 

@@ -143,6 +143,19 @@ def test_voxels_run_post_processing_helpers_match_numpy_expressions():
         small = v[:2, :3, :4]
         w2 = np.exp(small); w2[w2 > 1] = 1.0
         assert np.array_equal(_exp_clip(small), w2, equal_nan=True)
+    # big volumes go slab by slab over host threads: the same bits as one call
+    big = (rng.standard_normal((1 << 22) + 12345) * 4).astype(np.float32)
+    big[[0, 77, -1]] = [np.nan, np.inf, -np.inf]
+    want = np.exp(big)
+    want[want > 1] = 1.0
+    for workers in (None, 1, 3, 7):
+        got = _exp_clip(big, workers=workers)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert not np.shares_memory(_exp_clip(big), big)
+    for arr in (big.copy(), big[:1000].copy()):
+        w = np.exp(arr); w[w > 1] = 1.0
+        got = _exp_clip(arr, inplace=True)
+        assert got is arr and np.array_equal(got.view(np.uint32), w.view(np.uint32))
     last = np.zeros(10000); last[-1] = 1
     for arr in (np.zeros((5, 5)), np.arange(9.0), np.full((3, 3), np.nan), np.array([np.nan, 1.0]),
                 np.array([1.0, np.nan]), np.zeros(10000, dtype=np.int32), last, np.full((2, 2), -1, dtype=np.int32)):

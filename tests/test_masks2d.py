@@ -151,3 +151,13 @@ def test_device_resident_masks_to_volumes(gpu_device, type_, log):
                 want = np.exp(want)
                 want[want > 1] = 1.0
         assert np.array_equal(vols[name], want), name
+    # one engine, label after label (the reference's sequence) == two engines taking turns
+    serial = masks2d.voxels_from_masks(masks, cams, shape, origin, vs, type=type_, log=log, overlap=False)
+    assert list(serial) == LABELS
+    for name in LABELS:
+        assert np.array_equal(serial[name].view(np.uint32), vols[name].view(np.uint32)), name
+    five = {f"{name}{k}": masks[name] for k in range(2) for name in LABELS[:3]}  # more labels than engines
+    got = masks2d.voxels_from_masks(five, cams, shape, origin, vs, type=type_, log=log)
+    assert list(got) == list(five)
+    for key in five:
+        assert np.array_equal(got[key].view(np.uint32), vols[key[:-1]].view(np.uint32)), key
