@@ -267,6 +267,17 @@ int sc_selftest_project(sc_engine *e, int64_t count, uint32_t seed, int nposes, 
                         uint64_t *digests_out);
 
 /*
+ * Diagnostic (host code only, no device call): would a view with this pose take the kernels' certified
+ * path on a grid of nx x ny x nz voxels with this origin and voxel size?  The host checks, in double precision and with wide margins, that every voxel centre of the grid
+ * projects with 2^-10 < p_z and |p_x|, |p_y|, p_z < 2^30 and that the intrinsics are finite and below
+ * 2^30; for such a view the projection (backprojection.c:11-31) spends two comparisons on the range test
+ * of its shared-reciprocal division and two on the picture test instead of nine.  Results are the same
+ * either way (tests/test_project_selftest.py runs both); *certified = 1 or 0.  No reference counterpart.
+ */
+int sc_view_certified(const float origin[3], float voxel_size, int64_t nx, int64_t ny, int64_t nz, const float K[4],
+                      const float R[9], const float t[3], int *certified);
+
+/*
  * The carve's immediate consumer: plant3dvision/proc3d.py::vol2pcd (:490-570, called by
  * tasks/proc3d.py:134) on the GPU.  volume: host pointer, or device pointer on `device` when
  * on_device != 0 (e.g. sc_values_device_ptr: the volume then never crosses PCIe); dtype 0 int32,

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "sc_fused_counts": ("i", ["p", "p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
     "sc_selftest_project": ("i", ["p", "q", "I", "i", "p", "p", "p", "p", "p"]),
+    "sc_view_certified": ("i", ["p", "f", "q", "q", "q", "p", "p", "p", "p"]),
     "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_vol2pcd_last_error": ("s", []),
     "sc_free_host": ("v", ["p"]),
@@ -306,6 +307,19 @@ class TouchedEmpty:
             th.join()
         self._threads = []
         return self._arr
+
+
+def view_certified(shape, origin, voxel_size, K, R, t):
+    """Does a view with this pose take the kernels' certified (cheaper, same results) projection path on
+    this grid?  Host arithmetic only (``sc_view_certified``)."""
+    o = np.ascontiguousarray(np.asarray(origin, dtype=np.float32).reshape(3))
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(4))
+    R = np.ascontiguousarray(np.asarray(R, dtype=np.float32).reshape(9))
+    t = np.ascontiguousarray(np.asarray(t, dtype=np.float32).reshape(3))
+    out = np.zeros(1, dtype=np.int32)
+    check(backend().call("sc_view_certified", addr(o), float(voxel_size), int(shape[0]), int(shape[1]), int(shape[2]),
+                         addr(K), addr(R), addr(t), addr(out)), "sc_view_certified")
+    return bool(out[0])
 
 
 def pose_records(entries):

@@ -53,7 +53,7 @@ namespace {
 // device side
 // ------------------------------------------------------------------------------------------
 
-struct ViewDesc {   // 104 bytes, read with scalar loads (the view index is wave-uniform)
+struct ViewDesc {   // 112 bytes, read with scalar loads (the view index is wave-uniform)
     float K[4];     // fx fy cx cy
     float R[9];     // row-major
     float t[3];
@@ -63,8 +63,11 @@ struct ViewDesc {   // 104 bytes, read with scalar loads (the view index is wave
     int32_t pad;
     float Wf, Hf;
     const uint8_t *occ;  // carve: one byte per 32x32 tile: bit 0 some foreground, bit 1 only foreground
+    int32_t safe;        // certify_view(): every voxel centre of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30
+                         // under this pose, and the intrinsics are finite and below 2^30 (see project())
+    int32_t pad2;
 };
-static_assert(sizeof(ViewDesc) == 104, "ViewDesc layout");
+static_assert(sizeof(ViewDesc) == 112, "ViewDesc layout");
 
 struct GridDesc {
     float ox, oy, oz, vs;
@@ -158,20 +161,41 @@ __device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
 
 // backproject_point (backprojection.c:3-34) with the x/y partial sums hoisted.
 // a{x,y,z} = R[0]*x + R[1]*y etc. (rounded as the reference rounds them).
+//
+// What the instructions cost on gfx950 (tools/probes/valu_probe.hip, cycles of a SIMD per wavefront
+// instruction, independent instructions, 8 wavefronts per SIMD): v_mul_f32 / v_add_f32 / v_sub_f32 /
+// v_and / v_lshrrev / v_add_u32 / v_mov 2.6; every three-operand or VOP3-only form (v_fma_f32, v_cmp_*,
+// v_cvt_*, v_min/max, v_bfi, v_mad_*) 4.3-4.7; v_rcp_f32 8.3.  Where the host has certified the pose
+// (d.safe: every voxel of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30, intrinsics finite and below
+// 2^30) the range test of the fast division is the two comparisons left of it and the picture test is
+// two unsigned comparisons of the truncated coordinates -- uf, vf are finite there, v_cvt_i32_f32
+// truncates toward zero ((-1, 0) -> 0, accepted like the reference's cast) and saturates, so
+// (unsigned)u < W is exactly  uf > -1 && uf < W.
 __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
                                         const ViewDesc &d, int &u, int &v) {
     float pz = (az + d.R[8] * z) + d.t[2];  // :11
     float px = (ax + d.R[2] * z) + d.t[0];  // :17
     float py = (ay + d.R[5] * z) + d.t[1];  // :18
-    float qx, qy;
-    if (__ballot(!div_fast_range(px, py, pz)) == 0) {  // wave-uniform
-        float r = refined_rcp(pz);
-        qx = div_by_rcp(px, pz, r);
-        qy = div_by_rcp(py, pz, r);
-    } else {
-        qx = px / pz;
-        qy = py / pz;
+    const bool safe = d.safe != 0;          // wave-uniform
+    unsigned long long outside;             // lanes whose operands the fast division does not cover
+    if (safe) {
+        outside = __builtin_amdgcn_ballot_w64(!(fabsf(px) > 0x1p-40f)) | __builtin_amdgcn_ballot_w64(!(fabsf(py) > 0x1p-40f));
+        asm volatile("" : "+s"(outside));  // keeps the two ballots apart: merged, the lane predicate
+    } else {                               // travels through a vector register and back (two more instructions)
+        outside = __builtin_amdgcn_ballot_w64(!div_fast_range(px, py, pz));
+        asm volatile("" : "+s"(outside));
     }
+    if (outside == 0) {
+        const float r = refined_rcp(pz);
+        // (the packed forms v_pk_mul/fma_f32 were tried for the two chains: no faster in these kernels)
+        const float uf = div_by_rcp(px, pz, r) * d.K[0] + d.K[2];  // :20
+        const float vf = div_by_rcp(py, pz, r) * d.K[1] + d.K[3];  // :21
+        u = (int)uf;
+        v = (int)vf;
+        if (safe) return ((uint32_t)u < (uint32_t)d.W) & ((uint32_t)v < (uint32_t)d.H);
+        return (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);  // pz > 0 here
+    }
+    const float qx = px / pz, qy = py / pz;
     float uf = qx * d.K[0] + d.K[2];  // :20
     float vf = qy * d.K[1] + d.K[3];  // :21
     // :13 rejects pz < 0 (not NaN, not -0); :23-31 reject (int)uf outside [0, W-1].
@@ -1105,18 +1129,41 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         }
     }
     const uint32_t chunks = pref[kSub];
-    const uint32_t vgroups = FINAL ? (uint32_t)((nviews + vgsize - 1) / vgsize) : 1u;
-    const uint64_t items = (uint64_t)chunks * vgroups;
     const uint32_t lane = tid & 63u;
     const uint64_t nworkers = (uint64_t)nbid * (kBlock / 64);
     // the wavefront index must be a scalar for the compiler, or everything derived from the
     // item (view range, descriptors) is treated as divergent and fetched with vector loads
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (uint64_t item = (uint64_t)bid * (kBlock / 64) + wave; item < items;
-         item += nworkers) {
-        // neighbouring wavefronts take neighbouring chunks of the same view group
-        const uint32_t vgi = (uint32_t)(item / chunks);
-        const uint32_t c = (uint32_t)(item - (uint64_t)vgi * chunks);
+    // FINAL: the (chunk, view) pairs, chunk-major, are cut into one SPAN per wavefront -- every
+    // wavefront gets the same number of projections whatever the counts are (with whole
+    // (chunk, view group) items 17 k items over 4096 wavefronts meant 5 items for some and 4 for
+    // others), and a span crosses a chunk boundary once or twice, so the decode of the entries is
+    // paid once or twice per wavefront.  `vgsize` only rounds the span length.
+    // Not FINAL: an item is a chunk and all the views, dealt round-robin.
+    const uint64_t total = FINAL ? (uint64_t)chunks * (uint32_t)nviews : (uint64_t)chunks;
+    uint64_t per = 1;
+    if (FINAL) {
+        per = (total + nworkers - 1) / nworkers;
+        const uint64_t r = (uint64_t)max(vgsize, 1);
+        per = (per + r - 1) / r * r;
+    }
+    const uint64_t wid = (uint64_t)bid * (kBlock / 64) + wave;
+    uint64_t pos = FINAL ? min(total, wid * per) : wid;
+    const uint64_t end = FINAL ? min(total, pos + per) : total;
+    while (pos < end) {
+        uint32_t c;
+        int v0, v1;
+        if (FINAL) {
+            c = (uint32_t)(pos / (uint32_t)nviews);
+            v0 = (int)(pos - (uint64_t)c * (uint32_t)nviews);
+            v1 = (int)min((uint64_t)nviews, (uint64_t)v0 + (end - pos));
+            pos += (uint64_t)(v1 - v0);
+        } else {
+            c = (uint32_t)pos;
+            v0 = 0;
+            v1 = nviews;
+            pos += nworkers;
+        }
         uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= c (wave-uniform)
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
@@ -1124,8 +1171,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         }
         const uint32_t s = lo;
         const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
-        const int v0 = FINAL ? (int)vgi * vgsize : 0;
-        const int v1 = FINAL ? min(nviews, v0 + vgsize) : nviews;
         // P voxels per lane: the descriptor traffic and the scalar bookkeeping of a view are shared,
         // and a lane has P * U independent projection chains and gathers in flight
         uint32_t idx[P];
@@ -1159,8 +1204,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             bool ok[U][P], fg[U][P];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
-                const bool have = vi + q < v1;  // wave-uniform
-                const ViewDesc d = views[have ? vi + q : vi];
+                // past the end of the range the last view is applied once more: a view applied twice
+                // changes nothing (a carve is final, a kept 0 is already 1), and nothing per lane has
+                // to know whether the slot was real
+                const ViewDesc d = views[vi + q < v1 ? vi + q : vi];
                 // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
                 // tiles_x and the mask pointer one by one where they are first used, three
                 // more scalar-load round trips inside each projection
@@ -1168,8 +1215,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     int uu, vv;
+                    // dead lanes project along (their carve below is masked): cheaper than a per-lane test here
                     ok[q][p] = project(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
-                                       d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv) & alive[p] & have;
+                                       d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv);
                     uint32_t w = 0;
                     if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
                     fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
@@ -1184,8 +1232,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     carve |= ok[q][p] & !fg[q][p];
                     keep |= ok[q][p] & fg[q][p];
                 }
-                if (carve) {
+                if (carve & alive[p]) {
                     alive[p] = false;
+                    zero[p] = false;
                     labels[idx[p]] = -1;
                 } else if (zero[p] & keep) {
                     zero[p] = false;
@@ -1697,6 +1746,7 @@ __global__ __launch_bounds__(kBlock) void project_selftest_kernel(uint64_t count
 #pragma unroll
             for (int q = 0; q < 3; ++q) d.t[q] = r.t[q];
             d.mask = nullptr; d.occ = nullptr; d.W = r.W; d.H = r.H; d.tiles_x = 0; d.pad = 0;
+            d.safe = r.pad[0]; d.pad2 = 0;  // certified by the host for the box the samples come from
             d.Wf = (float)r.W; d.Hf = (float)r.H;
             // exactly what the voxel kernels do: coordinates as backprojection.c:71-73, the x / y
             // partial sums of the three dot products first (the reference's own association)
@@ -1909,7 +1959,7 @@ struct sc_engine {
     int64_t stage1_views = 8;    // views applied to the first survivor list
     int64_t stage2_views = 0;    // views applied to the second survivor list (0: no such stage)
     int64_t list_blocks = 2048;  // persistent grid of the list / resume kernels
-    int64_t view_group = 16;     // views per work item in the final list stage
+    int64_t view_group = 2;      // the spans of the final list stage are a multiple of this many views
 
     std::vector<TimedLaunch> timed[kNumKernels];
     hipEvent_t step_start = nullptr;
@@ -2089,7 +2139,35 @@ int check_dtype(const sc_engine *e, int dtype) {
     return fail(SC_ERR_INVALID, "mask dtype %d does not fit engine mode %d", dtype, e->mode);
 }
 
-void fill_desc(ViewDesc &d, const float *K, const float *R, const float *t, const void *mask,
+// Sufficient (not necessary) conditions, in double precision with room to spare, for what project()
+// takes for granted of a view with `safe` set: over the voxel centres  o + i * vs,  ilo <= i <= ihi per axis,  2^-10 < pz  and  |px|, |py|, pz < 2^30;  K finite and below 2^30 in magnitude.  M_r bounds the
+// magnitude of every partial sum of row r, so the float evaluation (six roundings, coordinates rounded
+// twice) is within 2^-20 M_r of the real value; the margins below are 2^-18 M_r and factors of 2^10.
+int32_t certify_view(const float *K, const float *R, const float *t, const float *o, float vs, const int64_t *ilo,
+                     const int64_t *ihi) {  // voxel indices ilo[a] .. ihi[a] along axis a
+    double lo[3], hi[3], amax[3];
+    for (int a = 0; a < 3; ++a) {
+        const double a0 = (double)o[a] + (double)ilo[a] * (double)vs, a1 = (double)o[a] + (double)ihi[a] * (double)vs;
+        if (!std::isfinite(a0) || !std::isfinite(a1)) return 0;
+        lo[a] = std::min(a0, a1);
+        hi[a] = std::max(a0, a1);
+        amax[a] = std::max(std::fabs(a0), std::fabs(a1)) * (1.0 + 0x1p-20) + 0x1p-100;
+    }
+    double M[3];
+    for (int r = 0; r < 3; ++r) {
+        M[r] = std::fabs((double)R[3 * r]) * amax[0] + std::fabs((double)R[3 * r + 1]) * amax[1] +
+               std::fabs((double)R[3 * r + 2]) * amax[2] + std::fabs((double)t[r]);
+        if (!(M[r] < 0x1p30)) return 0;  // also NaN
+    }
+    double pzmin = (double)t[2];
+    for (int a = 0; a < 3; ++a) pzmin += std::min((double)R[6 + a] * lo[a], (double)R[6 + a] * hi[a]);
+    if (!(pzmin - M[2] * 0x1p-18 > 0x1p-10)) return 0;
+    for (int q = 0; q < 4; ++q)
+        if (!(std::fabs((double)K[q]) < 0x1p30)) return 0;
+    return 1;
+}
+
+void fill_desc(const sc_engine *e, ViewDesc &d, const float *K, const float *R, const float *t, const void *mask,
                int H, int W, const uint8_t *occ = nullptr) {
     memcpy(d.K, K, sizeof d.K);
     memcpy(d.R, R, sizeof d.R);
@@ -2102,6 +2180,9 @@ void fill_desc(ViewDesc &d, const float *K, const float *R, const float *t, cons
     d.occ = occ;
     d.Wf = (float)W;
     d.Hf = (float)H;
+    const int64_t first[3] = {0, 0, 0}, last[3] = {e->nx - 1, e->ny - 1, e->nz - 1};  // the global grid: any partition of it is inside
+    d.safe = certify_view(K, R, t, e->origin, e->vs, first, last);
+    d.pad2 = 0;
 }
 
 size_t packed_words(int H, int W) {
@@ -2215,7 +2296,7 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     if (rc) return rc;
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
-        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
+        fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q,
                   static_cast<uint32_t *>(packed) + (size_t)q * words, H, W, occ + (size_t)q * occ_bytes);
         e->pending.push_back(d);
     }
@@ -2261,7 +2342,7 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
     if (rc) return rc;
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
-        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W,
+        fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W,
                   uni ? uni + (size_t)q * uni_per_view : nullptr);
         d.tiles_x = tiles_x;
         d.pad = 1;
@@ -2303,7 +2384,7 @@ int enqueue_tilef32(sc_engine *e, int V, const float *K, const float *R, const f
     if (rc) return rc;
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
-        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<char *>(tiled) + (size_t)q * per_view, H, W,
+        fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<char *>(tiled) + (size_t)q * per_view, H, W,
                   uni + (size_t)q * uni_view);
         d.tiles_x = tiles_x;
         d.pad = 2;
@@ -3214,7 +3295,7 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
         HIP_TRY(hipEventRecord(e->slot_ev[s], e->stream));
         e->slot_armed[s] = true;
         ViewDesc d;
-        fill_desc(d, K, R, t, dst, H, W);
+        fill_desc(e, d, K, R, t, dst, H, W);
         e->pending.push_back(d);
     }
     return after_enqueue(e);
@@ -3258,7 +3339,7 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
             e->deferred.row_stride = row; e->deferred.view_stride = view;
             for (int q = 0; q < V; ++q) {
                 ViewDesc d;
-                fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q, nullptr, H, W, nullptr);
+                fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q, nullptr, H, W, nullptr);
                 e->pending.push_back(d);
             }
             return SC_OK;
@@ -3280,7 +3361,7 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
     }
     for (int q = 0; q < V; ++q) {
         ViewDesc d;
-        fill_desc(d, K + 4 * q, R + 9 * q, t + 3 * q,
+        fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q,
                   static_cast<const char *>(masks_dev) + (int64_t)q * view, H, W);
         e->pending.push_back(d);
         rc = after_enqueue(e);
@@ -3397,6 +3478,15 @@ int sc_fused_counts(sc_engine *e, int64_t out[4]) {
     return SC_OK;
 }
 
+int sc_view_certified(const float origin[3], float voxel_size, int64_t nx, int64_t ny, int64_t nz, const float K[4],
+                      const float R[9], const float t[3], int *certified) {
+    if (!origin || !K || !R || !t || !certified) return fail(SC_ERR_INVALID, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return fail(SC_ERR_INVALID, "shape must be positive");
+    const int64_t first[3] = {0, 0, 0}, last[3] = {nx - 1, ny - 1, nz - 1};
+    *certified = certify_view(K, R, t, origin, voxel_size, first, last);
+    return SC_OK;
+}
+
 int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                          uint64_t *mismatches, uint64_t *fast_pairs) {
     if (!e || !mismatches || !fast_pairs || count < 0) return fail(SC_ERR_INVALID, "bad argument");
@@ -3436,6 +3526,26 @@ int sc_selftest_project(sc_engine *e, int64_t count, uint32_t seed, int nposes, 
     if (count == 0) return SC_OK;
     int rc = use_device(e);
     if (rc) return rc;
+    // each pose is certified (or not) for the box its samples come from, as fill_desc does for an engine's grid
+    std::vector<PoseRec> cert(hp, hp + nposes);
+    {
+        int64_t ilo[3] = {0, 0, 0}, ihi[3] = {0, 0, 0};
+        if (ijk) {
+            for (int a = 0; a < 3; ++a) ilo[a] = ihi[a] = ijk[a];
+            for (int64_t i = 0; i < count; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    ilo[a] = std::min<int64_t>(ilo[a], ijk[3 * i + a]);
+                    ihi[a] = std::max<int64_t>(ihi[a], ijk[3 * i + a]);
+                }
+        }
+        for (int q = 0; q < nposes; ++q) {
+            PoseRec &r = cert[q];
+            if (!ijk) { ihi[0] = r.nx - 1; ihi[1] = r.ny - 1; ihi[2] = r.nz - 1; }
+            const float o[3] = {r.ox, r.oy, r.oz};
+            r.pad[0] = certify_view(r.K, r.R, r.t, o, r.vs, ilo, ihi);
+        }
+    }
+    poses = reinterpret_cast<const float *>(cert.data());
     const size_t ndig = (size_t)((count + 65535) >> 16);
     PoseRec *dp = nullptr;
     int32_t *dijk = nullptr, *didx = nullptr;

@@ -205,3 +205,62 @@ def test_gpu_projection_equals_oracle_next_to_pixel_and_picture_borders(gpu_devi
         bad = np.flatnonzero(gw != ow)
         assert bad.size == 0, (seed, bad[:5], gw[bad[:5]], ow[bad[:5]])
     e.close()
+
+
+# -- CPU: the host-side certification of a pose (sc_view_certified) -------------------------------------
+def _projected_f32(shape, origin, vs, K, R, t, ijk):
+    """p_x, p_y, p_z of backprojection.c:11-18 in float32, one rounding per operation."""
+    R = np.asarray(R, F).reshape(9)
+    t = np.asarray(t, F)
+    x = F(origin[0]) + ijk[:, 0].astype(F) * F(vs)
+    y = F(origin[1]) + ijk[:, 1].astype(F) * F(vs)
+    z = F(origin[2]) + ijk[:, 2].astype(F) * F(vs)
+    with np.errstate(all="ignore"):
+        px = ((R[0] * x + R[1] * y) + R[2] * z) + t[0]
+        py = ((R[3] * x + R[4] * y) + R[5] * z) + t[1]
+        pz = ((R[6] * x + R[7] * y) + R[8] * z) + t[2]
+    return px, py, pz
+
+
+def test_certified_views_keep_their_promise_and_hopeless_ones_are_refused():
+    """What project() takes for granted of a certified view -- 2^-10 < p_z, |p_x|, |p_y|, p_z < 2^30 for
+    every voxel centre, intrinsics finite and below 2^30 -- holds on sampled voxels (corners included) of
+    every pose the host certifies; the bench scenes are certified; NaN / inf / a camera inside the grid /
+    a camera looking away are not."""
+    from plant3dvision_amd import scenes
+    rec, ent = pose_table()
+    rng = np.random.default_rng(11)
+    n_cert = n_not = 0
+    for q in range(len(ent)):
+        K, R, t, origin, vs, W, H, shape = ent[q]
+        cert = nat.view_certified(shape, origin, vs, K, R, t)
+        n_cert += cert
+        n_not += not cert
+        if not cert:
+            continue
+        corners = np.array([[a, b, c] for a in (0, shape[0] - 1) for b in (0, shape[1] - 1) for c in (0, shape[2] - 1)])
+        ijk = np.concatenate([corners, np.stack([rng.integers(0, s, 300) for s in shape], axis=1)]).astype(np.int64)
+        px, py, pz = _projected_f32(shape, origin, vs, K, R, t, ijk)
+        assert (pz > 2.0 ** -10).all() and (pz < 2.0 ** 30).all(), q
+        assert (np.abs(px) < 2.0 ** 30).all() and (np.abs(py) < 2.0 ** 30).all(), q
+        assert np.isfinite(np.asarray(K, F)).all() and (np.abs(np.asarray(K, F)) < 2.0 ** 30).all(), q
+    assert n_cert > 50 and n_not > 50, (n_cert, n_not)  # the self-test's table exercises both paths
+    shape, origin, vs, views = scenes.make_scene(512, 72, "plant")
+    assert all(nat.view_certified(shape, origin, vs, K, R, t) for K, R, t, _ in views)
+    shape, origin, vs, views = scenes.literal_real_plant_scene(60, "plant")
+    assert all(nat.view_certified(shape, origin, vs, K, R, t) for K, R, t, _ in views)
+    K, R, t, _ = views[0]
+    assert nat.view_certified(shape, origin, vs, K, R, t)
+    for bad in (np.nan, np.inf, -np.inf, 2.0 ** 31):
+        for which in range(3):
+            args = [np.array(K, F), np.array(R, F).reshape(9).copy(), np.array(t, F)]
+            args[which][0] = bad
+            assert not nat.view_certified(shape, origin, vs, *args), (bad, which)
+    centre = np.asarray(origin, np.float64) + 0.5 * vs * (np.asarray(shape) - 1)
+    Rm = np.asarray(R, np.float64).reshape(3, 3)
+    assert not nat.view_certified(shape, origin, vs, K, R, -Rm @ centre)           # the camera sits in the grid
+    cam = -Rm.T @ np.asarray(t, np.float64)            # the camera centre; turned round, it looks away
+    Rback = np.diag([-1.0, 1.0, -1.0]) @ Rm
+    assert not nat.view_certified(shape, origin, vs, K, Rback, -Rback @ cam)
+    with pytest.raises(ValueError):
+        nat.view_certified([0, 4, 4], origin, vs, K, R, t)
