@@ -26,6 +26,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     bad = 0
+    certified_views = uncertified_views = 0
     for c in range(cases):
         shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
         kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
@@ -42,6 +43,9 @@ def main():
             elif r < 0.3:   # telephoto
                 kw.update(fx=1e5, fy=1e5)
         sh, origin, vs, views = scenes.make_scene(shape, nviews, kind, **kw)
+        ncert = sum(nat.view_certified(sh, origin, vs, Kq, Rq, tq) for Kq, Rq, tq, _ in views)
+        certified_views += ncert
+        uncertified_views += len(views) - ncert
         dv = int(rng.choice([0, 0, 0, 1, -1, 5]))
         opts = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
         print(f"case {c}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts}", flush=True)
@@ -67,10 +71,11 @@ def main():
                       f"device {device_masks}: {int((got != want).sum())} voxels differ")
         e.dev_free(ptr); e.close()
         bad += 0 if ok else 1
-    print(f"{cases} cases, {bad} with mismatches")
+    print(f"{cases} cases, {bad} with mismatches; {certified_views} certified views, {uncertified_views} not")
     if len(sys.argv) > 3:
         import json
         json.dump({"tool": "tools/fuzz_carve.py", "cases": cases, "seed": int(sys.argv[2]), "cases_with_mismatches": bad,
+                   "views_on_the_certified_projection_path": certified_views, "views_on_the_general_path": uncertified_views,
                    "knobs": sorted(KNOBS), "scenes": ["plant", "noise", "solid", "empty", "dense"],
                    "checked": "HIP carve (host masks or device batch, fresh volume and a second batch on the stored one) "
                               "== oracle/spacecarve_oracle.c, every voxel"}, open(sys.argv[3], "w"), indent=1)
