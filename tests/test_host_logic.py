@@ -1,5 +1,7 @@
 """CPU: the host-side mirror of the reference interface (constructor contract, label loop,
 Voxels grid math and post-processing), with the oracle standing in for the device."""
+import os
+
 import numpy as np
 import pytest
 
@@ -281,3 +283,33 @@ def test_native_png_decoder_matches_pil_and_refuses_what_it_does_not_know():
     assert np.array_equal(read_image(RawFile(good, None)), m)           # the native decoder
     rgb = io.BytesIO(); Image.fromarray(m).convert("RGB").save(rgb, format="PNG")
     assert read_image(RawFile(rgb.getvalue(), m)) is m                   # refused -> the usual reader
+
+
+def test_png_decoder_survives_mutated_files_under_the_sanitizers(tmp_path):
+    """csrc/pngdec.cpp reads files from disk: built for the CPU with ASan + UBSan, it must decode or refuse
+    truncated / corrupted / foreign PNG files without touching memory it does not own (tools/png_fuzz.cpp)."""
+    import shutil
+    import subprocess
+    from PIL import Image
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "png_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(root, "include"), "-o", exe, os.path.join(root, "tools", "png_fuzz.cpp"),
+                           os.path.join(root, "plant-3d-vision_amd", "csrc", "pngdec.cpp"), "-lz"])
+    rng = np.random.default_rng(0)
+    seeds = []
+    for i, (w, h) in enumerate([(64, 48), (1, 1), (33, 7), (257, 129)]):
+        for name, arr, kw in (("b", (rng.random((h, w)) > 0.5).astype(np.uint8) * 255, dict(compress_level=1)),
+                              ("g", rng.integers(0, 256, (h, w), dtype=np.uint8), dict(compress_level=9, optimize=True)),
+                              ("s", (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8), dict())):
+            path = str(tmp_path / f"{name}{i}.png")
+            Image.fromarray(arr).save(path, **kw)
+            seeds.append(path)
+    Image.fromarray(rng.integers(0, 256, (20, 20, 3), dtype=np.uint8)).save(str(tmp_path / "rgb.png"))
+    Image.fromarray(rng.integers(0, 65536, (20, 20)).astype(np.uint16)).save(str(tmp_path / "g16.png"))
+    seeds += [str(tmp_path / "rgb.png"), str(tmp_path / "g16.png")]
+    out = subprocess.run([exe, "1500"] + seeds, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "accepted" in out.stdout and "refused" in out.stdout
