@@ -56,6 +56,9 @@ LANE_OPS_PER_VOXEL_VIEW = 52.7
 GRIDS_512 = {1: (512, 512, 512), 2: (640, 640, 640), 4: (808, 800, 832), 8: (1024, 1024, 1024)}
 
 
+COLLECTIVE = False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +80,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use device 0 (rehearsal)")
+    ap.add_argument("--rccl-rehearsal", action="store_true",
+                    help="one rank, but with an RCCL process group of one: barriers, the timing all-reduce and the "
+                         "assembly collectives run as they do at N > 1 (reported under 'assembly')")
     return ap.parse_args()
 
 
@@ -103,8 +109,12 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world, time_kernels=
     """Barrier + synchronize on both sides, MAX over ranks; returns (seconds, kernel stats).
     time_kernels=2: HIP events around the carve kernel only (the roofline's kernel); 1: around
     every kernel (each pair costs stream time, so the breakdown is taken in a separate pass)."""
+    world = 2 if COLLECTIVE else world  # barriers and the MAX over ranks also in the one-rank RCCL rehearsal
     engine.set_option(nat.SC_OPT_TIME_KERNELS, time_kernels)
     engine.reset_kernel_stats()
+    # the events of the timed launches exist before the clock starts (creating one costs the host tens of
+    # microseconds; the warm-up cannot be relied on to have left enough of them)
+    engine.set_option(nat.SC_OPT_RESERVE_EVENTS, min(65536, (2 if time_kernels == 2 else 16) * steps * (1 if vpl == 0 else 80) + 64))
     if world > 1:
         dist.barrier()
     engine.synchronize()
@@ -329,13 +339,21 @@ def main():
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         a.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # ONE JSON line on stdout: RCCL prints a version banner to stdout when its communicator comes up, so
+    # everything but that line (libraries included, file descriptor 1) goes to stderr from here on
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     if a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    global COLLECTIVE
+    collective = COLLECTIVE = world > 1 or a.rccl_rehearsal
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -350,6 +368,7 @@ def main():
     V = len(views)
     H, W = views[0][3].shape
     sb = ShardedBackprojection(gshape, origin, vs, rank=rank, world_size=world, device=local_rank)
+    sb.force_collective = bool(a.rccl_rehearsal)
     eng = sb.engine
     n_local = eng.num_voxels()
     n_total = int(np.prod(gshape))
@@ -366,7 +385,9 @@ def main():
         eng.set_option(int(k), int(val))
     vpl = {"fused": 0, "stream": 1}
     other = "stream" if a.path == "fused" else "fused"
-    # warmup both schedules (untimed)
+    # warmup (untimed), in the timing mode of the timed steps: the first batches with event pairs create
+    # their HIP events (tens of microseconds each), which is warm-up work, not a step's
+    eng.set_option(nat.SC_OPT_TIME_KERNELS, 2)
     run_steps(eng, nat, *call, a.warmup, vpl[a.path])
     eng.synchronize()
     dt, stats = timed(eng, nat, torch, dist, call, a.steps, vpl[a.path], world)
@@ -402,8 +423,10 @@ def main():
 
     # N > 1: carve + assembly, always (t_device + collective)
     asm = None
-    if world > 1 and a.assembly_steps > 0:
+    if collective and a.assembly_steps > 0:
         asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
+        if world == 1:
+            asm["rehearsal"] = "process group of one rank on one GPU: the collectives move nothing over xGMI"
     extras = avg = None
     if world == 1 and a.extra_steps > 0 and a.path == "fused":
         extras = extra_scenes(a, nat, torch, eng, gshape, masks_dev, a.extra_steps)
@@ -522,10 +545,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(gshape, origin, vs, views, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.dev_free(masks_dev)
     sb.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -112,6 +112,8 @@ extern "C" {
                                      are carved blind and skipped by later views; 0: the streaming kernel
                                      (every view reads the whole state: the north star's formulation)          */
 #define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1, 2 (default) or 4                  */
+#define SC_OPT_RESERVE_EVENTS 31    /* with SC_OPT_TIME_KERNELS: create n HIP events now (0..65536) so that the timed
+                                       launches that follow find them in the engine's pool instead of creating them */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
 
 /* kernel ids for sc_kernel_stats */

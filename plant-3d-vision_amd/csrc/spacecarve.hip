@@ -3159,6 +3159,17 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_VIEW_BRICK:
             e->view_brick = value ? 1 : 0;
             return SC_OK;
+        case SC_OPT_RESERVE_EVENTS: {
+            if (value < 0 || value > 65536) return fail(SC_ERR_INVALID, "reserve_events must be in [0, 65536]");
+            int rc = use_device(e);
+            if (rc) return rc;
+            while ((int64_t)e->event_pool.size() < value) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreate(&ev));
+                e->event_pool.push_back(ev);
+            }
+            return SC_OK;
+        }
         case SC_OPT_STAGE1_VOXELS:
             if (value != 1 && value != 2 && value != 4) return fail(SC_ERR_INVALID, "stage1_voxels must be 1, 2 or 4");
             e->stage1_voxels = value;

@@ -69,6 +69,9 @@ class ShardedBackprojection:
             rank = dist.get_rank() if dist.is_initialized() else 0
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.rank, self.world_size = int(rank), int(world_size)
+        #: rehearsal switch: with a process group of ONE rank, still go through the collectives (RCCL on a
+        #: one-GPU box exercises the same calls, buffers and stream ordering as on eight)
+        self.force_collective = False
         self.shape = [int(s) for s in shape]
         self.origin = origin
         self.voxel_size = voxel_size
@@ -193,7 +196,7 @@ class ShardedBackprojection:
             if not -128 <= int(self.default_value) <= 127:
                 raise ValueError("default_value does not fit int8")
             local = local.to(torch.int8)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collective:
             full = local.reshape(self.shape)
             return full.to(torch.int32) if compress and widen else full
         pad = self._planes_max() * self.shape[1] * self.shape[2]
@@ -225,7 +228,7 @@ class ShardedBackprojection:
                            device=local.device)
         pl = self.planes
         full[pl.start:pl.stop:pl.step] = local.reshape(len(pl), *self.shape[1:])
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collective:
             if dist.get_backend() == "gloo" and full.is_cuda:
                 h = full.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -244,7 +247,7 @@ class ShardedBackprojection:
         its slab to the host and the host tensors are gathered."""
         import torch
         import torch.distributed as dist
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collective:
             return np.ascontiguousarray(self.get_local()).reshape(self.shape)
         if compress is None:
             compress = self.dtype == np.int32 and -128 <= int(self.default_value) <= 127

@@ -214,3 +214,32 @@ def test_several_engines_from_one_process(gpu_device, partition, ndev):
     bp.close()
     with pytest.raises(ValueError):
         nat.EngineGroup(shape, origin, vs, nat.SC_MODE_CARVE, [])
+
+
+@pytest.mark.gpu
+def test_collectives_through_rccl_with_a_process_group_of_one(gpu_device):
+    """The calls an 8-GPU run makes -- all_gather_into_tensor / all_reduce / gather on device tensors that
+    alias the engine's memory, RCCL as the backend -- on the one GPU there is, with a group of one rank:
+    same buffers, same stream ordering, nothing moved over xGMI."""
+    port = _free_port()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        for partition, shape in (("cyclic", (37, 48, 64)), ("slab", (36, 32, 128))):
+            _, origin, vs, views = scene(tuple(shape), 8, "plant")
+            want = oracle_c.carve(list(shape), origin, vs, views)
+            sb = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, device=0, partition=partition)
+            sb.force_collective = True
+            for K, R, t, m in views:
+                sb.process_view(K, R, t, m)
+            full = sb.all_gather()
+            assert full.is_cuda and full.dtype == torch.int32 and np.array_equal(full.cpu().numpy(), want)
+            narrow = sb.all_gather(compress=True, widen=False)
+            assert narrow.dtype == torch.int8 and np.array_equal(narrow.cpu().numpy(), want)
+            assert np.array_equal(sb.all_reduce().cpu().numpy(), want)
+            host = sb.gather_to_host(dst=0)
+            assert host.dtype == np.int32 and np.array_equal(host, want)
+            dist.barrier()
+            sb.close()
+    finally:
+        dist.destroy_process_group()
