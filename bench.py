@@ -110,17 +110,22 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world, time_kernels=
     time_kernels=2: HIP events around the carve kernel only (the roofline's kernel); 1: around
     every kernel (each pair costs stream time, so the breakdown is taken in a separate pass)."""
     world = 2 if COLLECTIVE else world  # barriers and the MAX over ranks also in the one-rank RCCL rehearsal
-    engine.set_option(nat.SC_OPT_TIME_KERNELS, time_kernels)
+    span = time_kernels == "span"  # ONE event pair around all the steps: nothing between the batches
+    engine.set_option(nat.SC_OPT_TIME_KERNELS, 0 if span else time_kernels)
     engine.reset_kernel_stats()
     # the events of the timed launches exist before the clock starts (creating one costs the host tens of
     # microseconds; the warm-up cannot be relied on to have left enough of them)
-    engine.set_option(nat.SC_OPT_RESERVE_EVENTS, min(65536, (2 if time_kernels == 2 else 16) * steps * (1 if vpl == 0 else 80) + 64))
+    engine.set_option(nat.SC_OPT_RESERVE_EVENTS,
+                      8 if span else min(65536, (2 if time_kernels == 2 else 16) * steps * (1 if vpl == 0 else 80) + 64))
     if world > 1:
         dist.barrier()
     engine.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if span:
+        engine.span_begin()
     run_steps(engine, nat, *args_tuple, steps, vpl)
+    span_ms = engine.span_end() if span else 0.0  # waits for the second event
     engine.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -137,6 +142,9 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world, time_kernels=
                       ("flags", nat.SC_KERNEL_FLAGS), ("step", nat.SC_KERNEL_STEP)):
         n, ms = engine.kernel_stats(kid)
         stats[name] = {"launches": n, "total_ms": ms, "avg_ms": (ms / n if n else 0.0)}
+    if span:
+        stats["step"] = {"launches": steps, "total_ms": span_ms, "avg_ms": span_ms / steps,
+                         "timing": "one HIP event pair on the engine's stream around all the steps"}
     engine.set_option(nat.SC_OPT_TIME_KERNELS, 0)
     engine.reset_kernel_stats()
     return dt, stats
@@ -390,7 +398,8 @@ def main():
     eng.set_option(nat.SC_OPT_TIME_KERNELS, 2)
     run_steps(eng, nat, *call, a.warmup, vpl[a.path])
     eng.synchronize()
-    dt, stats = timed(eng, nat, torch, dist, call, a.steps, vpl[a.path], world)
+    dt, stats = timed(eng, nat, torch, dist, call, a.steps, vpl[a.path], world,
+                      time_kernels="span" if a.path == "fused" else 2)
     # per-kernel breakdown: a separate short pass with events around every kernel
     bsteps = max(2, min(a.steps, 5))
     dtb, breakdown = timed(eng, nat, torch, dist, call, bsteps, vpl[a.path], world, time_kernels=1)
@@ -460,10 +469,12 @@ def main():
     def roof(path, st, traffic):
         if path == "fused":
             # One "launch" of the fused schedule is the whole batch: pack16 -> brick_flags ->
-            # carve_brick -> carve_list<false> -> carve_list<true> (-> resume), timed by ONE event
-            # pair on the engine's stream (SC_KERNEL_STEP).  No single kernel of it owns the label
-            # write any more (the -1 fill of empty bricks rides with the final list stage), so the
-            # roofline is stated for the sequence.
+            # carve_brick -> carve_list<false> -> carve_list<true> (-> resume).  The timed steps are
+            # bracketed by ONE HIP event pair on the engine's stream (sc_span_begin / sc_span_end); a
+            # batch's duration is that span over the number of batches in it (they run back to back;
+            # an event pair per batch would put a barrier packet between them).  No single kernel of
+            # it owns the label write any more (the -1 fill of empty bricks rides with the final list
+            # stage), so the roofline is stated for the sequence.
             avg_ms = st["step"]["avg_ms"]
             launches = st["step"]["launches"]
             bytes_launch = 4.0 * n_local + float(V) * W * H

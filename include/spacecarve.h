@@ -238,6 +238,13 @@ int64_t sc_num_voxels(const sc_engine *e);
 int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *total_ms);
 int sc_reset_kernel_stats(sc_engine *e);
 
+/* One HIP event pair on the engine's stream around whatever the caller enqueues in between (any number
+ * of batches): sc_span_begin records the first event where the stream stands, sc_span_end records the
+ * second, waits for it and returns the milliseconds between them.  Unlike SC_OPT_TIME_KERNELS this puts
+ * nothing between the batches (an event pair per batch is a barrier packet each, 3-5 us of stream time). */
+int sc_span_begin(sc_engine *e);
+int sc_span_end(sc_engine *e, double *ms);
+
 /* Diagnostics of the last fused carve launch (waits for the stream): out[0] bricks no view found
  * empty (brick form, else 0), out[1] voxels alive after the dense stage, out[2] after the first
  * survivor stage, out[3] 1 if a survivor list overflowed (the dense resume kernel took over). */

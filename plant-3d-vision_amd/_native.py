@@ -61,6 +61,8 @@ _SIGNATURES = {
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_fused_counts": ("i", ["p", "p"]),
+    "sc_span_begin": ("i", ["p"]),
+    "sc_span_end": ("i", ["p", "p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
     "sc_selftest_project": ("i", ["p", "q", "I", "i", "p", "p", "p", "p", "p"]),
     "sc_view_certified": ("i", ["p", "f", "q", "q", "q", "p", "p", "p", "p"]),
@@ -512,6 +514,16 @@ class Engine:
 
     def reset_kernel_stats(self):
         self._call("sc_reset_kernel_stats")
+
+    def span_begin(self):
+        """First event of a pair on the engine's stream (see ``span_end``)."""
+        self._call("sc_span_begin")
+
+    def span_end(self):
+        """Second event of the pair: waits for it, returns the milliseconds since ``span_begin``."""
+        out = np.zeros(1, dtype=np.float64)
+        self._call("sc_span_end", addr(out))
+        return float(out[0])
 
     def fused_counts(self):
         """(live bricks, voxels alive after the dense stage, after the first list stage, overflow)

@@ -1964,6 +1964,8 @@ struct sc_engine {
     std::vector<TimedLaunch> timed[kNumKernels];
     hipEvent_t step_start = nullptr;
     bool step_open = false;
+    hipEvent_t span_start = nullptr;  // sc_span_begin .. sc_span_end
+    bool span_open = false;
     std::vector<hipEvent_t> event_pool;
 };
 
@@ -3053,6 +3055,7 @@ void sc_destroy(sc_engine *e) {
             (void)hipEventDestroy(tl.stop);
         }
     if (e->step_open) (void)hipEventDestroy(e->step_start);
+    if (e->span_open) (void)hipEventDestroy(e->span_start);
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     for (auto &c : e->chunks) (void)hipFree(c.base);
     for (int s = 0; s < kSlots; ++s) {
@@ -3467,6 +3470,41 @@ int sc_reset_kernel_stats(sc_engine *e) {
         }
         e->timed[k].clear();
     }
+    return SC_OK;
+}
+
+int sc_span_begin(sc_engine *e) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (e->span_open) return fail(SC_ERR_STATE, "a span is open already");
+    rc = get_event(e, &e->span_start);
+    if (rc) return rc;
+    hipEvent_t stop;
+    rc = get_event(e, &stop);  // the second event exists before the span starts
+    if (rc) return rc;
+    e->event_pool.push_back(stop);
+    HIP_TRY(hipEventRecord(e->span_start, e->stream));
+    e->span_open = true;
+    return SC_OK;
+}
+
+int sc_span_end(sc_engine *e, double *ms) {
+    if (!e || !ms) return fail(SC_ERR_INVALID, "null argument");
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (!e->span_open) return fail(SC_ERR_STATE, "no span is open");
+    hipEvent_t stop;
+    rc = get_event(e, &stop);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(stop, e->stream));
+    HIP_TRY(hipEventSynchronize(stop));
+    float f = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&f, e->span_start, stop));
+    *ms = (double)f;
+    e->event_pool.push_back(e->span_start);
+    e->event_pool.push_back(stop);
+    e->span_open = false;
     return SC_OK;
 }
 
