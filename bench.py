@@ -393,6 +393,8 @@ def main():
         eng.set_option(int(k), int(val))
     vpl = {"fused": 0, "stream": 1}
     other = "stream" if a.path == "fused" else "fused"
+    if a.path == "stream":
+        eng.set_option(nat.SC_OPT_VIEW_BRICK, 0)  # the streaming kernel, not the brick form of a one-view launch
     # warmup (untimed), in the timing mode of the timed steps: the first batches with event pairs create
     # their HIP events (tens of microseconds each), which is warm-up work, not a step's
     eng.set_option(nat.SC_OPT_TIME_KERNELS, 2)

@@ -87,7 +87,7 @@ def main():
            "carve_list_kernel<false>", "carve_list_kernel<true>", "carve_resume_kernel<true>")
     parts = {s: per_kernel[s]["hbm_bytes_per_launch"] for s in seq
              if s in per_kernel and "hbm_bytes_per_launch" in per_kernel[s]}
-    if parts:
+    if "carve_list_kernel<true>" in parts:  # a run of the fused schedule (a stream run has pack and flags launches too)
         traffic[f"fused_{a.scene}_{a.n}_{a.views}"] = {
             "hbm_bytes_per_launch": sum(parts.values()), "source": f"profiles/{a.tag}_pmc.json",
             "kernel": "fused batch = one launch each of: " + ", ".join(parts), "per_kernel": parts,
