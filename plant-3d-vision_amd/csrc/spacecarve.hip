@@ -110,6 +110,7 @@ struct CullStores {
     uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
     int32_t kept, fresh;   // see Fill
     uint32_t fill_blocks;  // 0: one store block per strip; n: n persistent store blocks
+    int32_t init;          // see Fill
 };
 
 // XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
@@ -493,15 +494,17 @@ constexpr int kBrickY = 16, kBrickZ = 64;
 // every corner in front of the camera its image is the convex hull of the images of its four
 // corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
 // corners hold for every voxel of the brick.
-struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == false: no verdict possible
+struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == false: no verdict from the tiles
     int tx0, tx1, ty0, ty1;
     bool ok;
+    bool outside;  // every voxel of the brick is behind the camera or projects out of the picture: the view
+                   // does nothing to it (backprojection.c:13,23-31)
 };
 
 __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0) {
-    Footprint fpr{0, 0, 0, 0, false};
+    Footprint fpr{0, 0, 0, 0, false, false};
     float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
-    float pzmin = INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    float pzmin = INFINITY, pzmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -525,11 +528,15 @@ __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const Gr
         // fminf/fmaxf drop NaN operands: track them explicitly
         nan |= __builtin_isunordered(u, v) | __builtin_isunordered(pz, pz);
         pzmin = fminf(pzmin, pz);
+        pzmax = fmaxf(pzmax, pz);
         qxm = fmaxf(qxm, fabsf(qx)); qym = fmaxf(qym, fabsf(qy));
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
     }
     if (nan) return fpr;
+    // depth is affine over the rectangle and its rounding error is below ez: with every corner below
+    // -4 ez every voxel has p_z < 0 and is rejected (:13)
+    if (pzmax < -4.0f * ez) { fpr.outside = true; return fpr; }
     bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
     // pixel-space slack: 2 px + propagated dot-product error + 8 ulp of the largest magnitude in
     // q * f + c (quotient estimate above, the voxel kernels' own division, product and sum
@@ -543,6 +550,9 @@ __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const Gr
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
     // a NaN anywhere makes a comparison false -> no culling
     bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
+    // the widened box holds every voxel's uf, vf: all of it at or left of -1, at or right of W, above or
+    // below the picture means (int)uf is outside [0, W - 1] (or (int)vf outside [0, H - 1]) for all of them
+    fpr.outside = front & ((umax <= -1.0f) | (umin >= d.Wf) | (vmax <= -1.0f) | (vmin >= d.Hf));
     if (!inside) return fpr;
     fpr.tx0 = (int)umin >> 5; fpr.tx1 = (int)umax >> 5; fpr.ty0 = (int)vmin >> 5; fpr.ty1 = (int)vmax >> 5;
     fpr.ok = (fpr.tx1 - fpr.tx0 + 1) * (fpr.ty1 - fpr.ty0 + 1) <= 64;
@@ -552,6 +562,7 @@ __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const Gr
 __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
                                                   int k0, int occ_tx) {
     const Footprint fpr = brick_footprint(d, g, x, j0, k0);
+    if (fpr.outside) return 4u;  // OUTSIDE: the view does nothing to the brick
     if (!fpr.ok) return 0u;
     uint32_t any = 0, all = 3;
     for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
     FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch,
     uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list) {
-    __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves];
+    __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves], s_seen[kFlagWaves];
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
         if (threadIdx.x == 0) ctl->nlive[parity ^ 1u] = ctl->nfill[parity ^ 1u] = 0u;  // the next launch's counters
@@ -632,31 +643,35 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     const int j0 = (int)(by * kBrickY), k0 = (int)(bz * kBrickZ);
     // round 0: the first `nviews` views, one per wavefront (more: strided)
-    bool empty = false, full = true;
+    // `full`: every view so far keeps the brick as it is -- sees all of it over foreground (verdict 2) or
+    // does not see it at all (4, OUTSIDE); `seen`: at least one of them was a 2, so a label 0 becomes 1
+    bool empty = false, full = true, seen = false;
     if (valid) {
         if (views == nullptr) {  // grid-uniform: nviews <= kFlagWaves, one view per wavefront
             if ((int)wave < nviews) {
                 const uint32_t v = brick_verdict(own.v[wave], g, x, j0, k0, own.v[wave].tiles_x);
                 empty = v == 1u;
-                full = v == 2u;
+                full = v == 2u || v == 4u;
+                seen = v == 2u;
             }
         } else {
             for (int vi = (int)wave; vi < nviews; vi += kFlagWaves) {
                 const ViewDesc d = views[vi];
                 const uint32_t v = brick_verdict(d, g, x, j0, k0, d.tiles_x);
                 empty |= v == 1u;
-                full &= v == 2u;
+                full &= v == 2u || v == 4u;
+                seen |= v == 2u;
             }
         }
     }
-    unsigned long long any_empty = 0, cand = 0;
+    unsigned long long any_empty = 0, cand = 0, any_seen = 0;
     {
-        const unsigned long long me = __ballot(empty), mf = __ballot(full && valid);
-        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; }
+        const unsigned long long me = __ballot(empty), mf = __ballot(full && valid), ms = __ballot(seen);
+        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; s_seen[wave] = ms; }
         __syncthreads();
         cand = ~0ull;
 #pragma unroll
-        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; }
+        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; any_seen |= s_seen[w]; }
         cand &= ~any_empty;
     }
     // FULL candidates (every view so far sees the whole brick over foreground) go through the
@@ -664,26 +679,28 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     // round 0; inside a solid object this is what spares its voxels all their projections
     for (int base = nviews; base < nall && cand != 0; base += kFlagWaves) {  // block-uniform
         const int vi = base + (int)wave;
-        bool e2 = false, f2 = true;
+        bool e2 = false, f2 = true, s2 = false;
         if (vi < nall && ((cand >> lane) & 1ull)) {
             const ViewDesc d = allviews[vi];
             const uint32_t v = brick_verdict(d, g, x, j0, k0, d.tiles_x);
             e2 = v == 1u;
-            f2 = v == 2u;
+            f2 = v == 2u || v == 4u;
+            s2 = v == 2u;
         }
-        const unsigned long long me = __ballot(e2), mf = __ballot(f2);
+        const unsigned long long me = __ballot(e2), mf = __ballot(f2), ms = __ballot(s2);
         __syncthreads();  // the previous round's masks have been read by everybody
-        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; }
+        if (lane == 0) { s_empty[wave] = me; s_full[wave] = mf; s_seen[wave] = ms; }
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; }
+        for (int w = 0; w < kFlagWaves; ++w) { any_empty |= s_empty[w]; cand &= s_full[w]; any_seen |= s_seen[w]; }
         cand &= ~any_empty;
     }
     if (nall <= 0) cand = 0;  // fullness not asked for
     if (wave != 0) return;
-    const bool gone = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull;
-    // kept by every view of the batch: FULL (2); by every view packed so far only: a candidate (3)
-    if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? 2 : 3) : 0));
+    const bool gone = (any_empty >> lane) & 1ull, kept = (cand >> lane) & 1ull, saw = (any_seen >> lane) & 1ull;
+    // kept by every view of the batch: FULL (2: some view saw it, a 0 becomes 1) or UNTOUCHED (6: no view
+    // sees any of it, the labels stay); by every view packed so far only: a candidate (3 seen / 7 unseen)
+    if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? (saw ? 2 : 6) : (saw ? 3 : 7)) : 0));
     if (valid && dead != nullptr && (gone || dead_stale)) dead[lb] = gone ? 1 : 0;
     // the bricks left go on the live list, one atomic per block
     const bool alive = valid && !gone && !kept;
@@ -703,7 +720,8 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
             if (lane == 0) base = atomicAdd(&ctl->nfill[parity], (uint32_t)__popcll(mf));
             base = __shfl(base, 0);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if (fillme) fill_list[base + (uint32_t)__popcll(mf & below)] = lb | (gone ? 0u : 0x80000000u);
+            // bit 31: kept whole (0 -> 1); bit 30: kept and unseen (nothing changes)
+            if (fillme) fill_list[base + (uint32_t)__popcll(mf & below)] = lb | (gone ? 0u : (saw ? 0x80000000u : 0x40000000u));
         }
     }
 }
@@ -846,6 +864,7 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
 struct Fill {
     int32_t kept;   // label of a FULL brick's voxels when the volume is fresh: init == 0 ? 1 : init
     int32_t fresh;  // the volume holds `init` everywhere (nothing applied since clear)
+    int32_t init;   // ... and this is what an UNTOUCHED brick (flag 6) of a fresh volume gets
 };
 
 __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
@@ -856,17 +875,20 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
     const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
     const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
     const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
+    // UNTOUCHED bricks (6) keep their labels: only a fresh volume, whose labels exist as `init` in name
+    // only, has something to write there
+    const unsigned long long untouched = fill.fresh ? __ballot(f == 6u) : 0ull;
     if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
     int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
     const bool vec = (g.nz & 3u) == 0;
     for (uint32_t bz = 0; bz < bricks_z; ++bz) {
-        const bool isfull = (full >> bz) & 1ull;
-        if (!((culled >> bz) & 1ull) && !isfull) continue;
+        const bool isfull = (full >> bz) & 1ull, isunt = (untouched >> bz) & 1ull;
+        if (!((culled >> bz) & 1ull) && !isfull && !isunt) continue;
         const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
         if (k0 >= g.nz) continue;
         const uint32_t n = min(4u, g.nz - k0);
         if (!isfull || fill.fresh) {
-            const int32_t val = isfull ? fill.kept : -1;
+            const int32_t val = isunt ? fill.init : (isfull ? fill.kept : -1);
             if (vec) {
                 // streaming store: the fill is written once and not read again by this batch; kept
                 // out of the caches it does not evict the masks the next batch packs
@@ -892,10 +914,12 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
-    __shared__ unsigned long long s_full[kFlagWaves];
+    __shared__ unsigned long long s_full[kFlagWaves], s_seen[kFlagWaves];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t lb = blockIdx.x * 64u + lane;
-    const bool isc = lb < nbricks && flags[lb] == 3u;
+    const uint32_t fl = lb < nbricks ? flags[lb] : 0u;
+    const bool isc = fl == 3u || fl == 7u;  // candidates: some view so far saw the brick whole / none sees it
+    unsigned long long any_seen = __ballot(fl == 3u);
     unsigned long long cand = __ballot(isc);
     if (cand == 0) return;  // block-uniform: every wavefront read the same 64 flags
     const uint32_t per_plane = bricks_y * bricks_z;
@@ -905,20 +929,22 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
         const int vi = base + (int)wave;
-        bool keeps = true;
+        bool keeps = true, sees = false;
         if (vi < v1 && ((cand >> lane) & 1ull)) {
             const ViewDesc d = views[vi];
-            keeps = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x) == 2u;
+            const uint32_t v = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
+            keeps = v == 2u || v == 4u;
+            sees = v == 2u;
         }
-        const unsigned long long mf = __ballot(keeps);
+        const unsigned long long mf = __ballot(keeps), ms = __ballot(sees);
         __syncthreads();  // the previous round's masks have been read by everybody
-        if (lane == 0) s_full[wave] = mf;
+        if (lane == 0) { s_full[wave] = mf; s_seen[wave] = ms; }
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kFlagWaves; ++w) cand &= s_full[w];
+        for (int w = 0; w < kFlagWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
     }
     if (wave != 0) return;
-    if (isc) flags[lb] = ((cand >> lane) & 1ull) ? 2 : 5;
+    if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
     const bool failed = isc && !((cand >> lane) & 1ull);
     const unsigned long long m = __ballot(failed);
     if (m != 0) {
@@ -958,7 +984,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     if (blockIdx.x >= nwalkers) {
         store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
-                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0});
+                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0, init});
         return;
     }
     const uint32_t nlive = ctl->nlive[parity];
@@ -1001,8 +1027,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             const uint32_t n = min(64u, nfill - base);
             for (uint32_t q = 0; q < n; ++q) {
                 const uint32_t ent = __builtin_amdgcn_readlane(mine, q);
-                const bool isfull = (ent >> 31) != 0;
-                const uint32_t lb = ent & 0x7fffffffu;
+                const bool isfull = (ent >> 31) != 0, isunt = ((ent >> 30) & 1u) != 0;
+                if (isunt && !FRESH) continue;  // kept and unseen: the labels stay
+                const uint32_t lb = ent & 0x3fffffffu;
                 const uint32_t il = lb / per_plane;
                 const uint32_t rem = lb - il * per_plane;
                 const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
@@ -1011,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nz + k0;
                 const uint32_t nv4 = min(4u, g.nz - k0);
                 if (!isfull || FRESH) {
-                    const int32_t val = isfull ? kept : -1;
+                    const int32_t val = isunt ? init : (isfull ? kept : -1);
                     if (vec) {
                         typedef int v4i __attribute__((ext_vector_type(4)));
                         v4i vv = {val, val, val, val};
@@ -1109,7 +1136,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         // wavefront's stores do not hold it up, so few of them keep the write path busy and the
         // wavefront slots go to the list blocks
         for (uint32_t strip = cs.first + (blockIdx.x - nbid); strip < cs.nstrips; strip += nstore)
-            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh});
+            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
@@ -1312,7 +1339,7 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
             decode_group(g, grp, vx);
             const uint32_t col = (uint32_t)(vx.elem / g.nz), il = col / g.ny, j = col - il * g.ny;
             const uint32_t fl = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ];
-            skip = fl == 5u || fl == 2u;
+            skip = fl == 5u || fl == 2u || fl == 6u;
         }
         // (a wavefront's lanes leave carve_group's view loop together: skipped lanes still vote)
         if (grp < g.ngroups && !skip) {
@@ -2522,7 +2549,7 @@ FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
     p.bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY);
     p.bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
     p.brick = (nv > 1 || e->view_brick) && e->brick && p.bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
-              (uint64_t)e->planes * p.bys * p.bzs < 0x80000000ull && has_occ;
+              (uint64_t)e->planes * p.bys * p.bzs < 0x40000000ull && has_occ;  // brick ids carry two flag bits in the fill list
     p.nbricks = p.brick ? (uint32_t)((uint64_t)e->planes * p.bys * p.bzs) : 0u;
     p.flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
     if (e->flag_views > 0 && e->flag_views < (int64_t)p.flag_views) p.flag_views = (int)e->flag_views;
@@ -2774,7 +2801,7 @@ int flush(sc_engine *e, size_t count = 0) {
             if (rc) return rc;
             int vg = (int)e->view_group;
             // open FULL candidates exist only when packing rode beside the dense stage
-            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u}, cs = none;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0}, cs = none;
             if (ride_blocks) {
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
                 hipLaunchKernelGGL(brick_confirm_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0, e->stream, g,
@@ -2791,11 +2818,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 if ((size_t)s1 < nv && e->stage1_store_share > 0) {
                     mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
                     const uint32_t n1 = mid - dense_store_strips, f1 = std::min<uint32_t>((uint32_t)e->fill_blocks, n1);
-                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, f1};
+                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, f1, init};
                     grid1 = dim3((uint32_t)e->stage1_list_blocks + (f1 ? f1 : n1));
                 }
                 const uint32_t nf = nstrips - mid, ff = std::min<uint32_t>((uint32_t)e->fill_blocks, nf);
-                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff};
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff, init};
                 fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
 #define LAUNCH_LIST(FIN, GRID, ...)                                                                      \

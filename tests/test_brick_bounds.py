@@ -27,13 +27,15 @@ def voxel_pixels(shape, origin, vs, K, R, t):
         return pz, ((px / pz) * K[0]) + K[2], ((py / pz) * K[1]) + K[3]
 
 
-def brick_box(origin, vs, K, R, t, i, j0, k0):
+def brick_box(origin, vs, K, R, t, i, j0, k0, info=None):
     """The kernel's bounding box of brick (plane i, columns j0.., voxels k0..): None if it gives up,
-    else (umin, umax, vmin, vmax) AFTER widening, with the estimate-error allowance removed."""
+    else (umin, umax, vmin, vmax) AFTER widening, with the estimate-error allowance removed.
+    `info` (a dict) receives `behind`: every corner deeper than 4 ez behind the camera."""
     R = np.asarray(R, dtype=F).reshape(9); t = np.asarray(t, dtype=F).reshape(3); K = np.asarray(K, dtype=F).reshape(4)
     x = F(F(origin[0]) + F(i) * F(vs))
     ez = ex = ey = qxm = qym = F(0)
     pzmin, umin, umax, vmin, vmax = F(np.inf), F(np.inf), F(-np.inf), F(np.inf), F(-np.inf)
+    pzmax = F(-np.inf)
     with np.errstate(all="ignore"):
         for c in range(4):
             y = F(F(origin[1]) + F(j0 + (BY - 1 if c >> 1 else 0)) * F(vs))
@@ -49,8 +51,10 @@ def brick_box(origin, vs, K, R, t, i, j0, k0):
             u, v = qx * K[0] + K[2], qy * K[1] + K[3]
             if np.isnan(u) or np.isnan(v) or np.isnan(pz):
                 return None
-            pzmin = min(pzmin, pz); qxm = max(qxm, abs(qx)); qym = max(qym, abs(qy))
+            pzmin = min(pzmin, pz); pzmax = max(pzmax, pz); qxm = max(qxm, abs(qx)); qym = max(qym, abs(qy))
             umin, umax, vmin, vmax = min(umin, u), max(umax, u), min(vmin, v), max(vmax, v)
+        if info is not None:
+            info["behind"] = bool(pzmax < F(-4) * ez)
         if not pzmin > F(4) * ez:
             return None
         inv = F(2) / pzmin
@@ -136,3 +140,48 @@ def test_corner_box_random_cameras(seed):
                     assert (v >= box[2]).all() and (v <= box[3]).all(), (seed, box, float(v.min()), float(v.max()))
                     accepted += 1
     assert accepted > 0
+
+
+def brick_outside(origin, vs, K, R, t, W, H, i, j0, k0):
+    """The kernel's OUTSIDE verdict (brick_footprint): every corner well behind the camera, or the brick
+    in front and its widened box entirely left of -1, right of W, above -1 or below H."""
+    info = {}
+    box = brick_box(origin, vs, K, R, t, i, j0, k0, info)
+    if info.get("behind"):
+        return True
+    if box is None:
+        return False
+    # brick_box took the estimate allowance OFF the slack (the smallest box the kernel may use); the
+    # verdict needs the whole box out of the picture, so the smallest box is the one to test
+    return box[1] <= -1.0 or box[0] >= float(W) or box[3] <= -1.0 or box[2] >= float(H)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_outside_verdict_means_no_voxel_is_touched(seed):
+    """Whenever the restated test calls a brick OUTSIDE for a view, the reference arithmetic rejects every
+    voxel of it (p_z < 0, or the truncated pixel outside the picture: backprojection.c:13,23-31)."""
+    rng = np.random.default_rng(5000 + seed)
+    shape = (2, int(rng.integers(5, 50)), int(rng.integers(10, 200)))
+    vs = float(rng.choice([0.25, 1.0, 3.0]))
+    origin = (rng.normal(size=3) * 50.0).astype(F)
+    extent = max(shape) * vs
+    center = origin + np.array(shape) * vs / 2.0
+    outside = inside_some = 0
+    for _ in range(12):
+        R, t = _random_pose(rng, center, extent)
+        w, h = int(rng.integers(20, 400)), int(rng.integers(20, 300))  # small pictures: much falls outside
+        f = float(w * rng.choice([0.5, 2.0, 10.0]))
+        K = np.array([f, f * rng.uniform(0.8, 1.25), w * rng.choice([0.5, 0.2, 1.5]), h * rng.choice([0.5, 0.8, -0.5])], dtype=F)
+        pz, uf, vf = voxel_pixels(shape, origin, vs, K, R, t)
+        with np.errstate(invalid="ignore"):
+            touched = ~(pz < 0) & (uf > -1) & (uf < w) & (vf > -1) & (vf < h)
+        for i in range(shape[0]):
+            for j0 in range(0, shape[1], BY):
+                for k0 in range(0, shape[2], BZ):
+                    sl = (i, slice(j0, min(shape[1], j0 + BY)), slice(k0, min(shape[2], k0 + BZ)))
+                    if brick_outside(origin, vs, K, R, t, w, h, i, j0, k0):
+                        assert not touched[sl].any(), (seed, i, j0, k0)
+                        outside += 1
+                    elif touched[sl].any():
+                        inside_some += 1
+    assert outside > 0 and inside_some > 0, (outside, inside_some)

@@ -1082,3 +1082,31 @@ def test_int8_read_back_of_carve_labels(gpu_device):
     bp.clear()
     assert (bp.get_values() == 0).all() and np.array_equal(got, want)  # the array handed out kept its contents
     bp.close()
+
+
+@pytest.mark.parametrize("default_value", [0, 1, -1, 5])
+@pytest.mark.parametrize("kind", ["plant", "solid", "dense"])
+def test_bricks_no_view_sees_keep_their_labels(gpu_device, kind, default_value):
+    """A grid much larger than what the cameras see (narrow pictures, a ring close to the object): most of
+    its bricks lie outside every picture.  The verdict for such a brick and view is OUTSIDE (the view does
+    nothing to it); kept by every view, seen by none: UNTOUCHED, its labels stay `default_value` -- on a
+    fresh volume, on a stored one, one launch per view, and with the views that see part of a brick packed
+    late (candidates that fail the confirmation)."""
+    shape = (12, 96, 384)
+    kw = dict(width=96, height=64, fx=260.0, fy=260.0, cx=48.0, cy=32.0, radius_factor=1.1)
+    _, origin, vs, views = scene(shape, 14, kind, **kw)
+    want = oracle_c.carve(list(shape), origin, vs, views, default_value, nthreads=4)
+    h = histogram3(want) if default_value == 0 else None
+    if h is not None:
+        assert h[1] > 0.3 * want.size, h  # a good part of the grid is seen by no view (label 0 stays)
+        assert h[0] > 0 or kind != "plant", h
+    for opts in ((), ((nat.SC_OPT_FLAG_VIEWS, 3),), ((nat.SC_OPT_PACK_RIDE, 0),), ((nat.SC_OPT_FULL_BRICKS, 0),),
+                 ((nat.SC_OPT_DEFER_STORES, 0),), ((nat.SC_OPT_VIEWS_PER_LAUNCH, 1),), ((nat.SC_OPT_VIEWS_PER_LAUNCH, 5),),
+                 ((nat.SC_OPT_VIEWS_PER_LAUNCH, 1), (nat.SC_OPT_VIEW_BRICK, 0)), ((nat.SC_OPT_COMPACT, 0),)):
+        got, counts = _device_batch_carve(shape, origin, vs, views, opts=opts, default_value=default_value)
+        assert np.array_equal(got, want), (kind, default_value, opts, histogram3(got), histogram3(want))
+    # a stored volume: three views one by one first, then the batch
+    got, _ = _device_batch_carve(shape, origin, vs, views[3:], default_value=default_value, preload=views[:3])
+    assert np.array_equal(got, want), (kind, default_value, "stored")
+    got = hip_carve(shape, origin, vs, views, default_value=default_value)
+    assert np.array_equal(got, want), (kind, default_value, "host masks")
