@@ -73,10 +73,11 @@ struct GridDesc {
     float ox, oy, oz, vs;
     uint32_t ny, nz;
     uint32_t i0;        // global x index of the engine's first plane
-    uint32_t gpc;       // 4-voxel groups per column = ceil(nz / 4)
+    uint32_t gpc;       // 4-voxel groups per row = nzp / 4 (the last ones of a padded row own fewer than 4 voxels, or none)
     uint64_t ngroups;   // columns owned * gpc
     uint32_t istride;   // global x step between the engine's planes (1: slab, W: plane-cyclic)
-    uint32_t pad_;
+    uint32_t nzp;       // row pitch of the state in voxels: nz rounded up to a multiple of 64 (a row = one
+                        // (plane, column) run of nz voxels, 256-byte aligned; the padding is never read back)
 };
 
 constexpr int kBlock = 256;
@@ -225,7 +226,7 @@ __device__ __forceinline__ uint32_t load_mask_word(const void *mask, uint32_t wo
 struct Vox4 {
     uint64_t elem;   // offset of the group's first voxel in the slab state
     uint32_t k0;     // z index of that voxel
-    uint32_t nvalid; // 1..4 voxels of this group that exist (nz tail)
+    uint32_t nvalid; // 0..4 voxels of this group that exist (nz tail, row padding)
     float x, y;
 };
 
@@ -243,8 +244,8 @@ __device__ __forceinline__ void decode_group(const GridDesc &g, uint64_t grp, Vo
     uint32_t il = col / g.ny;
     uint32_t j = col - il * g.ny;
     vx.k0 = kq * 4u;
-    vx.nvalid = min(4u, g.nz - vx.k0);
-    vx.elem = (uint64_t)col * g.nz + vx.k0;
+    vx.nvalid = vx.k0 < g.nz ? min(4u, g.nz - vx.k0) : 0u;
+    vx.elem = (uint64_t)col * g.nzp + vx.k0;  // == grp * 4: rows are whole groups
     // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index of the plane
     vx.x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     vx.y = g.oy + (float)(int)j * g.vs;
@@ -269,7 +270,10 @@ __device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const 
                                             const Append &ap) {
     Vox4 vx;
     int32_t lab[4], was[4];
-    if (!VEC) decode_group(g, grp, vx);  // the address needs the column
+    // a grid whose rows are padded (nz not a multiple of 64) has groups that own fewer than four voxels:
+    // they are told apart up front; on an unpadded grid a group is decoded only if something in it lives
+    const bool padded = g.nzp != g.nz;  // grid-uniform
+    if (!VEC || padded) decode_group(g, grp, vx);
     int32_t *p = labels + (VEC ? grp * 4 : vx.elem);
     if (FRESH) {
 #pragma unroll
@@ -283,11 +287,12 @@ __device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const 
     uint32_t alive = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if (VEC && padded && e >= (int)vx.nvalid) lab[e] = -1;  // padding counts as carved
         was[e] = lab[e];
         if ((VEC || e < (int)vx.nvalid) && lab[e] != -1) alive |= 1u << e;  // :67
     }
     if (!FRESH && alive == 0) return;  // nothing to do and nothing to write
-    if (VEC) decode_group(g, grp, vx);
+    if (VEC && !padded) decode_group(g, grp, vx);
 
     float z[4];
 #pragma unroll
@@ -736,8 +741,8 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
     const bool inside = j < g.ny && k0 < g.nz;
     const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
-    const bool vec = (g.nz & 3u) == 0;  // grid-uniform
-    const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nz + k0;
+    const bool vec = (g.nzp & 3u) == 0;  // grid-uniform (the pitch is a multiple of 64: always)
+    const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nzp + k0;
     int32_t *p = labels + elem;
     int32_t lab[4], was[4];
 #pragma unroll
@@ -750,6 +755,9 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         if (inside) {
             int4 q = *reinterpret_cast<const int4 *>(p);
             lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
         }
     } else {
 #pragma unroll
@@ -879,8 +887,8 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
     // only, has something to write there
     const unsigned long long untouched = fill.fresh ? __ballot(f == 6u) : 0ull;
     if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
-    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nz;
-    const bool vec = (g.nz & 3u) == 0;
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nzp;
+    const bool vec = (g.nzp & 3u) == 0;
     for (uint32_t bz = 0; bz < bricks_z; ++bz) {
         const bool isfull = (full >> bz) & 1ull, isunt = (untouched >> bz) & 1ull;
         if (!((culled >> bz) & 1ull) && !isfull && !isunt) continue;
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     const uint32_t per_plane = bricks_y * bricks_z;
     if (blockIdx.x >= nwalkers) {
         const uint32_t nfill = ctl->nfill[parity], nfillers = gridDim.x - nwalkers;
-        const bool vec = (g.nz & 3u) == 0;
+        const bool vec = (g.nzp & 3u) == 0;
         const int32_t kept = init == 0 ? 1 : init;
         // 64 entries per load (one per lane), handed out with v_readlane: one round trip per 64 bricks
         for (uint32_t base = (blockIdx.x - nwalkers) * 64u; base < nfill; base += nfillers * 64u) {
@@ -1035,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
                 const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
                 if (j >= g.ny || k0 >= g.nz) continue;
-                int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nz + k0;
+                int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nzp + k0;
                 const uint32_t nv4 = min(4u, g.nz - k0);
                 if (!isfull || FRESH) {
                     const int32_t val = isunt ? init : (isfull ? kept : -1);
@@ -1212,8 +1220,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             idx[p] = entry & 0x7fffffffu;
             zero[p] = (entry >> 31) != 0;  // label is still 0
             flipped[p] = false;
-            const uint32_t col = idx[p] / g.nz;
-            const uint32_t k = idx[p] - col * g.nz;
+            const uint32_t col = idx[p] / g.nzp;  // entries index the padded rows
+            const uint32_t k = idx[p] - col * g.nzp;
             const uint32_t il = col / g.ny;
             const uint32_t j = col - il * g.ny;
             x[p] = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
             // above over ALL views by a block that may not have written them yet: not this pass's voxels
             Vox4 vx;
             decode_group(g, grp, vx);
-            const uint32_t col = (uint32_t)(vx.elem / g.nz), il = col / g.ny, j = col - il * g.ny;
+            const uint32_t col = (uint32_t)(vx.elem / g.nzp), il = col / g.ny, j = col - il * g.ny;
             const uint32_t fl = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ];
             skip = fl == 5u || fl == 2u || fl == 6u;
         }
@@ -1615,8 +1623,8 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
     const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
     const bool inside = j < g.ny && k0 < g.nz;
     const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
-    const bool vec = (g.nz & 3u) == 0;
-    float *p = values + ((uint64_t)il * g.ny + j) * g.nz + k0;
+    const bool vec = (g.nzp & 3u) == 0;
+    float *p = values + ((uint64_t)il * g.ny + j) * g.nzp + k0;
     float val[4] = {init, init, init, init};
     if (!FRESH) {
         if (vec) {
@@ -1812,6 +1820,20 @@ __global__ __launch_bounds__(kBlock) void narrow_i8_kernel(const int32_t *__rest
     }
 }
 
+// The state without its row padding (rows of nz of nzp elements), as 4-byte elements or narrowed to int8:
+// one wavefront per row and pass, consecutive lanes on consecutive elements.
+template <typename OUT>
+__global__ __launch_bounds__(kBlock) void depitch_kernel(const uint32_t *__restrict__ src, OUT *__restrict__ dst,
+                                                         uint64_t rows, uint32_t nz, uint32_t nzp) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t row = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < rows;
+         row += (uint64_t)gridDim.x * (kBlock / 64)) {
+        const uint32_t *in = src + row * nzp;
+        OUT *out = dst + row * nz;
+        for (uint32_t k = lane; k < nz; k += 64u) out[k] = (OUT)in[k];  // int8: the low byte, as the narrowing kernel
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
                                                       uint32_t bits) {
     uint64_t idx = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -1905,6 +1927,10 @@ struct sc_engine {
     int device = 0;
     int mode = SC_MODE_CARVE;
     int64_t nx = 0, ny = 0, nz = 0, i0 = 0, istride = 1, planes = 0, n = 0;
+    int64_t nzp = 0;     // row pitch of the state in voxels (nz rounded up to a multiple of 64)
+    int64_t npitch = 0;  // planes * ny * nzp: elements of the state as it lies in memory
+    void *dense = nullptr;  // planes * ny * nz elements: the state without the row padding, made on demand
+                            // for read-backs and device consumers when nzp != nz
     float origin[3] = {0, 0, 0};
     float vs = 1.0f;
     float default_value = 0.0f;
@@ -2075,13 +2101,30 @@ GridDesc grid_desc(const sc_engine *e) {
     g.nz = (uint32_t)e->nz;
     g.i0 = (uint32_t)e->i0;
     g.istride = (uint32_t)e->istride;
-    g.pad_ = 0;
-    g.gpc = (uint32_t)((e->nz + 3) / 4);
+    g.nzp = (uint32_t)e->nzp;
+    g.gpc = (uint32_t)(e->nzp / 4);
     g.ngroups = (uint64_t)e->planes * (uint64_t)e->ny * g.gpc;
     return g;
 }
 
 int32_t init_bits_i32(const sc_engine *e) { return (int32_t)e->default_value; }
+
+// The state as planes * ny * nz contiguous elements on the device: the state itself when its rows are not
+// padded, else a copy without the padding (made on the engine's stream, valid until the state changes).
+int dense_state(sc_engine *e, void **ptr) {
+    if (e->nzp == e->nz) {
+        *ptr = e->state;
+        return SC_OK;
+    }
+    if (!e->dense) HIP_TRY(hipMalloc(&e->dense, (size_t)e->n * 4));
+    const uint64_t rows = (uint64_t)e->planes * (uint64_t)e->ny;
+    hipLaunchKernelGGL(depitch_kernel<uint32_t>, dim3((uint32_t)std::min<uint64_t>((rows + 3) / 4, 65536)), dim3(kBlock), 0,
+                       e->stream, static_cast<const uint32_t *>(e->state), static_cast<uint32_t *>(e->dense), rows,
+                       (uint32_t)e->nz, (uint32_t)e->nzp);
+    HIP_TRY(hipGetLastError());
+    *ptr = e->dense;
+    return SC_OK;
+}
 
 int materialize(sc_engine *e) {
     if (!e->fresh) return SC_OK;
@@ -2092,7 +2135,7 @@ int materialize(sc_engine *e) {
     } else {
         memcpy(&bits, &e->default_value, 4);
     }
-    uint64_t n = (uint64_t)e->n;
+    uint64_t n = (uint64_t)e->npitch;  // padding included
     uint64_t blocks = (n + (uint64_t)kBlock * 4 - 1) / ((uint64_t)kBlock * 4);
     LaunchTimer lt{e, SC_KERNEL_FILL};
     int rc = lt.begin();
@@ -2545,10 +2588,10 @@ FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
     p.ndense = (int)e->dense_views;
     p.nstage1 = (int)e->stage1_views;
     p.compact = e->compact && nv >= (size_t)kMinFusedViews && nv > (size_t)p.ndense &&
-                (uint64_t)e->n < 0x80000000ull;
+                (uint64_t)e->npitch < 0x80000000ull;
     p.bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY);
     p.bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
-    p.brick = (nv > 1 || e->view_brick) && e->brick && p.bzs <= 64 && (uint64_t)e->n < 0x80000000ull &&
+    p.brick = (nv > 1 || e->view_brick) && e->brick && p.bzs <= 64 && (uint64_t)e->npitch < 0x80000000ull &&
               (uint64_t)e->planes * p.bys * p.bzs < 0x40000000ull && has_occ;  // brick ids carry two flag bits in the fill list
     p.nbricks = p.brick ? (uint32_t)((uint64_t)e->planes * p.bys * p.bzs) : 0u;
     p.flag_views = (int)nv;  // every view of the batch may veto a brick, not only the dense stage's
@@ -2623,7 +2666,7 @@ int flush(sc_engine *e, size_t count = 0) {
     GridDesc g = grid_desc(e);
     uint64_t blocks = (g.ngroups + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
-    bool vec = (e->nz % 4) == 0;
+    bool vec = (e->nzp % 4) == 0;  // rows are whole 16-byte groups (the pitch is a multiple of 64): always
     dim3 grid((uint32_t)blocks), block(kBlock);
     const ViewDesc *vd = nullptr, *vpin = nullptr;
     if (nv > 1) {
@@ -2865,7 +2908,7 @@ int flush(sc_engine *e, size_t count = 0) {
         if (rc) return rc;
         // brick form: uint8 masks with uniformity flags on every view of the batch, a table, a grid it fits
         const uint32_t abys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), abzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
-        bool abrick = nv > 1 && e->avg_brick && (uint64_t)e->n < 0x80000000ull &&
+        bool abrick = nv > 1 && e->avg_brick && (uint64_t)e->npitch < 0x80000000ull &&
                       (uint64_t)e->planes * abys * abzs < 0x80000000ull;
         bool any_f32 = false;
         for (size_t q = 0; q < nv && abrick; ++q) {
@@ -3005,12 +3048,14 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
     e->mode = mode;
     e->nx = nx; e->ny = ny; e->nz = nz; e->i0 = i0; e->istride = istride; e->planes = planes;
     e->n = planes * ny * nz;
+    e->nzp = (nz + 63) / 64 * 64;
+    e->npitch = planes * ny * e->nzp;
     memcpy(e->origin, origin, sizeof e->origin);
     e->vs = vs;
     e->default_value = default_value;
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->n * 4);
+    if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->npitch * 4);
     if (he != hipSuccess) {
         int code = he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE;
         fail(code, "engine setup failed: %s", hipGetErrorString(he));
@@ -3093,6 +3138,7 @@ void sc_destroy(sc_engine *e) {
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->narrow) (void)hipFree(e->narrow);
+    if (e->dense) (void)hipFree(e->dense);
     if (e->verd) (void)hipFree(e->verd);
     if (e->verdf) (void)hipFree(e->verdf);
     if (e->dead) (void)hipFree(e->dead);
@@ -3431,7 +3477,10 @@ int sc_get_values(sc_engine *e, void *out) {
     if (rc) return rc;
     rc = materialize(e);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, e->state, (size_t)e->n * 4, hipMemcpyDeviceToHost, e->stream));
+    void *src = nullptr;
+    rc = dense_state(e, &src);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, src, (size_t)e->n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return SC_OK;
 }
@@ -3448,8 +3497,15 @@ int sc_get_values_i8(sc_engine *e, int8_t *out) {
     if (!e->narrow) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->narrow), (size_t)e->n));
     const uint64_t n = (uint64_t)e->n;
     const uint64_t blocks = (n + (uint64_t)kBlock * 16 - 1) / ((uint64_t)kBlock * 16);
-    hipLaunchKernelGGL(narrow_i8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
-                       static_cast<const int32_t *>(e->state), e->narrow, n);
+    if (e->nzp == e->nz) {
+        hipLaunchKernelGGL(narrow_i8_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream,
+                           static_cast<const int32_t *>(e->state), e->narrow, n);
+    } else {  // rows without their padding, narrowed on the way
+        const uint64_t rows = (uint64_t)e->planes * (uint64_t)e->ny;
+        hipLaunchKernelGGL(depitch_kernel<int8_t>, dim3((uint32_t)std::min<uint64_t>((rows + 3) / 4, 65536)), dim3(kBlock), 0,
+                           e->stream, static_cast<const uint32_t *>(e->state), e->narrow, rows, (uint32_t)e->nz,
+                           (uint32_t)e->nzp);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, e->narrow, (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -3462,8 +3518,7 @@ int sc_values_device_ptr(sc_engine *e, void **ptr) {
     if (rc) return rc;
     rc = materialize(e);
     if (rc) return rc;
-    *ptr = e->state;
-    return SC_OK;
+    return dense_state(e, ptr);  // planes * ny * nz elements, no row padding
 }
 
 int64_t sc_num_voxels(const sc_engine *e) { return e ? e->n : 0; }
@@ -3806,8 +3861,11 @@ int sc_group_get_values(sc_group *g, void *out) {
         int rc = use_device(e);
         if (rc) return rc;
         char *dst = static_cast<char *>(out) + (size_t)e->i0 * plane;
+        void *src = nullptr;
+        rc = dense_state(e, &src);  // without the row padding
+        if (rc) return rc;
         // the engine's planes are contiguous on the device and istride planes apart in the grid
-        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)e->istride * plane, e->state, plane, plane, (size_t)e->planes,
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)e->istride * plane, src, plane, plane, (size_t)e->planes,
                                  hipMemcpyDeviceToHost, e->stream));
     }
     for (auto *e : g->eng) {

@@ -1110,3 +1110,43 @@ def test_bricks_no_view_sees_keep_their_labels(gpu_device, kind, default_value):
     assert np.array_equal(got, want), (kind, default_value, "stored")
     got = hip_carve(shape, origin, vs, views, default_value=default_value)
     assert np.array_equal(got, want), (kind, default_value, "host masks")
+
+
+@pytest.mark.parametrize("shape", [(9, 21, 70), (5, 17, 1), (4, 16, 64), (6, 33, 129), (3, 40, 191)])
+def test_row_padding_never_shows(gpu_device, shape):
+    """The state's rows are padded to multiples of 64 voxels on the device; every way out of the engine
+    (int32 and int8 read-back, the dense device pointer, averaging volumes, a stored volume read twice)
+    hands over nx * ny * nz elements in the reference's order."""
+    _, origin, vs, views = scene(shape, 7, "plant")
+    want = oracle_c.carve(list(shape), origin, vs, views, nthreads=2)
+    for vpl in (0, 1, 3):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        got = e.get_values()
+        assert got.shape == tuple(shape) and np.array_equal(got, want), (shape, vpl)
+        got8 = e.get_values_i8()
+        assert got8.dtype == np.int8 and np.array_equal(got8, want), (shape, vpl)
+        dense = np.empty(shape, dtype=np.int32)
+        e.dev_download(dense, e.values_device_ptr())
+        assert np.array_equal(dense, want), (shape, vpl, "device pointer")
+        assert np.array_equal(e.get_values(), want)  # again, unchanged
+        e.close()
+    table = img_as_float32(np.arange(256, dtype=np.uint8))
+    wantf = oracle_c.average(list(shape), origin, vs, [(K, R, t, table[m]) for K, R, t, m in views])
+    for vpl in (0, 1):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE)
+        e.set_lut(table)
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8_LUT)
+        assert np.array_equal(e.get_values().view(np.uint32), wantf.view(np.uint32)), (shape, vpl, "average")
+        densef = np.empty(shape, dtype=np.float32)
+        e.dev_download(densef, e.values_device_ptr())
+        assert np.array_equal(densef.view(np.uint32), wantf.view(np.uint32))
+        e.close()
+    # before any view: default_value everywhere
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=7.0)
+    assert (e.get_values() == 7).all() and (e.get_values_i8() == 7).all()
+    e.close()
