@@ -27,10 +27,14 @@ def run(shape, origin, vs, views, steps=20):
 out = {}
 shapes = [(300, 300, 560), (304, 304, 576), (512, 512, 512), (500, 500, 500), (511, 513, 509)]
 if len(sys.argv) > 1:  # e.g. 500x500x500 literal
-    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:] if a != "literal"]
+    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:] if a not in ("literal", "dense")]
 if len(sys.argv) == 1 or "literal" in sys.argv[1:]:
     shape, origin, vs, views = scenes.literal_real_plant_scene(60, "plant")
     out["literal_301x301x561_60_views"] = run(shape, origin, vs, views)
+if len(sys.argv) == 1 or "dense" in sys.argv[1:]:
+    shape, origin, vs, views = scenes.make_scene(512, 72, "dense")
+    out["dense_512_72_views"] = run(shape, origin, vs, views)
+shapes = [s_ for s_ in shapes if s_]
 for shp in shapes:
     shape, origin, vs, views = scenes.make_scene(shp, 72, "plant")
     out["x".join(map(str, shp)) + "_72_views"] = run(shape, origin, vs, views)
