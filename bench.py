@@ -240,6 +240,32 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
                      "roofline_frac_hbm": bytes_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "fused_counts": {"live_bricks": live, "alive_after_dense_stage": s0,
                                       "alive_after_first_list_stage": s1n, "list_overflow": ovf}}
+    # the reference's own configuration (configs/test_geom_pipe_real.toml:27-36 -> 301 x 301 x 561 voxels,
+    # the 60 views of tests/testdata/real_plant): an unaligned grid, a third of it seen by no view
+    shape_l, origin_l, vs_l, views_l = scenes.literal_real_plant_scene(60, "plant")
+    lit = nat.Engine(shape_l, origin_l, vs_l, nat.SC_MODE_CARVE, device=eng.device)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views_l]))
+    ptr = lit.dev_alloc(stack.nbytes)
+    lit.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views_l]); R = np.stack([v[1] for v in views_l]); t = np.stack([v[2] for v in views_l])
+    Vl, Hl, Wl = stack.shape
+
+    def step_l():
+        lit.clear()
+        lit.process_views_device(K, R, t, ptr, Vl, Hl, Wl, nat.SC_MASK_U8)
+        lit.flush()
+
+    ms = host_timed(lit, torch, step_l, steps, warmup=2)
+    live, s0, s1n, ovf = lit.fused_counts()
+    nl = lit.num_voxels()
+    out["literal_301x301x561_60"] = {
+        "ms_per_step": ms, "value": nl * Vl / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
+        "roofline_frac_hbm": (4.0 * nl + float(Vl) * Wl * Hl) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "fused_counts": {"live_bricks": live, "alive_after_dense_stage": s0, "alive_after_first_list_stage": s1n,
+                         "list_overflow": ovf},
+        "note": "the reference's literal test configuration; 32 % of the grid is seen by no view"}
+    lit.dev_free(ptr)
+    lit.close()
     return out
 
 

@@ -249,6 +249,9 @@ int sc_span_end(sc_engine *e, double *ms);
  * empty (brick form, else 0), out[1] voxels alive after the dense stage, out[2] after the first
  * survivor stage, out[3] 1 if a survivor list overflowed (the dense resume kernel took over). */
 int sc_fused_counts(sc_engine *e, int64_t out[4]);
+/* ... the same four, then out[4]: candidate bricks (kept as they are by the views packed ahead) that a later
+ * view did not keep -- carved brick by brick by the resume kernel; out[5..7]: 0 (reserved). */
+int sc_fused_counts_ex(sc_engine *e, int64_t out[8]);
 
 /* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on
  * `count` pseudo-random operand triples (mode 0: raw bit patterns, 1: projection-like

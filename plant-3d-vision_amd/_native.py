@@ -61,6 +61,7 @@ _SIGNATURES = {
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_fused_counts": ("i", ["p", "p"]),
+    "sc_fused_counts_ex": ("i", ["p", "p"]),
     "sc_span_begin": ("i", ["p"]),
     "sc_span_end": ("i", ["p", "p"]),
     "sc_selftest_division": ("i", ["p", "q", "I", "i", "p", "p"]),
@@ -531,6 +532,13 @@ class Engine:
         out = np.zeros(4, dtype=np.int64)
         self._call("sc_fused_counts", addr(out))
         return tuple(int(x) for x in out)
+
+    def fused_counts_ex(self):
+        """``fused_counts()`` as a dict, plus ``late_bricks``."""
+        out = np.zeros(8, dtype=np.int64)
+        self._call("sc_fused_counts_ex", addr(out))
+        return {"live_bricks": int(out[0]), "alive_after_dense_stage": int(out[1]),
+                "alive_after_first_list_stage": int(out[2]), "list_overflow": int(out[3]), "late_bricks": int(out[4])}
 
     def selftest_division(self, count, seed=1, mode=1):
         """(mismatches, fast_pairs) of the shared-reciprocal division vs hipcc's IEEE division."""

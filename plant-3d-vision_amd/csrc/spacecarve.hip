@@ -731,11 +731,15 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     }
 }
 
-template <bool FRESH>
+// ORDERED: the views are views[order[0..nviews)] (a list in LDS: only the views that still have a say
+// about this brick, see the late bricks of carve_resume_kernel), and `seen` says that a view left out of
+// that list saw the whole brick over foreground: a label still 0 at the end becomes 1.
+template <bool FRESH, bool ORDERED = false>
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
-                                             uint32_t k0, uint32_t lb, uint32_t lane) {
+                                             uint32_t k0, uint32_t lb, uint32_t lane,
+                                             const uint16_t *order = nullptr, bool seen = false) {
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
     // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
@@ -782,8 +786,13 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     for (int vi = 0; vi < nviews; vi += 2) {
         if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
         const bool two = vi + 1 < nviews;      // wave-uniform
-        const ViewDesc da = views[vi];
-        const ViewDesc db = views[two ? vi + 1 : vi];
+        int ia = vi, ib = two ? vi + 1 : vi;
+        if (ORDERED) {
+            ia = __builtin_amdgcn_readfirstlane((int)order[ia]);
+            ib = __builtin_amdgcn_readfirstlane((int)order[ib]);
+        }
+        const ViewDesc da = views[ia];
+        const ViewDesc db = views[ib];
         const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
         const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
         const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
@@ -823,6 +832,11 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         }
     }
 
+    if (ORDERED && seen) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) lab[e] = 1;  // :81 by a view that was not worth projecting for
+    }
     if (vec) {
         bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
         if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
@@ -1308,6 +1322,7 @@ struct LateBricks {           // FULL candidates that turned out not to be (see 
     uint32_t bricks_y, bricks_z;
 };
 
+constexpr int kLateViews = 256;  // views of a batch the late bricks' view lists cover (more: every view is applied)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                               const ViewDesc *__restrict__ views,
@@ -1325,14 +1340,51 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
         const uint32_t nlate = ctl->nlate;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
         const uint32_t per_plane = lb.bricks_y * lb.bricks_z;
+        // A late brick was kept as it is by the views packed ahead: most views have no say about it (a
+        // brick inside a solid object lies over foreground in nearly all of them, one at the edge of the
+        // pictures outside nearly all).  Wavefront 0 asks every view at once, one view per lane, and the
+        // block projects the brick's voxels only for the views that are neither FULL nor OUTSIDE.
+        __shared__ uint16_t s_order[kLateViews];
+        __shared__ uint32_t s_count, s_seen;
+        const bool listed = lb.nall <= kLateViews;  // grid-uniform
         for (uint32_t t = blockIdx.x; t < nlate; t += gridDim.x) {
             const uint32_t id = lb.late[t];
             const uint32_t il = id / per_plane;
             const uint32_t rem = id - il * per_plane;
             const uint32_t by = rem / lb.bricks_z, bz = rem - by * lb.bricks_z;
             const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
-            if (lb.fresh) brick_voxels<true>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
-            else brick_voxels<false>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
+            if (listed) {
+                if (wave == 0) {
+                    const float bx = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+                    uint32_t count = 0;
+                    unsigned long long sawm = 0;
+                    for (int base = 0; base < lb.nall; base += 64) {
+                        const int vi = base + (int)lane;
+                        bool need = false, sees = false;
+                        if (vi < lb.nall) {
+                            const ViewDesc d = lb.allviews[vi];  // one descriptor per lane
+                            const uint32_t v = brick_verdict(d, g, bx, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
+                            need = !(v == 2u || v == 4u);  // undecided, or empty (carved voxel by voxel)
+                            sees = v == 2u;
+                        }
+                        const unsigned long long mn = __ballot(need);
+                        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                        if (need) s_order[count + (uint32_t)__popcll(mn & below)] = (uint16_t)vi;
+                        count += (uint32_t)__popcll(mn);
+                        sawm |= __ballot(sees);
+                    }
+                    if (lane == 0) { s_count = count; s_seen = sawm != 0 ? 1u : 0u; }
+                }
+                __syncthreads();
+                const int n = (int)s_count;
+                const bool seen = s_seen != 0u;
+                if (lb.fresh) brick_voxels<true, true>(labels, g, lb.allviews, n, lb.init, none, il, j, k0, id, lane, s_order, seen);
+                else brick_voxels<false, true>(labels, g, lb.allviews, n, lb.init, none, il, j, k0, id, lane, s_order, seen);
+                __syncthreads();  // the list is reused for the next brick
+            } else {
+                if (lb.fresh) brick_voxels<true>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
+                else brick_voxels<false>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
+            }
         }
     }
     if (!ctl->overflow) return;
@@ -3587,6 +3639,17 @@ int sc_span_end(sc_engine *e, double *ms) {
     e->event_pool.push_back(e->span_start);
     e->event_pool.push_back(stop);
     e->span_open = false;
+    return SC_OK;
+}
+
+int sc_fused_counts_ex(sc_engine *e, int64_t out[8]) {
+    if (!e || !out) return fail(SC_ERR_INVALID, "bad argument");
+    for (int q = 0; q < 8; ++q) out[q] = 0;
+    int rc = sc_fused_counts(e, out);
+    if (rc || !e->ctl) return rc;
+    ListCtl host;
+    HIP_TRY(hipMemcpy(&host, e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
+    out[4] = host.nlate;
     return SC_OK;
 }
 

@@ -19,10 +19,11 @@ def run(shape, origin, vs, views, steps=20):
     go(3); eng.synchronize()
     eng.span_begin(); go(steps); ms = eng.span_end() / steps
     live, s0, s1, ovf = eng.fused_counts()
+    late = eng.fused_counts_ex()["late_bricks"]
     eng.dev_free(ptr); eng.close()
     n = int(np.prod(shape))
     return {"shape": list(shape), "views": V, "ms_per_batch": ms, "Mvoxel_views_per_s": n * V / ms / 1e3,
-            "label_write_GBps": 4.0 * n / ms / 1e6, "live_bricks": live, "survivors": [s0, s1], "overflow": ovf}
+            "label_write_GBps": 4.0 * n / ms / 1e6, "live_bricks": live, "late_bricks": late, "survivors": [s0, s1], "overflow": ovf}
 
 out = {}
 shapes = [(300, 300, 560), (304, 304, 576), (512, 512, 512), (500, 500, 500), (511, 513, 509)]
