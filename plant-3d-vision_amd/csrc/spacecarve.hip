@@ -589,6 +589,7 @@ __device__ __forceinline__ uint32_t brick_flat_f32(const ViewDesc &d, const Grid
                                                    uint32_t &bits) {
     const Footprint fpr = brick_footprint(d, g, x, j0, k0);
     bits = 0u;
+    if (fpr.outside) return 4u;  // the view adds nothing to the brick
     if (!fpr.ok) return 0u;
     const int otx = (d.W + 31) >> 5, oty = (d.H + 31) >> 5;
     const uint32_t *val = reinterpret_cast<const uint32_t *>(d.occ + (((size_t)otx * oty + 3) & ~(size_t)3));
@@ -1630,7 +1631,8 @@ __global__ __launch_bounds__(kBlock) void uniform_f32_kernel(const float *__rest
 // nothing but 0, every voxel of the brick is in-image and adds table[0] for that view; over tiles of
 // nothing but 255, table[255]: the same float32 addition the reference performs
 // (backprojection.c:54), in the same view order, without projecting anything.  Only views whose
-// footprint is mixed are projected voxel by voxel.
+// footprint is mixed are projected voxel by voxel; a view that does not see the brick at all (verdict 4,
+// OUTSIDE) is skipped.
 __global__ __launch_bounds__(kBlock) void avg_flags_kernel(GridDesc g, const ViewDesc *__restrict__ views,
                                                            int nviews, uint32_t bricks_y, uint32_t bricks_z,
                                                            uint32_t nbricks, uint8_t *__restrict__ verd,
@@ -1705,6 +1707,7 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
         const uint32_t minef = (myverdf != nullptr && (int)lane < nv) ? myverdf[v0 + (int)lane] : 0u;
         for (int q = 0; q < nv; ++q) {
             const uint32_t c = __builtin_amdgcn_readlane(mine, q);  // wave-uniform (brick-uniform)
+            if (c == 4u) continue;  // OUTSIDE: no voxel of the brick is in the picture, the view adds nothing (:50-52)
             if (c != 0u) {
                 const float add = c == 1u ? add0 : (c == 2u ? add255 : __uint_as_float(__builtin_amdgcn_readlane(minef, q)));
 #pragma unroll

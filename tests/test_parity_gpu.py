@@ -9,7 +9,7 @@ import pytest
 
 from oracle import oracle_c
 from plant3dvision_amd import _native as nat
-from plant3dvision_amd.cl import EPS, Backprojection, img_as_float32
+from plant3dvision_amd.cl import EPS, Backprojection, averaging_table, img_as_float32
 from plant3dvision_amd.tasks import cl as tasks_cl
 from tests.helpers import files_from_views, histogram3, scene, sha256
 
@@ -1150,3 +1150,33 @@ def test_row_padding_never_shows(gpu_device, shape):
     e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=7.0)
     assert (e.get_values() == 7).all() and (e.get_values_i8() == 7).all()
     e.close()
+
+
+@pytest.mark.parametrize("form", ["u8", "f32"])
+@pytest.mark.parametrize("log", [False, True])
+def test_average_of_bricks_no_view_sees(gpu_device, form, log):
+    """Averaging on a grid much wider than the pictures: a view that does not see a brick at all adds
+    nothing to it -- not even +0.0 (a default of -0.0 keeps its sign where no view reaches)."""
+    shape = (6, 96, 384)
+    kw = dict(width=96, height=64, fx=260.0, fy=260.0, cx=48.0, cy=32.0, radius_factor=1.1)
+    _, origin, vs, views = scene(shape, 9, "dense", **kw)
+    table = averaging_table(log)
+    rng = np.random.default_rng(8)
+    for default_value in (0.0, -0.0, 2.5):
+        if form == "u8":
+            masks = [m if q % 2 else rng.integers(0, 256, m.shape, dtype=np.uint8) for q, (_, _, _, m) in enumerate(views)]
+            fviews = [(K, R, t, table[m]) for (K, R, t, _), m in zip(views, masks)]
+        else:
+            masks = [table[m] if q % 2 else rng.random(m.shape, dtype=np.float32) for q, (_, _, _, m) in enumerate(views)]
+            fviews = [(K, R, t, m) for (K, R, t, _), m in zip(views, masks)]
+        want = oracle_c.average(list(shape), origin, vs, fviews, default_value)
+        assert (want.view(np.uint32) == np.float32(default_value).view(np.uint32)).mean() > 0.3  # unseen voxels
+        for vpl in (0, 1, 4):
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE, default_value=default_value)
+            e.set_lut(table)
+            e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+            for (K, R, t, _), m in zip(views, masks):
+                e.process_view(K, R, t, m, nat.SC_MASK_U8_LUT if form == "u8" else nat.SC_MASK_F32)
+            got = e.get_values()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (form, log, default_value, vpl)
+            e.close()
