@@ -2721,7 +2721,8 @@ int flush(sc_engine *e, size_t count = 0) {
     GridDesc g = grid_desc(e);
     uint64_t blocks = (g.ngroups + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
-    bool vec = (e->nzp % 4) == 0;  // rows are whole 16-byte groups (the pitch is a multiple of 64): always
+    // (rows are whole 16-byte groups -- the pitch is a multiple of 64 voxels -- so every kernel takes its
+    // vector form, VEC = true; the element-wise forms remain in the templates for a layout without padding)
     dim3 grid((uint32_t)blocks), block(kBlock);
     const ViewDesc *vd = nullptr, *vpin = nullptr;
     if (nv > 1) {
@@ -2815,14 +2816,14 @@ int flush(sc_engine *e, size_t count = 0) {
         }
         if (nv == 1 && !brick) {
             // kStreamGroups groups per lane when the state is streamed through (see kernel)
-            uint32_t per_block = (!e->fresh && vec) ? kBlock * kStreamGroups : kBlock;
+            uint32_t per_block = !e->fresh ? kBlock * kStreamGroups : kBlock;
             dim3 grid1((uint32_t)((g.ngroups + per_block - 1) / per_block));
 #define LAUNCH_CARVE1(F, V) \
     hipLaunchKernelGGL((carve_kernel_1<F, V>), grid1, block, 0, e->stream, st, g, one, init)
             if (e->fresh) {
-                if (vec) LAUNCH_CARVE1(true, true); else LAUNCH_CARVE1(true, false);
+                LAUNCH_CARVE1(true, true);
             } else {
-                if (vec) LAUNCH_CARVE1(false, true); else LAUNCH_CARVE1(false, false);
+                LAUNCH_CARVE1(false, true);
             }
 #undef LAUNCH_CARVE1
         } else {
@@ -2881,9 +2882,9 @@ int flush(sc_engine *e, size_t count = 0) {
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
                        init, ap)
                 if (e->fresh) {
-                    if (vec) LAUNCH_CARVE(true, true); else LAUNCH_CARVE(true, false);
+                    LAUNCH_CARVE(true, true);
                 } else {
-                    if (vec) LAUNCH_CARVE(false, true); else LAUNCH_CARVE(false, false);
+                    LAUNCH_CARVE(false, true);
                 }
 #undef LAUNCH_CARVE
             }
@@ -2947,12 +2948,8 @@ int flush(sc_engine *e, size_t count = 0) {
             // the resume kernel is also what zeroes the next batch's counters
             e->ctl_clean[e->ctl_idx ^ 1] = true;
             const LateBricks late{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
-            if (vec)
-                hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
-            else
-                hipLaunchKernelGGL(carve_resume_kernel<false>, dim3(list_blocks), block, 0, e->stream,
-                                   st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
+            hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
+                               st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
             HIP_TRY(hipGetLastError());
             rc = lt2.end();
             if (rc) return rc;
@@ -3030,9 +3027,9 @@ int flush(sc_engine *e, size_t count = 0) {
                                (int)nv, e->default_value, e->lut_dev);                           \
     } while (0)
         if (e->fresh) {
-            if (vec) LAUNCH_AVG(true, true); else LAUNCH_AVG(true, false);
+            LAUNCH_AVG(true, true);
         } else {
-            if (vec) LAUNCH_AVG(false, true); else LAUNCH_AVG(false, false);
+            LAUNCH_AVG(false, true);
         }
 #undef LAUNCH_AVG
         HIP_TRY(hipGetLastError());
