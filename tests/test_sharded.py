@@ -158,7 +158,7 @@ def _gpu_worker(rank, world, port, shape, partition, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("partition,shape", [("cyclic", (37, 48, 64)), ("slab", (36, 32, 128))])
+@pytest.mark.parametrize("partition,shape", [("cyclic", (37, 48, 64)), ("slab", (36, 32, 128)), ("cyclic", (21, 30, 75))])
 def test_two_ranks_over_hip_engines_sharing_the_gpu(gpu_device, partition, shape):
     """world_size 2 with the HIP engine behind both ranks (one GPU, gloo as the transport): the
     device branches of all_gather / all_reduce / gather_to_host that RCCL would run on 8 GPUs."""
@@ -184,13 +184,14 @@ def test_two_ranks_over_hip_engines_sharing_the_gpu(gpu_device, partition, shape
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nz", [128, 70])
 @pytest.mark.parametrize("partition,ndev", [("cyclic", 3), ("slab", 2), ("cyclic", 1)])
-def test_several_engines_from_one_process(gpu_device, partition, ndev):
+def test_several_engines_from_one_process(gpu_device, partition, ndev, nz):
     """sc_create_sharded: one engine per listed device (here the one GPU, several times), x-planes dealt
     as the ranks of the multi-process path get them, the grid read back whole in global order."""
     from plant3dvision_amd import _native as nat
     from plant3dvision_amd.cl import Backprojection, img_as_float32
-    shape, origin, vs, views = scene((37, 48, 128), 9, "plant")
+    shape, origin, vs, views = scene((37, 48, nz), 9, "plant")  # nz = 70: padded rows on the device
     want = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
     g = nat.EngineGroup(shape, origin, vs, nat.SC_MODE_CARVE, [0] * ndev, partition=partition)
     for vpl in (0, 1):
