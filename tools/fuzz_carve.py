@@ -26,7 +26,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     bad = 0
-    certified_views = uncertified_views = 0
+    certified_views = uncertified_views = averaged = 0
     for c in range(cases):
         shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
         kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
@@ -70,11 +70,47 @@ def main():
                 print(f"MISMATCH case {c} round {rnd}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts} "
                       f"device {device_masks}: {int((got != want).sum())} voxels differ")
         e.dev_free(ptr); e.close()
+        # the average kernel on the same rig (every third case): uint8 masks through the table or float32
+        # masks, binary or grey, fused / per view, brick and tile forms on or off -- bitwise against the oracle
+        if c % 3 == 0 and int(np.prod(sh)) * nviews < 4e7:
+            from plant3dvision_amd.cl import averaging_table
+            log = bool(rng.random() < 0.5)
+            table = averaging_table(log)
+            form = str(rng.choice(["u8", "f32"]))
+            grey = rng.random() < 0.5
+            adv = float(rng.choice([0.0, 0.0, -0.0, 1.5]))
+            ms = []
+            for _, _, _, m in views:
+                if form == "u8":
+                    ms.append(rng.integers(0, 256, m.shape, dtype=np.uint8) if grey else m)
+                else:
+                    ms.append(rng.random(m.shape, dtype=np.float32) if grey else table[m])
+            fviews = [(Kq, Rq, tq, (table[m] if form == "u8" else m)) for (Kq, Rq, tq, _), m in zip(views, ms)]
+            wantf = oracle_c.average(sh, origin, vs, fviews, adv, nthreads=4)
+            aopts = {"SC_OPT_VIEWS_PER_LAUNCH": int(rng.choice([0, 0, 1, 4])), "SC_OPT_AVG_BRICK": int(rng.choice([0, 1, 1])),
+                     "SC_OPT_AVG_TILE_F32": int(rng.choice([0, 1, 1]))}
+            print(f"   average: form {form} grey {grey} log {log} default {adv} opts {aopts}", flush=True)
+            ea = nat.Engine(sh, origin, vs, nat.SC_MODE_AVERAGE, default_value=adv)
+            ea.set_lut(table)
+            for k, v in aopts.items():
+                ea.set_option(getattr(nat, k), v)
+            for rnd in range(2):
+                if rnd:
+                    ea.clear()
+                for (Kq, Rq, tq, _), m in zip(views, ms):
+                    ea.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8_LUT if form == "u8" else nat.SC_MASK_F32)
+                gotf = ea.get_values()
+                if not np.array_equal(gotf.view(np.uint32), wantf.view(np.uint32)):
+                    ok = False
+                    print(f"MISMATCH (average) case {c} round {rnd}: {int((gotf.view(np.uint32) != wantf.view(np.uint32)).sum())} voxels differ")
+            ea.close()
+            averaged += 1
         bad += 0 if ok else 1
-    print(f"{cases} cases, {bad} with mismatches; {certified_views} certified views, {uncertified_views} not")
+    print(f"{cases} cases ({averaged} with the average kernel too), {bad} with mismatches; {certified_views} certified views, {uncertified_views} not")
     if len(sys.argv) > 3:
         import json
         json.dump({"tool": "tools/fuzz_carve.py", "cases": cases, "seed": int(sys.argv[2]), "cases_with_mismatches": bad,
+                   "cases_with_the_average_kernel_too": averaged,
                    "views_on_the_certified_projection_path": certified_views, "views_on_the_general_path": uncertified_views,
                    "knobs": sorted(KNOBS), "scenes": ["plant", "noise", "solid", "empty", "dense"],
                    "checked": "HIP carve (host masks or device batch, fresh volume and a second batch on the stored one) "
