@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--views", type=int, default=72)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--workers", type=int, default=0, help="decode threads of the default run (0: the class's own choice)")
     a = ap.parse_args()
     from PIL import Image
     from plant3dvision_amd import scenes
@@ -70,7 +71,7 @@ def main():
     pil_files = [PilFile(f.id, f.path, f._md) for f in files]
     for name, cls, kw in (("serial", SerialBackprojection, dict(decode_workers=1, views_per_launch=1)),
                           ("pil", Backprojection, dict()),
-                          ("default", Backprojection, dict())):
+                          ("default", Backprojection, dict(decode_workers=a.workers) if a.workers else dict())):
         best, runs = None, []
         for _ in range(a.reps):
             bp = cls(shape, origin, vs, **kw)
