@@ -304,6 +304,9 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
                const double gauss_w[5], int device, double **points_out, double **normals_out,
                int64_t *count);
 const char *sc_vol2pcd_last_error(void);
+/* sc_vol2pcd keeps its device work buffers (49 bytes per voxel of the largest volume seen, per device) between
+ * calls; this gives them back. */
+void sc_vol2pcd_release(void);
 void sc_free_host(void *p);
 
 /*
