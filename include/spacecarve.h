@@ -115,6 +115,17 @@ extern "C" {
 #define SC_OPT_RESERVE_EVENTS 31    /* with SC_OPT_TIME_KERNELS: create n HIP events now (0..65536) so that the timed
                                        launches that follow find them in the engine's pool instead of creating them */
 #define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
+#define SC_OPT_BULK_MIN 32        /* a wavefront's share of a live brick (a UNIT: 4 columns x 64 voxels) with at least this
+                                     many voxels alive after the dense views is asked about as a whole: every remaining
+                                     view at once, one view per lane, over 8x8-pixel cells of the masks; only the
+                                     undecided views project its voxels (128; 0 = never)                          */
+#define SC_OPT_ITEM_BIAS 33       /* sixteenths (12): a unit's undecided (half, 8 views) pairs become work items of the
+                                     final stage when they number at most this share of what its voxels would cost in
+                                     the survivor lists; otherwise the voxels take the lists                      */
+#define SC_OPT_UNIT_BLOCKS 34     /* blocks of 8 wavefronts giving the units their verdicts (512)                  */
+#define SC_OPT_BULK_ADAPT 35      /* 1 (default): the engine looks at what the units' verdicts of its last batches spared
+                                     the survivor stages and leaves the bulk list out for 64 batches when that was less
+                                     than they cost (a thin plant); 0: always on                                   */
 
 /* kernel ids for sc_kernel_stats */
 #define SC_KERNEL_CARVE 0
@@ -250,7 +261,9 @@ int sc_span_end(sc_engine *e, double *ms);
  * survivor stage, out[3] 1 if a survivor list overflowed (the dense resume kernel took over). */
 int sc_fused_counts(sc_engine *e, int64_t out[4]);
 /* ... the same four, then out[4]: candidate bricks (kept as they are by the views packed ahead) that a later
- * view did not keep -- carved brick by brick by the resume kernel; out[5..7]: 0 (reserved). */
+ * view did not keep -- carved brick by brick by the resume kernel; out[5]: units on the bulk list
+ * (SC_OPT_BULK_MIN); out[6]: their work items; out[7]: batches the engine will still run without the bulk
+ * list (SC_OPT_BULK_ADAPT). */
 int sc_fused_counts_ex(sc_engine *e, int64_t out[8]);
 
 /* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on

@@ -16,6 +16,11 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libspacecarve.so")
+# A/B measurements only (tools/, bench.py --opt runs): another build of the same library, e.g. the previous
+# round's; entry points it lacks are simply not bound
+_ALT_LIB = os.environ.get("SPACECARVE_LIB", "")
+if _ALT_LIB:
+    LIB_PATH = os.path.abspath(_ALT_LIB)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "spacecarve.h")
 
 # constants of include/spacecarve.h
@@ -34,6 +39,7 @@ SC_OPT_FULL_BRICKS, SC_OPT_AVG_BRICK = 19, 20
 SC_OPT_STAGE1_STORE_SHARE, SC_OPT_STAGE1_LIST_BLOCKS = 17, 21
 SC_OPT_PACK_RIDE, SC_OPT_BRICK_WALKERS, SC_OPT_FILL_BLOCKS, SC_OPT_FINAL_VOXELS = 22, 23, 25, 24
 SC_OPT_VIEW_BRICK, SC_OPT_AVG_TILE_F32, SC_OPT_STAGE1_VOXELS, SC_OPT_RESERVE_EVENTS = 26, 29, 30, 31
+SC_OPT_BULK_MIN, SC_OPT_ITEM_BIAS, SC_OPT_UNIT_BLOCKS, SC_OPT_BULK_ADAPT = 32, 33, 34, 35
 
 # name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
 _SIGNATURES = {
@@ -126,7 +132,12 @@ class _CtypesBackend:
         self.lib = ctypes.CDLL(path)
         self.fn = {}
         for name, (res, args) in _SIGNATURES.items():
-            f = getattr(self.lib, name)
+            try:
+                f = getattr(self.lib, name)
+            except AttributeError:
+                if _ALT_LIB:
+                    continue
+                raise
             f.restype = _CT[res]
             f.argtypes = [_CT[a] for a in args]
             self.fn[name] = f
@@ -535,11 +546,12 @@ class Engine:
         return tuple(int(x) for x in out)
 
     def fused_counts_ex(self):
-        """``fused_counts()`` as a dict, plus ``late_bricks``."""
+        """``fused_counts()`` as a dict, plus ``late_bricks`` and ``bulk_units``."""
         out = np.zeros(8, dtype=np.int64)
         self._call("sc_fused_counts_ex", addr(out))
         return {"live_bricks": int(out[0]), "alive_after_dense_stage": int(out[1]),
-                "alive_after_first_list_stage": int(out[2]), "list_overflow": int(out[3]), "late_bricks": int(out[4])}
+                "alive_after_first_list_stage": int(out[2]), "list_overflow": int(out[3]), "late_bricks": int(out[4]),
+                "bulk_units": int(out[5]), "unit_items": int(out[6]), "bulk_hold": int(out[7])}
 
     def selftest_division(self, count, seed=1, mode=1):
         """(mismatches, fast_pairs) of the shared-reciprocal division vs hipcc's IEEE division."""

@@ -53,7 +53,7 @@ namespace {
 // device side
 // ------------------------------------------------------------------------------------------
 
-struct ViewDesc {   // 112 bytes, read with scalar loads (the view index is wave-uniform)
+struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave-uniform)
     float K[4];     // fx fy cx cy
     float R[9];     // row-major
     float t[3];
@@ -66,8 +66,12 @@ struct ViewDesc {   // 112 bytes, read with scalar loads (the view index is wave
     int32_t safe;        // certify_view(): every voxel centre of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30
                          // under this pose, and the intrinsics are finite and below 2^30 (see project())
     int32_t pad2;
+    const uint32_t *cmask;  // carve, 16-byte pack form: per 32x32 tile the 4x4 map of its 8x8-pixel CELLS -- bits 0..15
+                            // "cell holds some foreground", bits 16..31 "cell holds some background" (cell (cx, cy) of
+                            // the tile at bit cy * 4 + cx; padding counts as background); null: no cell level
+    uint64_t reserved;
 };
-static_assert(sizeof(ViewDesc) == 112, "ViewDesc layout");
+static_assert(sizeof(ViewDesc) == 128, "ViewDesc layout");
 
 struct GridDesc {
     float ox, oy, oz, vs;
@@ -95,14 +99,16 @@ struct alignas(128) ListCounter {
     uint32_t pad[31];
 };
 struct ListCtl {
-    ListCounter count[3][kSub];  // entries appended per sub-list, one set per list stage
+    ListCounter count[5][kSub];  // entries appended per sub-list, one set per list stage; set 3: bulk units, set 4:
+                                 // their work items
     uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
     uint32_t nlive[2];           // brick form: bricks no view found empty (entries of the live list); the flags
                                  // kernel of launch q counts in word q & 1 and zeroes the other one, so launches
                                  // that keep the same block (fewer than 6 views: no survivor stages) need no memset
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
     uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
-    uint32_t pad[26];
+    uint32_t ncand;              // FULL candidates the flags kernel left open (the confirm kernel has work)
+    uint32_t pad[25];
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
@@ -257,6 +263,12 @@ struct Append {
     ListCtl *ctl;
     uint32_t subcap;  // entries per sub-list
     uint32_t sub;     // sub-list of this block
+    // brick form: a wavefront's share of a brick (16 columns x 16 voxels, a UNIT) with at least `bulk_min`
+    // voxels alive after the dense views goes on the bulk list as a whole instead of voxel by voxel
+    // (unit_verdicts: the views are asked about the unit, one view per lane, before any projects its voxels)
+    uint32_t *bulk;   // nullptr: no such list
+    uint32_t bulkcap; // units per sub-list
+    uint32_t bulk_min;
 };
 
 // carve (backprojection.c:57-84) of one 4-voxel group over views[0..nviews), state in
@@ -418,13 +430,14 @@ struct PackJob {
     uint32_t flip;      // 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
     int32_t use_order;  // 0: slot s takes raw view s
     uint8_t *occ;
+    uint32_t *cmask;    // per tile: the 4x4 map of its 8x8-pixel cells, [slot][tiles_y][tiles_x] (see ViewDesc)
     int32_t slot0, nslots;
     uint16_t order[kPackOrderMax];
 };
 
 template <int ROWS>  // tile rows per block: that many 16-byte loads in flight per lane
 __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
-    __shared__ uint32_t occ_s[ROWS * 4], hole_s[ROWS * 4];
+    __shared__ uint32_t cm_s[ROWS * 4];  // per tile of the block: cells with some foreground | cells with some background << 16
     const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
     const uint32_t flip = pj.flip;
     const int lane = threadIdx.x & 63;
@@ -438,9 +451,10 @@ __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
     slot += pj.slot0;
     const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
     const uint8_t *raw = pj.raw + view * pj.view_stride;
-    if (threadIdx.x < ROWS * 4) occ_s[threadIdx.x] = hole_s[threadIdx.x] = 0;
-    int row = (int)(threadIdx.x >> 6) * 8 + (lane >> 3);  // row inside the tile
-    int c = lane & 7;                                      // 16-pixel chunk inside the panel
+    if (threadIdx.x < ROWS * 4) cm_s[threadIdx.x] = 0;
+    const int wave = (int)(threadIdx.x >> 6);
+    int row = wave * 8 + (lane >> 3);  // row inside the tile
+    int c = lane & 7;                  // 16-pixel chunk inside the panel
     int u0 = bx * 128 + c * 16;
     int tx = bx * 4 + (c >> 1);
     uint4 q[ROWS];
@@ -459,10 +473,19 @@ __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
                         (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
         uint32_t other = __shfl_xor(half, 1);
         uint32_t word = half | (other << 16);
-        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y) {
+        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
             pj.out[(int64_t)slot * pj.out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
-            if (word) occ_s[k * 4 + (c >> 1)] = 1;  // racing stores of the same value
-            if (~word) hole_s[k * 4 + (c >> 1)] = 1;  // some background (padding counts as such)
+        // 8x8-pixel cells: this wavefront holds rows 8w .. 8w + 7 of the tile (cell row w), lane 8r + c the
+        // pixels 16c .. 16c + 15 of row r -- two cells' worth.  Four ballots; bit c + 8r of each belongs to
+        // lane 8r + c, so lane c < 8 reads off its two cells over the eight rows.
+        const unsigned long long any_a = __ballot((half & 0xffu) != 0u), any_b = __ballot((half >> 8) != 0u);
+        const unsigned long long all_a = __ballot((half & 0xffu) == 0xffu), all_b = __ballot((half >> 8) == 0xffu);
+        if (lane < 8) {
+            constexpr unsigned long long M = 0x0101010101010101ull;
+            const uint32_t fa = ((any_a >> c) & M) != 0 ? 1u : 0u, fb = ((any_b >> c) & M) != 0 ? 1u : 0u;
+            const uint32_t ha = ((all_a >> c) & M) != M ? 1u : 0u, hb = ((all_b >> c) & M) != M ? 1u : 0u;  // padding: background
+            const int bit = wave * 4 + (c & 1) * 2;  // cell (2 (c & 1), w) of tile c >> 1
+            atomicOr(&cm_s[k * 4 + (c >> 1)], ((fa | (fb << 1)) << bit) | ((ha | (hb << 1)) << (16 + bit)));
         }
     }
     __syncthreads();
@@ -470,9 +493,12 @@ __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
     // written here, nothing for the host to clear
     if (threadIdx.x < ROWS * 4) {
         int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
-        if (ty < tiles_y && txo < tiles_x)
-            pj.occ[(int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo] =
-                (occ_s[threadIdx.x] ? 1 : 0) | (hole_s[threadIdx.x] ? 0 : 2);
+        if (ty < tiles_y && txo < tiles_x) {
+            const uint32_t cm = cm_s[threadIdx.x];
+            const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo;
+            pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+            if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+        }
     }
 }
 
@@ -499,22 +525,25 @@ constexpr int kBrickY = 16, kBrickZ = 64;
 // every corner in front of the camera its image is the convex hull of the images of its four
 // corners, and |R[..] * coordinate| terms are largest at a corner, so bounds taken over the four
 // corners hold for every voxel of the brick.
-struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == false: no verdict from the tiles
-    int tx0, tx1, ty0, ty1;
-    bool ok;
-    bool outside;  // every voxel of the brick is behind the camera or projects out of the picture: the view
-                   // does nothing to it (backprojection.c:13,23-31)
+// The image of a RECTANGLE of voxels of one x-plane (columns j0..j1, voxels k0..k1): a box in pixel
+// coordinates that contains the pixel every voxel of the rectangle is projected to by the reference
+// arithmetic, or the knowledge that no voxel of it is touched by the view at all.
+struct PixelBox {
+    float umin, umax, vmin, vmax;  // widened by the bound of DESIGN.md 4b
+    bool inside;   // every voxel is in front of the camera and lands inside the picture, on a pixel of the box
+    bool outside;  // every voxel is behind the camera or projects out of the picture: the view does nothing to
+                   // it (backprojection.c:13,23-31)
 };
 
-__device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0) {
-    Footprint fpr{0, 0, 0, 0, false, false};
+__device__ __forceinline__ PixelBox rect_box(const ViewDesc &d, const GridDesc &g, float x, int j0, int j1, int k0, int k1) {
+    PixelBox bx{0.0f, 0.0f, 0.0f, 0.0f, false, false};
     float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
     float pzmin = INFINITY, pzmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float y = g.oy + (float)(j0 + ((c >> 1) ? kBrickY - 1 : 0)) * g.vs;  // backprojection.c:72
-        float z = g.oz + (float)(k0 + ((c & 1) ? kBrickZ - 1 : 0)) * g.vs;   // :73
+        float y = g.oy + (float)((c >> 1) ? j1 : j0) * g.vs;  // backprojection.c:72
+        float z = g.oz + (float)((c & 1) ? k1 : k0) * g.vs;   // :73
         float rzx = d.R[6] * x, rzy = d.R[7] * y, rzz = d.R[8] * z;
         float rxx = d.R[0] * x, rxy = d.R[1] * y, rxz = d.R[2] * z;
         float ryx = d.R[3] * x, ryy = d.R[4] * y, ryz = d.R[5] * z;
@@ -538,10 +567,10 @@ __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const Gr
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
     }
-    if (nan) return fpr;
+    if (nan) return bx;
     // depth is affine over the rectangle and its rounding error is below ez: with every corner below
     // -4 ez every voxel has p_z < 0 and is rejected (:13)
-    if (pzmax < -4.0f * ez) { fpr.outside = true; return fpr; }
+    if (pzmax < -4.0f * ez) { bx.outside = true; return bx; }
     bool front = pzmin > 4.0f * ez;  // depth is affine over the rectangle: all voxels in front
     // pixel-space slack: 2 px + propagated dot-product error + 8 ulp of the largest magnitude in
     // q * f + c (quotient estimate above, the voxel kernels' own division, product and sum
@@ -553,15 +582,92 @@ __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const Gr
     float mv = 2.0f + fabsf(d.K[1]) * (ey + qym * ez) * inv +
                (fabsf(d.K[1]) * qym + fabsf(d.K[3]) + fmaxf(fabsf(vmin), fabsf(vmax))) * 0x1p-20f;
     umin -= mu; umax += mu; vmin -= mv; vmax += mv;
-    // a NaN anywhere makes a comparison false -> no culling
-    bool inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
+    // a NaN anywhere makes a comparison false -> no verdict
+    bx.inside = front & (umin >= 0.0f) & (umax <= d.Wf - 1.0f) & (vmin >= 0.0f) & (vmax <= d.Hf - 1.0f);
     // the widened box holds every voxel's uf, vf: all of it at or left of -1, at or right of W, above or
     // below the picture means (int)uf is outside [0, W - 1] (or (int)vf outside [0, H - 1]) for all of them
-    fpr.outside = front & ((umax <= -1.0f) | (umin >= d.Wf) | (vmax <= -1.0f) | (vmin >= d.Hf));
-    if (!inside) return fpr;
-    fpr.tx0 = (int)umin >> 5; fpr.tx1 = (int)umax >> 5; fpr.ty0 = (int)vmin >> 5; fpr.ty1 = (int)vmax >> 5;
+    bx.outside = front & ((umax <= -1.0f) | (umin >= d.Wf) | (vmax <= -1.0f) | (vmin >= d.Hf));
+    bx.umin = umin; bx.umax = umax; bx.vmin = vmin; bx.vmax = vmax;
+    return bx;
+}
+
+struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == false: no verdict from the tiles
+    int tx0, tx1, ty0, ty1;
+    bool ok;
+    bool outside;  // see PixelBox
+};
+
+__device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0) {
+    Footprint fpr{0, 0, 0, 0, false, false};
+    const PixelBox bx = rect_box(d, g, x, j0, j0 + kBrickY - 1, k0, k0 + kBrickZ - 1);
+    fpr.outside = bx.outside;
+    if (!bx.inside) return fpr;
+    fpr.tx0 = (int)bx.umin >> 5; fpr.tx1 = (int)bx.umax >> 5; fpr.ty0 = (int)bx.vmin >> 5; fpr.ty1 = (int)bx.vmax >> 5;
     fpr.ok = (fpr.tx1 - fpr.tx0 + 1) * (fpr.ty1 - fpr.ty0 + 1) <= 64;
     return fpr;
+}
+
+// Verdict of a view about a rectangle of voxels at the CELL level (8x8 pixels, ViewDesc::cmask): every voxel
+// of the rectangle lands in-image on a pixel of the box, so when no cell under the box holds foreground the
+// view carves them all (EMPTY, 1: backprojection.c:79), when none holds background it keeps them all (FULL,
+// 2: :81); 4 OUTSIDE (rect_box); else 0.  Up to 16 32x32 tiles are looked at (one word each).
+constexpr int kCellShift = 3;  // 8x8-pixel cells
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {  // bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+template <int NX, int NY>  // the cells of the box among the tiles of an NX x NY window: foreground / background seen
+__device__ __forceinline__ void window_cells(const ViewDesc &d, int cx0, int cx1, int cy0, int cy1, int tx0, int ty0,
+                                             int nxw, int nyw, uint32_t &fg, uint32_t &bg) {
+    // every word first (one lane asks for one view: its loads hit nothing another lane's do, and a loop
+    // would wait for each in turn), then the masks
+    uint32_t w[NY][NX];
+#pragma unroll
+    for (int a = 0; a < NY; ++a)
+#pragma unroll
+        for (int b = 0; b < NX; ++b) {
+            w[a][b] = 0u;
+            if (a < nyw && b < nxw) w[a][b] = d.cmask[(ty0 + a) * d.tiles_x + tx0 + b];
+        }
+    uint32_t cols[NX];
+#pragma unroll
+    for (int b = 0; b < NX; ++b) {  // columns of cells of tile column b inside the box
+        const int ox = (tx0 + b) * 4;
+        const int c0 = min(max(cx0 - ox, 0), 3), c1 = max(min(cx1 - ox, 3), c0);
+        cols[b] = ((0xfu >> (3 - (c1 - c0))) << c0) * 0x1111u;
+    }
+#pragma unroll
+    for (int a = 0; a < NY; ++a) {  // rows of cells of tile row a inside the box: bits 4 r0 .. 4 r1 + 3
+        const int oy = (ty0 + a) * 4;
+        const int r0 = min(max(cy0 - oy, 0), 3), r1 = max(min(cy1 - oy, 3), r0);
+        const uint32_t rows = (0xffffu >> (12 - 4 * (r1 - r0))) << (4 * r0);
+#pragma unroll
+        for (int b = 0; b < NX; ++b) {  // (tiles beyond the window hold 0)
+            const uint32_t m = rows & cols[b];
+            fg |= w[a][b] & m;
+            bg |= (w[a][b] >> 16) & m;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t rect_verdict_cells(const ViewDesc &d, const GridDesc &g, float x, int j0, int j1,
+                                                       int k0, int k1) {
+    const PixelBox bx = rect_box(d, g, x, j0, j1, k0, k1);
+    if (bx.outside) return 4u;
+    if (!bx.inside) return 0u;
+    const int cx0 = (int)bx.umin >> kCellShift, cx1 = (int)bx.umax >> kCellShift;
+    const int cy0 = (int)bx.vmin >> kCellShift, cy1 = (int)bx.vmax >> kCellShift;
+    const int tx0 = cx0 >> 2, ty0 = cy0 >> 2;
+    const int nxw = (cx1 >> 2) - tx0 + 1, nyw = (cy1 >> 2) - ty0 + 1;  // the window of tiles under the box
+    // a 3 x 3 window or one of three shapes of 16 tiles; the lanes of a wavefront ask about one rectangle of
+    // voxels from cameras of one rig, so they mostly agree on the shape and one of the four runs
+    const int shape = (nxw <= 3 && nyw <= 3) ? 4 : ((nxw <= 2 && nyw <= 8) ? 1 : ((nxw <= 4 && nyw <= 4) ? 2 : ((nxw <= 8 && nyw <= 2) ? 3 : 0)));
+    if (shape == 0) return 0u;
+    uint32_t fg = 0, bg = 0;
+    if (shape == 4) window_cells<3, 3>(d, cx0, cx1, cy0, cy1, tx0, ty0, nxw, nyw, fg, bg);  // the usual one: a square unit
+    if (shape == 1) window_cells<2, 8>(d, cx0, cx1, cy0, cy1, tx0, ty0, nxw, nyw, fg, bg);
+    if (shape == 2) window_cells<4, 4>(d, cx0, cx1, cy0, cy1, tx0, ty0, nxw, nyw, fg, bg);
+    if (shape == 3) window_cells<8, 2>(d, cx0, cx1, cy0, cy1, tx0, ty0, nxw, nyw, fg, bg);
+    return fg == 0u ? 1u : (bg == 0u ? 2u : 0u);
 }
 
 __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
@@ -707,6 +813,10 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     // kept by every view of the batch: FULL (2: some view saw it, a 0 becomes 1) or UNTOUCHED (6: no view
     // sees any of it, the labels stay); by every view packed so far only: a candidate (3 seen / 7 unseen)
     if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? (saw ? 2 : 6) : (saw ? 3 : 7)) : 0));
+    if (nall < nbatch) {  // grid-uniform: later views are not packed yet, kept bricks are candidates
+        const unsigned long long mc = __ballot(inb && !isdead && !gone && kept);
+        if (mc != 0 && lane == 0) atomicAdd(&ctl->ncand, (uint32_t)__popcll(mc));
+    }
     if (valid && dead != nullptr && (gone || dead_stale)) dead[lb] = gone ? 1 : 0;
     // the bricks left go on the live list, one atomic per block
     const bool alive = valid && !gone && !kept;
@@ -728,6 +838,50 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             // bit 31: kept whole (0 -> 1); bit 30: kept and unseen (nothing changes)
             if (fillme) fill_list[base + (uint32_t)__popcll(mf & below)] = lb | (gone ? 0u : (saw ? 0x80000000u : 0x40000000u));
+        }
+    }
+}
+
+// Two views applied to the four voxels of a lane: both projections first, then the eight gathers of a
+// lane in one flight (the kernels that call this wait on memory, not on arithmetic), then
+// backprojection.c:79-83 for the first view and, for what it left alive, for the second.
+__device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db, bool two, float x, float y,
+                                          const float (&z)[4], int32_t (&lab)[4], uint32_t &alive) {
+    const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
+    const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
+    const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
+    const uint32_t *bitb = static_cast<const uint32_t *>(db.mask);
+    bool oka[4], okb[4];
+    uint32_t wa[4], wb[4];
+    int sha[4], shb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int u, v;
+        const bool live = (alive >> e) & 1u;
+        oka[e] = project(aax, aay, aaz, z[e], da, u, v) & live;
+        sha[e] = u & 31;
+        wa[e] = load_mask_word(bita, oka[e] ? mask_word_index(u, v, da.tiles_x) : 0u);
+        okb[e] = project(bax, bay, baz, z[e], db, u, v) & live & two;
+        shb[e] = u & 31;
+        wb[e] = load_mask_word(bitb, okb[e] ? mask_word_index(u, v, db.tiles_x) : 0u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (oka[e]) {
+            if (((wa[e] >> sha[e]) & 1u) == 0) {  // :79
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {  // :81
+                lab[e] = 1;
+            }
+        }
+        if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
+            if (((wb[e] >> shb[e]) & 1u) == 0) {
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {
+                lab[e] = 1;
+            }
         }
     }
 }
@@ -781,9 +935,6 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
 
-    // two views per iteration: both projections first, then the eight gathers of a lane in one
-    // flight (the kernel waits on memory, not on arithmetic), then backprojection.c:79-83 for
-    // the first view and, for what it left alive, for the second
     for (int vi = 0; vi < nviews; vi += 2) {
         if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
         const bool two = vi + 1 < nviews;      // wave-uniform
@@ -794,43 +945,7 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         }
         const ViewDesc da = views[ia];
         const ViewDesc db = views[ib];
-        const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
-        const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
-        const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
-        const uint32_t *bitb = static_cast<const uint32_t *>(db.mask);
-        bool oka[4], okb[4];
-        uint32_t wa[4], wb[4];
-        int sha[4], shb[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int u, v;
-            const bool live = (alive >> e) & 1u;
-            oka[e] = project(aax, aay, aaz, z[e], da, u, v) & live;
-            sha[e] = u & 31;
-            wa[e] = load_mask_word(bita, oka[e] ? mask_word_index(u, v, da.tiles_x) : 0u);
-            okb[e] = project(bax, bay, baz, z[e], db, u, v) & live & two;
-            shb[e] = u & 31;
-            wb[e] = load_mask_word(bitb, okb[e] ? mask_word_index(u, v, db.tiles_x) : 0u);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (oka[e]) {
-                if (((wa[e] >> sha[e]) & 1u) == 0) {  // :79
-                    lab[e] = -1;
-                    alive &= ~(1u << e);
-                } else if (lab[e] == 0) {  // :81
-                    lab[e] = 1;
-                }
-            }
-            if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
-                if (((wb[e] >> shb[e]) & 1u) == 0) {
-                    lab[e] = -1;
-                    alive &= ~(1u << e);
-                } else if (lab[e] == 0) {
-                    lab[e] = 1;
-                }
-            }
-        }
+        two_views(da, db, two, x, y, z, lab, alive);
     }
 
     if (ORDERED && seen) {
@@ -856,7 +971,16 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
             b[e] = __ballot((alive >> e) & 1u);
             total += (uint32_t)__popcll(b[e]);
         }
-        if (total != 0) {  // wave-uniform
+        bool bulked = false;
+        if (ap.bulk != nullptr && total >= ap.bulk_min) {  // wave-uniform
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&ap.ctl->count[3][ap.sub].n, 1u);
+            pos = __shfl(pos, 0);
+            bulked = pos < ap.bulkcap;  // (a full sub-list: the voxels take the ordinary lists)
+            if (bulked && lane == 0)
+                ap.bulk[(size_t)ap.sub * ap.bulkcap + pos] = lb * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        }
+        if (total != 0 && !bulked) {  // wave-uniform
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&ap.ctl->count[0][ap.sub].n, total);
             base = __shfl(base, 0);
@@ -928,54 +1052,253 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
     }
 }
 
+// The UNITS of the bulk list (a wavefront's share of a live brick -- its 16 columns, voxels 16w .. 16w + 15 of
+// each: a square patch of the plane -- with most of its voxels alive after the dense views) are asked about as a whole before anything projects
+// their voxels: every remaining view at once, one view per lane, at the cell level (rect_verdict_cells).
+//   some view sees the unit entirely over background (EMPTY): every voxel is carved, done;
+//   views that see it entirely over foreground (FULL) make a label 0 a 1 (backprojection.c:81) here and now,
+//   and like the views that do not see it at all (OUTSIDE) have nothing more to say;
+//   the UNDECIDED views are the only ones that have to project its voxels: they become work items
+//   (half a unit x up to 16 of those views, see UnitItems) for the final list stage -- or, when that would
+//   be no cheaper than the ordinary survivor lists (few voxels alive, most views undecided), the unit's
+//   voxels are appended to the first list like any other survivor.
+struct UnitJob {
+    const uint32_t *units;    // null: no bulk list.  [kSub][cap] unit ids (brick * 4 + wavefront), counts in ctl->count[3]
+    uint32_t cap;
+    uint4 *items;             // [kSub][icap] work items out, counts in ctl->count[4]
+    uint32_t icap;
+    const ViewDesc *views;    // every view of the batch
+    int32_t nall, ndense;     // ... their number (<= 128), and how many of them the dense stage has applied
+    uint32_t bricks_y, bricks_z;
+    int32_t *labels;
+    uint32_t *list;           // the first survivor list and the room of its sub-lists (counts in ctl->count[0])
+    uint32_t subcap;
+    uint32_t bias;            // items are chosen when their turns * 16 <= bias * the turns the lists would take
+    uint32_t *stats;          // per unit block: {units that got their verdicts, turns those spared the survivor stages}
+};
+
+__device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
+                                              uint32_t sub, uint32_t lane, uint32_t &saved) {
+    const uint32_t lb = unit >> 2, w = unit & 3u;
+    const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / uj.bricks_z, bz = rem - by * uj.bricks_z;
+    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
+    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const uint32_t elem = (il * g.ny + j) * g.nzp + k0;
+    int32_t *p = uj.labels + elem;  // the pitch is a multiple of 64: 16-byte groups
+    int32_t lab[4] = {-1, -1, -1, -1};  // what a lane does not own counts as carved
+    if (inside) {
+        const int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    unsigned long long need[2] = {0ull, 0ull};
+    bool seen = false, empty = false;
+    for (int h = 0; h < 2 && h * 64 < uj.nall; ++h) {
+        const int vi = h * 64 + (int)lane;
+        uint32_t v = 8u;  // no such view, or one the dense stage has applied
+        if (vi < uj.nall && vi >= uj.ndense) {
+            const ViewDesc d = uj.views[vi];  // one descriptor per lane
+            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+        }
+        empty |= __ballot(v == 1u) != 0;
+        seen |= __ballot(v == 2u) != 0;
+        need[h] = __ballot(v == 0u);
+    }
+    unsigned long long b[4];
+    uint32_t nalive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        b[e] = __ballot((alive >> e) & 1u);
+        nalive += (uint32_t)__popcll(b[e]);
+    }
+    // turns of (128 voxels x 2 views) the unit's voxels would take in the survivor lists
+    const uint32_t list_cost = ((nalive + 127u) >> 7) * (((uint32_t)(uj.nall - uj.ndense) + 1u) >> 1);
+    if (empty) {  // some view carves every voxel of the unit
+        if (inside && alive != 0) *reinterpret_cast<int4 *>(p) = make_int4(-1, -1, -1, -1);
+        saved += list_cost;
+        return;
+    }
+    if (seen) {
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) { lab[e] = 1; changed = true; }  // :81 by a view that keeps the whole unit
+        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    }
+    const uint32_t nneed = (uint32_t)__popcll(need[0]) + (uint32_t)__popcll(need[1]);
+    const unsigned long long anyalive = __ballot(alive != 0);
+    if (nneed == 0 || anyalive == 0) {  // wave-uniform: the labels are final
+        saved += list_cost;
+        return;
+    }
+    // the undecided views of each 64-view word in pieces of up to 16; one item per (half with something
+    // alive, word, piece): lane = piece * 4 + word * 2 + half
+    unsigned long long pm[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool bit = (need[h] >> lane) & 1ull;
+        const uint32_t piece = lanes_below(need[h]) >> 4;  // this lane's view is the (16 piece + ..)-th undecided one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pm[h][q] = __ballot(bit && piece == (uint32_t)q);
+    }
+    const uint32_t hq = lane & 1u, wq = (lane >> 1) & 1u, pq = lane >> 2;
+    unsigned long long mymask = 0ull;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (wq == (uint32_t)h && pq == (uint32_t)q) mymask = pm[h][q];
+    const uint32_t halves = ((uint32_t)(anyalive & 0xffffffffull) != 0u ? 1u : 0u) + ((uint32_t)(anyalive >> 32) != 0u ? 1u : 0u);
+    const bool half_alive = ((anyalive >> (32u * hq)) & 0xffffffffull) != 0;
+    const bool mine = lane < 16u && mymask != 0ull && half_alive;
+    const unsigned long long im = __ballot(mine);
+    const uint32_t nitems = (uint32_t)__popcll(im);
+    // turns of (128 voxels x 2 views): the items' against what the unit's voxels would take in the lists
+    const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (item_cost * 16u <= uj.bias * list_cost) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
+        pos = __shfl(pos, 0);
+        if (pos + nitems <= uj.icap) {
+            if (mine)
+                uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
+                    make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
+            saved += list_cost - min(list_cost, item_cost);
+            return;
+        }
+        // (no room: the count stays beyond the capacity, the reader clamps it; the voxels take the list)
+    }
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->count[0][sub].n, nalive);
+    base = __shfl(base, 0);
+    if (base + nalive > uj.subcap) {
+        if (lane == 0) ctl->overflow = 1u;
+        return;
+    }
+    uint32_t *dst = uj.list + (size_t)sub * uj.subcap + base;
+    uint32_t off = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if ((alive >> e) & 1u) dst[off + (uint32_t)__popcll(b[e] & below)] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
+        off += (uint32_t)__popcll(b[e]);
+    }
+}
+
 // FULL candidates (flag 3: every view the flags kernel could see keeps the brick whole, but the masks
 // of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
 // views: same organisation as the flags kernel's own FULL rounds (64 bricks per block, one view per
 // wavefront and round, verdicts joined in LDS).  Kept by all: flag 2, filled like any FULL brick.
 // Otherwise flag 5 and a place on the LATE list: the resume kernel carves such a brick over all the
 // views of the batch, voxel by voxel.  A block without candidates leaves at once.
+// The units of the bulk list get their verdicts, one wavefront per unit (unit_verdicts): a persistent grid of
+// blocks of 8 wavefronts, launched behind the confirm kernel (the masks of every view are packed by then) and
+// ahead of the list stages.  (A kernel of its own: inside the confirm kernel its registers cost that kernel's
+// blocks three wavefronts per SIMD, 40 us on a batch of all-foreground masks.)
+__global__ __launch_bounds__(64 * kFlagWaves) void unit_verdict_kernel(GridDesc g, ListCtl *ctl, UnitJob uj) {
+    const uint32_t nunitblocks = gridDim.x;
+    __shared__ uint32_t upref[kSub + 1];
+    const uint32_t tid = threadIdx.x;
+    {
+        if (tid < kSub) upref[tid + 1] = min(ctl->count[3][tid].n, uj.cap);
+        if (tid == 0) upref[0] = 0;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            uint32_t val = 0, add = 0;
+            if (tid < kSub) {
+                val = upref[tid + 1];
+                add = (tid >= off) ? upref[tid + 1 - off] : 0u;
+            }
+            __syncthreads();
+            if (tid < kSub) upref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
+    const uint32_t total = upref[kSub];
+    const uint32_t uwave = __builtin_amdgcn_readfirstlane(tid >> 6), ulane = tid & 63u;
+    const uint32_t nworkers = nunitblocks * kFlagWaves;
+    uint32_t nunits = 0, saved = 0;
+    for (uint32_t i = blockIdx.x * kFlagWaves + uwave; i < total; i += nworkers) {
+        uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (upref[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t unit = __builtin_amdgcn_readfirstlane(uj.units[(size_t)lo * uj.cap + (i - upref[lo])]);
+        unit_verdicts(uj, g, ctl, unit, lo, ulane, saved);
+        ++nunits;
+    }
+    // what the host's on / off decision reads (see flush): one pair per block, summed by a list kernel (ReportJob)
+    // (atomics on one address from every wavefront of the grid would take longer than the verdicts)
+    __shared__ uint32_t s_stat[2];
+    if (tid < 2) s_stat[tid] = 0u;
+    __syncthreads();
+    if (ulane == 0 && nunits != 0) {
+        atomicAdd(&s_stat[0], nunits);
+        atomicAdd(&s_stat[1], saved);
+    }
+    __syncthreads();
+    if (tid < 2) uj.stats[blockIdx.x * 2u + tid] = s_stat[tid];
+}
+
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
+    if (v0 >= v1 || ctl->ncand == 0) return;  // no view was packed late, or the flags kernel left no candidate open
     __shared__ unsigned long long s_full[kFlagWaves], s_seen[kFlagWaves];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t lb = blockIdx.x * 64u + lane;
-    const uint32_t fl = lb < nbricks ? flags[lb] : 0u;
-    const bool isc = fl == 3u || fl == 7u;  // candidates: some view so far saw the brick whole / none sees it
-    unsigned long long any_seen = __ballot(fl == 3u);
-    unsigned long long cand = __ballot(isc);
-    if (cand == 0) return;  // block-uniform: every wavefront read the same 64 flags
     const uint32_t per_plane = bricks_y * bricks_z;
-    const uint32_t il = lb / per_plane;
-    const uint32_t rem = lb - il * per_plane;
-    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-    for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
-        const int vi = base + (int)wave;
-        bool keeps = true, sees = false;
-        if (vi < v1 && ((cand >> lane) & 1ull)) {
-            const ViewDesc d = views[vi];
-            const uint32_t v = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
-            keeps = v == 2u || v == 4u;
-            sees = v == 2u;
-        }
-        const unsigned long long mf = __ballot(keeps), ms = __ballot(sees);
-        __syncthreads();  // the previous round's masks have been read by everybody
-        if (lane == 0) { s_full[wave] = mf; s_seen[wave] = ms; }
-        __syncthreads();
+    // a persistent grid over the groups of 64 bricks
+    for (uint32_t grp = blockIdx.x; grp * 64u < nbricks; grp += gridDim.x) {
+        const uint32_t lb = grp * 64u + lane;
+        const uint32_t fl = lb < nbricks ? flags[lb] : 0u;
+        const bool isc = fl == 3u || fl == 7u;  // candidates: some view so far saw the brick whole / none sees it
+        unsigned long long any_seen = __ballot(fl == 3u);
+        unsigned long long cand = __ballot(isc);
+        if (cand == 0) continue;  // block-uniform: every wavefront read the same 64 flags
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+        for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
+            const int vi = base + (int)wave;
+            bool keeps = true, sees = false;
+            if (vi < v1 && ((cand >> lane) & 1ull)) {
+                const ViewDesc d = views[vi];
+                const uint32_t v = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
+                keeps = v == 2u || v == 4u;
+                sees = v == 2u;
+            }
+            const unsigned long long mf = __ballot(keeps), ms = __ballot(sees);
+            __syncthreads();  // the previous round's masks have been read by everybody
+            if (lane == 0) { s_full[wave] = mf; s_seen[wave] = ms; }
+            __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kFlagWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
-    }
-    if (wave != 0) return;
-    if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
-    const bool failed = isc && !((cand >> lane) & 1ull);
-    const unsigned long long m = __ballot(failed);
-    if (m != 0) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctl->nlate, (uint32_t)__popcll(m));
-        pos = __shfl(pos, 0);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        if (failed) late[pos + (uint32_t)__popcll(m & below)] = lb;
+            for (int w = 0; w < kFlagWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
+        }
+        if (wave != 0) continue;
+        if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
+        const bool failed = isc && !((cand >> lane) & 1ull);
+        const unsigned long long m = __ballot(failed);
+        if (m != 0) {
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&ctl->nlate, (uint32_t)__popcll(m));
+            pos = __shfl(pos, 0);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (failed) late[pos + (uint32_t)__popcll(m & below)] = lb;
+        }
     }
 }
 
@@ -1023,8 +1346,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         const uint32_t il = lb / per_plane;
         const uint32_t rem = lb - il * per_plane;
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-        const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
-        brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + (lane & 15) * 4, lb, lane);
+        // wavefront w: all 16 columns of the brick, voxels 16 w .. 16 w + 15 of each (lane = column * 4 + group
+        // of 4 voxels) -- a square patch of the plane, the UNIT the bulk list speaks of (see Append)
+        const uint32_t j = by * kBrickY + (lane >> 2);
+        brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + wave * 16u + (lane & 3u) * 4u, lb, lane);
     }
 }
 
@@ -1078,7 +1403,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         return;
     }
     const uint32_t nlive = ctl->nlive[parity];
-    const Append none{nullptr, nullptr, 0u, 0u};
+    const Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
     const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3, per_xcd = nwalkers >> 3;
     for (uint32_t t = seq; ; t += per_xcd) {
         const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
@@ -1103,7 +1428,7 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
     constexpr int G = (!FRESH && VEC) ? kStreamGroups : 1;
     uint32_t lb = spread_block(blockIdx.x, gridDim.x);
     uint64_t grp = (uint64_t)lb * (kBlock * G) + threadIdx.x;
-    Append none{nullptr, nullptr, 0u, 0u};
+    Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
     int4 cur = make_int4(-1, -1, -1, -1);
     // streaming loads: the state (512 MiB) is far bigger than the Infinity Cache, every view
     // reads all of it once
@@ -1122,6 +1447,26 @@ __global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ l
         cur = nxt;
     }
 }
+
+// Work items of the bulk units (see unit_verdicts): (half a unit = 8 columns x 16 voxels, up to 16 of the
+// views that have to project its voxels, as a mask over 64 consecutive views).  The final list stage's
+// wavefronts take them after their own spans; items of one unit may run side by side, which is exact for the
+// same reason as the spans of one chunk: -1 is a plain store, 0 -> 1 a compare-and-swap on 0.
+// What the bulk units' verdicts of this batch were worth, for the host's on / off decision (see flush): the
+// sums over the unit blocks' pairs (UnitJob::stats), written as ONE 8-byte word to page-locked memory by
+// block 0 of the first list kernel behind the verdicts, when it is through with its own work.
+struct ReportJob {
+    unsigned long long *report;  // null: nothing to report.  seq << 48 | min(units, 2^24 - 1) << 24 | min(turns spared / 16, 2^24 - 1)
+    const uint32_t *stats;
+    uint32_t nstats, seq;
+};
+
+struct UnitItems {
+    const uint4 *items;       // null: none.  .x = unit * 2 + half, .y = first view of the mask, .z / .w = the mask
+    uint32_t cap;             // items per sub-list (counts in ctl->count[4])
+    const ViewDesc *views;    // every view of the batch (the items' view numbers index this)
+    uint32_t bricks_y, bricks_z;
+};
 
 // Fused carve, sparse phase: one lane per SURVIVOR.  Reads the survivor sub-lists a previous
 // stage appended and applies views with every lane busy, two views per iteration (two
@@ -1144,26 +1489,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
                                                             ListCtl *ctl, int sin, int sout,
-                                                            uint32_t subcap, int vgsize, CullStores cs) {
+                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui,
+                                                            ReportJob rj) {
     __shared__ uint32_t pref[kSub + 1];
     const uint32_t tid = threadIdx.x;
+    const uint32_t bx = blockIdx.x, gdim = gridDim.x;
     // A final stage with deferred stores has cs.nstrips STORE blocks behind its persistent list
     // blocks: this stage is bound by projection arithmetic and the -1 fill of the bricks the flags
     // kernel found empty by HBM writes, so the two run side by side instead of one after the
     // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
     const bool split = cs.flags != nullptr;
     const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : cs.nstrips - cs.first) : 0u;
-    const uint32_t nbid = gridDim.x - nstore;
-    if (split && blockIdx.x >= nbid) {
+    const uint32_t nbid = gdim - nstore;
+    if (split && bx >= nbid) {
         // one short block per strip, or (fill_blocks > 0) that many blocks walking the strips: a
         // wavefront's stores do not hold it up, so few of them keep the write path busy and the
         // wavefront slots go to the list blocks
-        for (uint32_t strip = cs.first + (blockIdx.x - nbid); strip < cs.nstrips; strip += nstore)
+        for (uint32_t strip = cs.first + (bx - nbid); strip < cs.nstrips; strip += nstore)
             store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
         return;
     }
     if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
-    const uint32_t bid = blockIdx.x;
+    const uint32_t bid = bx;
     constexpr uint32_t CH = 64u * P;
     {
         uint32_t c = (min(ctl->count[sin][tid].n, subcap) + CH - 1u) / CH;  // kSub == kBlock
@@ -1180,6 +1527,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     const uint32_t chunks = pref[kSub];
     const uint32_t lane = tid & 63u;
+    __shared__ uint32_t ipref[FINAL ? kSub + 1 : 1];
+    const bool with_items = FINAL && ui.items != nullptr;  // grid-uniform
+    if (with_items) {
+        const uint32_t c = min(ctl->count[4][tid].n, ui.cap);
+        if (tid == 0) ipref[0] = 0;
+        ipref[tid + 1] = c;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            const uint32_t val = ipref[tid + 1];
+            const uint32_t add = (tid >= off) ? ipref[tid + 1 - off] : 0u;
+            __syncthreads();
+            ipref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
     const uint64_t nworkers = (uint64_t)nbid * (kBlock / 64);
     // the wavefront index must be a scalar for the compiler, or everything derived from the
     // item (view range, descriptors) is treated as divergent and fetched with vector loads
@@ -1311,6 +1673,103 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             }
         }
     }
+    if (with_items) {
+        // the bulk units' work items, dealt round-robin: two voxels per lane, the views the item names, two
+        // per turn as above
+        const uint32_t itotal = ipref[kSub];
+        const uint32_t per_plane = ui.bricks_y * ui.bricks_z;
+        for (uint32_t i = (uint32_t)wid; i < itotal; i += (uint32_t)nworkers) {
+            uint32_t lo = 0, hi = kSub;  // largest s with ipref[s] <= i (wave-uniform)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ipref[mid] <= i) lo = mid; else hi = mid;
+            }
+            uint4 it = ui.items[(size_t)lo * ui.cap + (i - ipref[lo])];
+            it.x = __builtin_amdgcn_readfirstlane(it.x);
+            it.y = __builtin_amdgcn_readfirstlane(it.y);
+            it.z = __builtin_amdgcn_readfirstlane(it.z);
+            it.w = __builtin_amdgcn_readfirstlane(it.w);
+            const uint32_t unit = it.x >> 1, lb = unit >> 2;
+            const uint32_t il = lb / per_plane, rem = lb - il * per_plane;
+            const uint32_t by = rem / ui.bricks_z, bz = rem - by * ui.bricks_z;
+            // half h of a unit: its columns 8 h .. 8 h + 7; lane = (column & 3) * 16 + voxel, p = column >> 2
+            const uint32_t j0 = by * kBrickY + (it.x & 1u) * 8u + (lane >> 4), k = bz * kBrickZ + (unit & 3u) * 16u + (lane & 15u);
+            const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+            const float z = g.oz + (float)(int)k * g.vs;
+            uint32_t idx[2];
+            bool alive[2], zero[2];
+            float y[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t j = j0 + 4u * (uint32_t)p;
+                const bool inside = j < g.ny && k < g.nz;
+                idx[p] = (il * g.ny + j) * g.nzp + k;
+                int32_t lab = -1;
+                if (inside) lab = labels[idx[p]];
+                alive[p] = lab != -1;
+                zero[p] = lab == 0;
+                y[p] = g.oy + (float)(int)j * g.vs;
+            }
+            unsigned long long m = ((unsigned long long)it.w << 32) | it.z;
+            const uint32_t vbase = it.y;
+            while (m != 0) {
+                if (__ballot(alive[0] | alive[1]) == 0) break;
+                const uint32_t a = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t b = a;  // a lone view is applied twice: nothing changes the second time
+                if (m != 0) {
+                    b = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                }
+                bool ok[2][2], fg[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const ViewDesc d = ui.views[vbase + (q ? b : a)];
+                    asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        int uu, vv;
+                        ok[q][p] = project(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
+                                           d.R[6] * x + d.R[7] * y[p], z, d, uu, vv);
+                        uint32_t w = 0;
+                        if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
+                        fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const bool carve = (ok[0][p] & !fg[0][p]) | (ok[1][p] & !fg[1][p]);
+                    const bool keep = (ok[0][p] & fg[0][p]) | (ok[1][p] & fg[1][p]);
+                    if (carve & alive[p]) {
+                        alive[p] = false;
+                        zero[p] = false;
+                        labels[idx[p]] = -1;
+                    } else if (zero[p] & keep) {
+                        zero[p] = false;
+                        atomicCAS(&labels[idx[p]], 0, 1);
+                    }
+                }
+            }
+        }
+    }
+    if (rj.report != nullptr && bid == 0) {  // block-uniform
+        __shared__ uint32_t s_sum[2];
+        if (tid < 2) s_sum[tid] = 0u;
+        __syncthreads();
+        uint32_t a = 0, b = 0;
+        for (uint32_t q = tid; q < rj.nstats; q += kBlock) {
+            a += rj.stats[q * 2u];
+            b += rj.stats[q * 2u + 1u];
+        }
+        if (a | b) {
+            atomicAdd(&s_sum[0], a);
+            atomicAdd(&s_sum[1], b);
+        }
+        __syncthreads();
+        if (tid == 0)
+            *rj.report = ((unsigned long long)(rj.seq & 0xffffu) << 48) | ((unsigned long long)min(s_sum[0], 0xffffffu) << 24) |
+                         (unsigned long long)min(s_sum[1] >> 4, 0xffffffu);
+    }
 }
 
 // Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
@@ -1323,7 +1782,91 @@ struct LateBricks {           // FULL candidates that turned out not to be (see 
     uint32_t bricks_y, bricks_z;
 };
 
-constexpr int kLateViews = 256;  // views of a batch the late bricks' view lists cover (more: every view is applied)
+// A unit of a LATE brick (a FULL candidate some later view did not keep whole after all) through every view of
+// the batch, one wavefront: the views are first asked about the unit as a whole, 64 at a time, one view per
+// lane, at the cell level -- a view that sees it entirely over background carves all of it, views that see it
+// entirely over foreground or not at all have nothing to say about its voxels one by one -- and only the
+// others project them, two per turn.  (A brick inside a solid object lies over foreground in nearly all the
+// views, one at the edge of the pictures outside nearly all.)
+template <bool FRESH>
+__device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const GridDesc &g,
+                                          const ViewDesc *__restrict__ views, int nall, int32_t init, uint32_t unit,
+                                          uint32_t bricks_y, uint32_t bricks_z, uint32_t lane) {
+    const uint32_t lb = unit >> 2, w = unit & 3u;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
+    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nzp + k0;  // the pitch is a multiple of 64: 16-byte groups
+    int32_t lab[4] = {-1, -1, -1, -1}, was[4];  // what a lane does not own counts as carved
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = init;
+    } else if (inside) {
+        const int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        was[e] = lab[e];
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
+    bool seen = false;
+    for (int base = 0; base < nall; base += 64) {
+        if (__ballot(alive != 0) == 0) break;
+        const int vi = base + (int)lane;
+        uint32_t v = 8u;  // no such view
+        if (vi < nall) {
+            const ViewDesc d = views[vi];  // one descriptor per lane
+            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+        }
+        const unsigned long long empty = __ballot(v == 1u), full = __ballot(v == 2u);
+        unsigned long long need = __ballot(v == 0u);
+        if (empty != 0) {  // some view carves every voxel of the unit
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lab[e] = -1;
+            alive = 0;
+            break;
+        }
+        seen |= full != 0;
+        while (need != 0) {
+            if (__ballot(alive != 0) == 0) break;
+            const int a = __builtin_ctzll(need);
+            need &= need - 1;
+            int b = a;
+            const bool two = need != 0;
+            if (two) {
+                b = __builtin_ctzll(need);
+                need &= need - 1;
+            }
+            const ViewDesc da = views[base + a];
+            const ViewDesc db = views[base + b];
+            two_views(da, db, two, x, y, z, lab, alive);
+        }
+    }
+    if (seen) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) lab[e] = 1;  // :81 by a view that kept the whole unit
+    }
+    const bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+    if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                               const ViewDesc *__restrict__ views,
@@ -1335,57 +1878,16 @@ __global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restric
         uint32_t *z = reinterpret_cast<uint32_t *>(next);
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < sizeof(ListCtl) / 4; i += gridDim.x * kBlock) z[i] = 0u;
     }
-    Append none{nullptr, nullptr, 0u, 0u};
+    Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
     if (lb.late != nullptr) {
-        // a brick some later view does not keep whole after all: every view, voxel by voxel
+        // bricks some later view does not keep whole after all: every view, one wavefront per unit
         const uint32_t nlate = ctl->nlate;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const uint32_t per_plane = lb.bricks_y * lb.bricks_z;
-        // A late brick was kept as it is by the views packed ahead: most views have no say about it (a
-        // brick inside a solid object lies over foreground in nearly all of them, one at the edge of the
-        // pictures outside nearly all).  Wavefront 0 asks every view at once, one view per lane, and the
-        // block projects the brick's voxels only for the views that are neither FULL nor OUTSIDE.
-        __shared__ uint16_t s_order[kLateViews];
-        __shared__ uint32_t s_count, s_seen;
-        const bool listed = lb.nall <= kLateViews;  // grid-uniform
-        for (uint32_t t = blockIdx.x; t < nlate; t += gridDim.x) {
-            const uint32_t id = lb.late[t];
-            const uint32_t il = id / per_plane;
-            const uint32_t rem = id - il * per_plane;
-            const uint32_t by = rem / lb.bricks_z, bz = rem - by * lb.bricks_z;
-            const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
-            if (listed) {
-                if (wave == 0) {
-                    const float bx = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-                    uint32_t count = 0;
-                    unsigned long long sawm = 0;
-                    for (int base = 0; base < lb.nall; base += 64) {
-                        const int vi = base + (int)lane;
-                        bool need = false, sees = false;
-                        if (vi < lb.nall) {
-                            const ViewDesc d = lb.allviews[vi];  // one descriptor per lane
-                            const uint32_t v = brick_verdict(d, g, bx, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
-                            need = !(v == 2u || v == 4u);  // undecided, or empty (carved voxel by voxel)
-                            sees = v == 2u;
-                        }
-                        const unsigned long long mn = __ballot(need);
-                        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                        if (need) s_order[count + (uint32_t)__popcll(mn & below)] = (uint16_t)vi;
-                        count += (uint32_t)__popcll(mn);
-                        sawm |= __ballot(sees);
-                    }
-                    if (lane == 0) { s_count = count; s_seen = sawm != 0 ? 1u : 0u; }
-                }
-                __syncthreads();
-                const int n = (int)s_count;
-                const bool seen = s_seen != 0u;
-                if (lb.fresh) brick_voxels<true, true>(labels, g, lb.allviews, n, lb.init, none, il, j, k0, id, lane, s_order, seen);
-                else brick_voxels<false, true>(labels, g, lb.allviews, n, lb.init, none, il, j, k0, id, lane, s_order, seen);
-                __syncthreads();  // the list is reused for the next brick
-            } else {
-                if (lb.fresh) brick_voxels<true>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
-                else brick_voxels<false>(labels, g, lb.allviews, lb.nall, lb.init, none, il, j, k0, id, lane);
-            }
+        const uint32_t nworkers = gridDim.x * (kBlock / 64);
+        for (uint32_t t = blockIdx.x * (kBlock / 64) + wave; t < nlate * 4u; t += nworkers) {
+            const uint32_t unit = lb.late[t >> 2] * 4u + (t & 3u);
+            if (lb.fresh) late_unit<true>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
+            else late_unit<false>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
         }
     }
     if (!ctl->overflow) return;
@@ -2031,6 +2533,24 @@ struct sc_engine {
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
+    uint32_t *bulk = nullptr;  // units (a wavefront's share of a live brick) finished as a whole (counts in ctl->count[3])
+    uint32_t bulkcap = 0;      // ... per sub-list
+    int64_t bulk_min = 128;    // voxels of a unit (of 256) alive after the dense views for it to go there (0: never)
+    bool last_bulk = false;    // the last fused launch had a bulk list
+    uint4 *items = nullptr;    // the bulk units' work items (counts in ctl->count[4])
+    uint32_t itemcap = 0;      // ... per sub-list
+    int64_t item_bias = 12;    // sixteenths: items are chosen over the lists when they cost at most this share
+    int64_t unit_blocks = 512; // blocks of 8 wavefronts walking the bulk list behind the confirm kernel
+    // Whether the bulk list pays is a property of the scene (a bulky object or a grid wider than the pictures:
+    // yes; a thin plant: the verdicts settle next to nothing and cost ~10 us), so the engine looks at what the
+    // verdicts of its last batches spared the survivor stages and leaves the bulk list out for a while when
+    // that was less than they cost.  Results never depend on it.
+    int64_t bulk_adapt = 1;
+    volatile unsigned long long *report = nullptr;  // page-locked: see ReportJob
+    uint32_t report_seq = 0, report_seen = 0;
+    int bulk_hold = 0;         // batches still to run without the bulk list
+    uint32_t *unit_stats = nullptr;  // [unit blocks][2], see UnitJob
+    size_t unit_stats_cap = 0;
     uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
     uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
     uint32_t last_parity = 0;
@@ -2310,6 +2830,8 @@ void fill_desc(const sc_engine *e, ViewDesc &d, const float *K, const float *R, 
     const int64_t first[3] = {0, 0, 0}, last[3] = {e->nx - 1, e->ny - 1, e->nz - 1};  // the global grid: any partition of it is inside
     d.safe = certify_view(K, R, t, e->origin, e->vs, first, last);
     d.pad2 = 0;
+    d.cmask = nullptr;
+    d.reserved = 0;
 }
 
 size_t packed_words(int H, int W) {
@@ -2318,7 +2840,7 @@ size_t packed_words(int H, int W) {
 }
 
 PackJob make_pack_job(const void *raw_dev, int64_t row_stride, int64_t view_stride, int W, int H,
-                      uint32_t *packed, int64_t words, uint32_t flip, uint8_t *occ) {
+                      uint32_t *packed, int64_t words, uint32_t flip, uint8_t *occ, uint32_t *cmask) {
     PackJob pj;
     memset(&pj, 0, sizeof pj);
     pj.raw = static_cast<const uint8_t *>(raw_dev);
@@ -2332,6 +2854,7 @@ PackJob make_pack_job(const void *raw_dev, int64_t row_stride, int64_t view_stri
     pj.out_view_words = words;
     pj.flip = flip;
     pj.occ = occ;
+    pj.cmask = cmask;
     return pj;
 }
 
@@ -2386,9 +2909,16 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     bool bytes = dtype != SC_MASK_I32;
     uint32_t flip = pack_flip(dtype);
     bool fast = pack16_eligible(raw_dev, W, dtype, row_stride, view_stride);
+    uint32_t *cmask = nullptr;
+    if (fast && e->bulk_min > 0) {  // the cell level behind the bulk units' verdicts: one word per tile
+        void *cv = nullptr;
+        rc = arena_alloc(e, occ_bytes * 4 * (size_t)V, &cv);
+        if (rc) return rc;
+        cmask = static_cast<uint32_t *>(cv);
+    }
     if (fast) {
         PackJob pj = make_pack_job(raw_dev, row_stride, view_stride, W, H, static_cast<uint32_t *>(packed),
-                                   (int64_t)words, flip, occ);
+                                   (int64_t)words, flip, occ, cmask);
         pj.slot0 = 0;
         pj.nslots = V;
         rc = lt.begin();
@@ -2425,6 +2955,7 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
         ViewDesc d;
         fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q,
                   static_cast<uint32_t *>(packed) + (size_t)q * words, H, W, occ + (size_t)q * occ_bytes);
+        if (cmask) d.cmask = cmask + (size_t)q * occ_bytes;
         e->pending.push_back(d);
     }
     return SC_OK;
@@ -2577,7 +3108,12 @@ int ensure_ctl(sc_engine *e) {
         nbricks = (size_t)e->planes * (size_t)((e->ny + kBrickY - 1) / kBrickY) * (size_t)((e->nz + kBrickZ - 1) / kBrickZ);
     char *base = nullptr;
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), 2 * sizeof(ListCtl) + flag_bytes + 3 * nbricks * sizeof(uint32_t) + 16));
+    // bulk units: four per brick, hashed over the sub-lists; twice the even share each (a full one sends its
+    // units' voxels down the ordinary lists)
+    e->bulkcap = (uint32_t)((nbricks * 4 * 2 + kSub - 1) / kSub + 64);
+    const size_t bulk_words = nbricks ? (size_t)kSub * e->bulkcap : 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base),
+                      2 * sizeof(ListCtl) + flag_bytes + (3 * nbricks + bulk_words) * sizeof(uint32_t) + 16));
     HIP_TRY(hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream));
     e->ctl2[0] = reinterpret_cast<ListCtl *>(base);
     e->ctl2[1] = e->ctl2[0] + 1;
@@ -2588,6 +3124,13 @@ int ensure_ctl(sc_engine *e) {
     e->live = reinterpret_cast<uint32_t *>(base + 2 * sizeof(ListCtl) + flag_bytes);
     e->late = e->live + nbricks;
     e->fill_list = e->late + nbricks;
+    e->bulk = bulk_words ? e->fill_list + nbricks : nullptr;
+    if (bulk_words) {
+        // up to 2 halves x 2 words x 4 pieces per unit; room for a third of that on average (a full sub-list
+        // sends the unit's voxels down the ordinary lists)
+        e->itemcap = e->bulkcap * 5u;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->items), (size_t)kSub * e->itemcap * sizeof(uint4)));
+    }
     return SC_OK;
 }
 
@@ -2602,12 +3145,20 @@ int deferred_job(sc_engine *e, PackJob *out) {
     const size_t occ_bytes = (size_t)((db.W + kTile - 1) / kTile) * (size_t)((db.H + kTile - 1) / kTile);
     rc = arena_alloc(e, occ_bytes * (size_t)db.V, &occ_v);
     if (rc) return rc;
+    uint32_t *cmask = nullptr;
+    if (e->bulk_min > 0) {
+        void *cv = nullptr;
+        rc = arena_alloc(e, occ_bytes * 4 * (size_t)db.V, &cv);
+        if (rc) return rc;
+        cmask = static_cast<uint32_t *>(cv);
+    }
     for (int q = 0; q < db.V; ++q) {
         e->pending[(size_t)q].mask = static_cast<uint32_t *>(packed) + (size_t)q * words;
         e->pending[(size_t)q].occ = static_cast<uint8_t *>(occ_v) + (size_t)q * occ_bytes;
+        if (cmask) e->pending[(size_t)q].cmask = cmask + (size_t)q * occ_bytes;
     }
     *out = make_pack_job(db.raw, db.row_stride, db.view_stride, db.W, db.H, static_cast<uint32_t *>(packed),
-                         (int64_t)words, pack_flip(db.dtype), static_cast<uint8_t *>(occ_v));
+                         (int64_t)words, pack_flip(db.dtype), static_cast<uint8_t *>(occ_v), cmask);
     return SC_OK;
 }
 
@@ -2777,7 +3328,7 @@ int flush(sc_engine *e, size_t count = 0) {
         const int ndense = fp.ndense, nstage1 = fp.nstage1, flag_views = fp.flag_views;
         const uint32_t list_blocks = (uint32_t)e->list_blocks;
         const bool compact = fp.compact, brick = fp.brick, defer_stores = fp.defer_stores;
-        Append ap{nullptr, nullptr, 0u, 0u};
+        Append ap{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
         int dense_views = (int)nv;
         const uint32_t bys = fp.bys, bzs = fp.bzs, nbricks = fp.nbricks, nstrips = fp.nstrips;
         const uint32_t dense_store_strips = fp.dense_store_strips;
@@ -2809,6 +3360,44 @@ int flush(sc_engine *e, size_t count = 0) {
             ap.subcap = e->subcap;
             dense_views = ndense;
         }
+        // bulk units: brick form with survivor stages, every view with its cell level
+        bool bulk_on = compact && brick && e->bulk_min > 0 && e->bulk != nullptr;
+        if (nv > 128) bulk_on = false;  // the units' verdict masks cover 128 views
+        for (size_t q = 0; q < nv && bulk_on; ++q) bulk_on = e->pending[q].cmask != nullptr;
+        if (bulk_on && e->bulk_adapt) {
+            if (!e->report) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(const_cast<unsigned long long **>(&e->report)), 64, hipHostMallocDefault));
+                e->report[0] = 0ull;
+            }
+            const unsigned long long rep = e->report[0];
+            const uint32_t seq = (uint32_t)(rep >> 48);
+            if (seq != e->report_seen) {  // a batch has reported since the last look
+                e->report_seen = seq;
+                const uint64_t units = (rep >> 24) & 0xffffffu, spared = (rep & 0xffffffu) << 4;
+                // Measured on one MI355X: the verdicts take max(10 us, 3.3 ns per unit) and a turn spared is worth
+                // 0.28 ns of the survivor stages (2.3 us per turn over 8192 wavefronts)
+                // (no unit at all: the verdict kernel's launch and the dense stage's bookkeeping bought nothing)
+                if (spared < std::max<uint64_t>(36000, units * 12)) e->bulk_hold = 64;
+            }
+            if (e->bulk_hold > 0) {
+                --e->bulk_hold;
+                bulk_on = false;
+            }
+        }
+        if (bulk_on && (size_t)e->unit_blocks > e->unit_stats_cap) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->unit_stats) (void)hipFree(e->unit_stats);
+            e->unit_stats = nullptr;
+            e->unit_stats_cap = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->unit_stats), (size_t)e->unit_blocks * 2 * sizeof(uint32_t)));
+            e->unit_stats_cap = (size_t)e->unit_blocks;
+        }
+        if (bulk_on) {
+            ap.bulk = e->bulk;
+            ap.bulkcap = e->bulkcap;
+            ap.bulk_min = (uint32_t)e->bulk_min;
+        }
+        e->last_bulk = bulk_on;
         LaunchTimer lt{e, SC_KERNEL_CARVE};
         if (!brick) {  // the brick form starts the timer after its flags kernel
             rc = lt.begin();
@@ -2903,8 +3492,17 @@ int flush(sc_engine *e, size_t count = 0) {
             CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0}, cs = none;
             if (ride_blocks) {
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
-                hipLaunchKernelGGL(brick_confirm_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0, e->stream, g,
-                                   vd, packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
+                // (one block per 64 bricks up to 4096 blocks; without candidates a block leaves after one scalar load)
+                const uint32_t nconfirm = std::min<uint32_t>((nbricks + 63u) / 64u, 4096u);
+                hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kFlagWaves), 0, e->stream, g, vd,
+                                   packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
+            }
+            if (bulk_on) {
+                // ... and the units of the bulk list their verdicts
+                const UnitJob uj{e->bulk, e->bulkcap, e->items, e->itemcap, vd, (int32_t)nv, ndense, bys, bzs, st,
+                                 e->lists, e->subcap, (uint32_t)e->item_bias, e->unit_stats};
+                hipLaunchKernelGGL(unit_verdict_kernel, dim3((uint32_t)e->unit_blocks), dim3(64 * kFlagWaves), 0,
+                                   e->stream, g, e->ctl, uj);
             }
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
@@ -2933,15 +3531,22 @@ int flush(sc_engine *e, size_t count = 0) {
             // stage 1 (l0 -> l1), optional stage 2 (l1 -> l0), final stage on what is left
             int s2 = (int)std::min<size_t>(nv, (size_t)s1 + (size_t)e->stage2_views);
             uint32_t *nolist = nullptr;
+            // the final stage also takes the work items of the bulk units
+            const UnitItems noitems{nullptr, 0u, nullptr, 0u, 0u}, ui{bulk_on ? e->items : nullptr, e->itemcap, vd, bys, bzs};
+            // ... and the first list kernel behind the verdicts tells the host what they were worth
+            const ReportJob norep{nullptr, nullptr, 0u, 0u};
+            ReportJob rj = norep;
+            if (bulk_on && e->bulk_adapt)
+                rj = ReportJob{const_cast<unsigned long long *>(e->report), e->unit_stats, (uint32_t)e->unit_blocks, ++e->report_seq};
             if ((size_t)s1 >= nv) {
-                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs);
+                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs, ui, rj);
             } else {
-                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1);
+                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1, noitems, rj);
                 if (s2 > s1 && (size_t)s2 < nv) {
-                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none);
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs);
+                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none, noitems, norep);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs, ui, norep);
                 } else {
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs, ui, norep);
                 }
             }
 #undef LAUNCH_LIST
@@ -3197,6 +3802,9 @@ void sc_destroy(sc_engine *e) {
     if (e->lut_dev) (void)hipFree(e->lut_dev);
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
+    if (e->items) (void)hipFree(e->items);
+    if (e->report) (void)hipHostFree(const_cast<unsigned long long *>(e->report));
+    if (e->unit_stats) (void)hipFree(e->unit_stats);
     if (e->state) (void)hipFree(e->state);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -3324,6 +3932,22 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_VIEW_GROUP:
             if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "view_group must be in [1, 4096]");
             e->view_group = value;
+            return SC_OK;
+        case SC_OPT_BULK_MIN:
+            if (value < 0 || value > 256) return fail(SC_ERR_INVALID, "bulk_min must be in [0, 256]");
+            e->bulk_min = value;
+            return SC_OK;
+        case SC_OPT_ITEM_BIAS:
+            if (value < 0 || value > 64) return fail(SC_ERR_INVALID, "item_bias must be in [0, 64]");
+            e->item_bias = value;
+            return SC_OK;
+        case SC_OPT_BULK_ADAPT:
+            e->bulk_adapt = value ? 1 : 0;
+            e->bulk_hold = 0;
+            return SC_OK;
+        case SC_OPT_UNIT_BLOCKS:
+            if (value < 1 || value > 65536) return fail(SC_ERR_INVALID, "unit_blocks must be in [1, 65536]");
+            e->unit_blocks = value;
             return SC_OK;
         case SC_OPT_MAX_PENDING:
             if (value < 1) return fail(SC_ERR_INVALID, "max_pending must be >= 1");
@@ -3650,6 +4274,12 @@ int sc_fused_counts_ex(sc_engine *e, int64_t out[8]) {
     ListCtl host;
     HIP_TRY(hipMemcpy(&host, e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
     out[4] = host.nlate;
+    if (e->last_bulk)
+        for (int q = 0; q < kSub; ++q) {
+            out[5] += std::min<uint32_t>(host.count[3][q].n, e->bulkcap);
+            out[6] += std::min<uint32_t>(host.count[4][q].n, e->itemcap);
+        }
+    out[7] = e->bulk_hold;
     return SC_OK;
 }
 

@@ -170,6 +170,10 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_FINAL_VOXELS": 4, "SC_OPT_STAGE1_VOXELS": 2},                # four, one view per turn; two in the first stage
     {"SC_OPT_STAGE1_VOXELS": 4, "SC_OPT_VIEW_GROUP": 3},
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
+    {"SC_OPT_BULK_MIN": 0},                                               # no unit is finished as a whole
+    {"SC_OPT_BULK_MIN": 1},                                               # every unit with a voxel alive is
+    {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0},
+    {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
                                         ("dense", (14, 48, 192)),    # a bulky object: whole-brick masks at work
@@ -234,6 +238,48 @@ def test_bricks_every_view_keeps_whole(gpu_device, shape, default_value, defer):
             e.process_view(K, R, t, m, nat.SC_MASK_U8)
         assert np.array_equal(e.get_values(), oracle_c.carve(sh, origin, vs, vv + inv, default_value, nthreads=4))
         e.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 32, 128), (5, 37, 131), (9, 48, 192)])
+@pytest.mark.parametrize("default_value", [0, 1, -1, 7])
+@pytest.mark.parametrize("bulk_min,full", [(128, 1), (1, 0), (200, 0)])
+def test_bulk_units_asked_as_a_whole(gpu_device, shape, default_value, bulk_min, full):
+    """Units (a wavefront's share of a live brick) with most voxels alive after the dense views are finished
+    as a whole: every view is asked about the unit from its summed-area table over 8x8-pixel cells --
+    entirely over background: carved; entirely over foreground or out of the picture: nothing to project --
+    and only the undecided views project its voxels.  A disc that holds the inner units and cuts through
+    the outer ones (all three verdicts at work), the bulky ellipsoid, all-foreground masks; a fresh volume,
+    a second batch over the stored one, and a batch of inverted masks over that."""
+    sh, origin, vs, views = scene(shape, 11, "solid")
+    H, W = views[0][3].shape
+    yy, xx = np.mgrid[0:H, 0:W]
+    disc = (((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.22 * min(H, W)) ** 2).astype(np.uint8) * 255
+    dense = [m for _, _, _, m in scene(shape, 11, "dense")[3]]
+    used = 0
+    for masks in ([disc] * len(views), dense, [m for _, _, _, m in views]):
+        vv = [(K, R, t, m) for (K, R, t, _), m in zip(views, masks)]
+        want = oracle_c.carve(sh, origin, vs, vv, default_value, nthreads=4)
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=default_value)
+        e.set_option(nat.SC_OPT_BULK_MIN, bulk_min)
+        e.set_option(nat.SC_OPT_FULL_BRICKS, full)
+        stack = np.ascontiguousarray(np.stack(masks))
+        ptr = e.dev_alloc(stack.nbytes)
+        e.dev_upload(ptr, stack)
+        K = np.stack([v[0] for v in vv]); R = np.stack([v[1] for v in vv]); t = np.stack([v[2] for v in vv])
+        e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), ("device batch, fresh", histogram3(want))
+        used += e.fused_counts_ex()["bulk_units"]
+        for Kq, Rq, tq, m in vv:
+            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), "host masks, stored state"
+        inv = [(Kq, Rq, tq, np.invert(m)) for Kq, Rq, tq, m in vv]
+        for Kq, Rq, tq, m in inv:
+            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), oracle_c.carve(sh, origin, vs, vv + inv, default_value, nthreads=4))
+        e.dev_free(ptr)
+        e.close()
+    if default_value != -1:
+        assert used > 0, "no unit ever took the bulk path"
 
 
 def test_fused_compaction_with_slab_and_default_values(gpu_device):
