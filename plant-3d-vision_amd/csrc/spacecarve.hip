@@ -107,8 +107,12 @@ struct ListCtl {
                                  // that keep the same block (fewer than 6 views: no survivor stages) need no memset
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
     uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
-    uint32_t ncand;              // FULL candidates the flags kernel left open (the confirm kernel has work)
-    uint32_t pad[25];
+    uint32_t pad[26];
+    ListCounter cand;            // .n non-zero: the flags kernel left FULL candidates open (the confirm kernel has work).
+                                 // A flag on a line of its own, read before it is written: as a count (an atomic per
+                                 // block, 11 ns each on one address) it cost 22 us when every brick is a candidate,
+                                 // and as a plain store on the line of the live-brick counter it doubled that
+                                 // kernel's time on a bulky object (the atomics on `nlive` waited behind the stores)
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? (saw ? 2 : 6) : (saw ? 3 : 7)) : 0));
     if (nall < nbatch) {  // grid-uniform: later views are not packed yet, kept bricks are candidates
         const unsigned long long mc = __ballot(inb && !isdead && !gone && kept);
-        if (mc != 0 && lane == 0) atomicAdd(&ctl->ncand, (uint32_t)__popcll(mc));
+        if (mc != 0 && lane == 0 && ctl->cand.n == 0u) ctl->cand.n = 1u;
     }
     if (valid && dead != nullptr && (gone || dead_stale)) dead[lb] = gone ? 1 : 0;
     // the bricks left go on the live list, one atomic per block
@@ -1256,7 +1260,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void unit_verdict_kernel(GridDesc 
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
-    if (v0 >= v1 || ctl->ncand == 0) return;  // no view was packed late, or the flags kernel left no candidate open
+    if (v0 >= v1 || ctl->cand.n == 0) return;  // no view was packed late, or the flags kernel left no candidate open
     __shared__ unsigned long long s_full[kFlagWaves], s_seen[kFlagWaves];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t per_plane = bricks_y * bricks_z;

@@ -27,9 +27,10 @@ def voxel_pixels(shape, origin, vs, K, R, t):
         return pz, ((px / pz) * K[0]) + K[2], ((py / pz) * K[1]) + K[3]
 
 
-def brick_box(origin, vs, K, R, t, i, j0, k0, info=None):
-    """The kernel's bounding box of brick (plane i, columns j0.., voxels k0..): None if it gives up,
-    else (umin, umax, vmin, vmax) AFTER widening, with the estimate-error allowance removed.
+def brick_box(origin, vs, K, R, t, i, j0, k0, info=None, nj=BY, nk=BZ):
+    """The kernel's bounding box (``rect_box``) of the rectangle of voxels (plane i, columns j0 .. j0 + nj - 1,
+    voxels k0 .. k0 + nk - 1; a brick by default): None if it gives up, else (umin, umax, vmin, vmax) AFTER
+    widening, with the estimate-error allowance removed.
     `info` (a dict) receives `behind`: every corner deeper than 4 ez behind the camera."""
     R = np.asarray(R, dtype=F).reshape(9); t = np.asarray(t, dtype=F).reshape(3); K = np.asarray(K, dtype=F).reshape(4)
     x = F(F(origin[0]) + F(i) * F(vs))
@@ -38,8 +39,8 @@ def brick_box(origin, vs, K, R, t, i, j0, k0, info=None):
     pzmax = F(-np.inf)
     with np.errstate(all="ignore"):
         for c in range(4):
-            y = F(F(origin[1]) + F(j0 + (BY - 1 if c >> 1 else 0)) * F(vs))
-            z = F(F(origin[2]) + F(k0 + (BZ - 1 if c & 1 else 0)) * F(vs))
+            y = F(F(origin[1]) + F(j0 + (nj - 1 if c >> 1 else 0)) * F(vs))
+            z = F(F(origin[2]) + F(k0 + (nk - 1 if c & 1 else 0)) * F(vs))
             rzx, rzy, rzz = R[6] * x, R[7] * y, R[8] * z
             rxx, rxy, rxz = R[0] * x, R[1] * y, R[2] * z
             ryx, ryy, ryz = R[3] * x, R[4] * y, R[5] * z
@@ -142,11 +143,11 @@ def test_corner_box_random_cameras(seed):
     assert accepted > 0
 
 
-def brick_outside(origin, vs, K, R, t, W, H, i, j0, k0):
+def brick_outside(origin, vs, K, R, t, W, H, i, j0, k0, nj=BY, nk=BZ):
     """The kernel's OUTSIDE verdict (brick_footprint): every corner well behind the camera, or the brick
     in front and its widened box entirely left of -1, right of W, above -1 or below H."""
     info = {}
-    box = brick_box(origin, vs, K, R, t, i, j0, k0, info)
+    box = brick_box(origin, vs, K, R, t, i, j0, k0, info, nj=nj, nk=nk)
     if info.get("behind"):
         return True
     if box is None:
@@ -185,3 +186,89 @@ def test_outside_verdict_means_no_voxel_is_touched(seed):
                     elif touched[sl].any():
                         inside_some += 1
     assert outside > 0 and inside_some > 0, (outside, inside_some)
+
+
+# ---- units (a wavefront's share of a brick: 16 columns x 16 voxels) and the cell level ---------------------
+
+UJ, UK = 16, 16
+
+
+def cell_masks(mask):
+    """Restatement of what ``pack16_block`` records per 32x32 tile: a 4x4 map of its 8x8-pixel cells, bit
+    cy * 4 + cx of `fg` = the cell holds some foreground, of `bg` = some background (padding is background)."""
+    H, W = mask.shape
+    ty, tx = (H + 31) // 32, (W + 31) // 32
+    pad = np.zeros((ty * 32, tx * 32), dtype=bool)
+    pad[:H, :W] = mask != 0
+    cells = pad.reshape(ty * 4, 8, tx * 4, 8)
+    return cells.any(axis=(1, 3)), (~cells).any(axis=(1, 3))  # [cells_y][cells_x] each
+
+
+def unit_verdict(origin, vs, K, R, t, W, H, fg, bg, i, j0, k0):
+    """``rect_verdict_cells`` on a unit: 4 OUTSIDE, 1 EMPTY, 2 FULL, 0 undecided."""
+    if brick_outside(origin, vs, K, R, t, W, H, i, j0, k0, nj=UJ, nk=UK):
+        return 4
+    box = brick_box(origin, vs, K, R, t, i, j0, k0, nj=UJ, nk=UK)
+    if box is None:
+        return 0
+    # the kernel widens by MORE than `box` (the estimate allowance was taken off): test the larger box the
+    # other way round -- inside the picture with the full slack -- by asking for the smaller one plus 1 px
+    umin, umax, vmin, vmax = box
+    if not (umin - 1 >= 0 and umax + 1 <= W - 1 and vmin - 1 >= 0 and vmax + 1 <= H - 1):
+        return 0
+    cx0, cx1, cy0, cy1 = int(umin - 1) >> 3, int(umax + 1) >> 3, int(vmin - 1) >> 3, int(vmax + 1) >> 3
+    if not fg[cy0:cy1 + 1, cx0:cx1 + 1].any():
+        return 1
+    if not bg[cy0:cy1 + 1, cx0:cx1 + 1].any():
+        return 2
+    return 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_unit_verdicts_at_the_cell_level_hold_for_every_voxel(seed):
+    """Whenever the restated cell-level verdict calls a 16 x 16-voxel unit EMPTY / FULL / OUTSIDE for a view, the
+    reference arithmetic lands every voxel of it in-image on a zero pixel / on a non-zero pixel / nowhere
+    (backprojection.c:13,23-31,79-83) -- discs and bars of foreground at all scales, cameras near and far."""
+    rng = np.random.default_rng(9000 + seed)
+    shape = (2, int(rng.integers(10, 60)), int(rng.integers(10, 120)))
+    vs = float(rng.choice([0.25, 1.0, 3.0]))
+    origin = (rng.normal(size=3) * 50.0).astype(F)
+    extent = max(shape) * vs
+    center = origin + np.array(shape) * vs / 2.0
+    seen = {1: 0, 2: 0, 4: 0, 0: 0}
+    for _ in range(10):
+        R, t = _random_pose(rng, center, extent)
+        w, h = int(rng.integers(40, 700)), int(rng.integers(40, 500))
+        f = float(w * rng.choice([0.5, 1.0, 3.0]))
+        K = np.array([f, f * rng.uniform(0.8, 1.25), w * rng.choice([0.5, 0.3, 0.9]), h * rng.choice([0.5, 0.7])], dtype=F)
+        yy, xx = np.mgrid[0:h, 0:w]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            mask = ((yy - h * rng.uniform(0.2, 0.8)) ** 2 + (xx - w * rng.uniform(0.2, 0.8)) ** 2) < (rng.uniform(0.1, 0.6) * min(w, h)) ** 2
+        elif kind == 1:
+            mask = (xx > w * rng.uniform(0.2, 0.6)) & (yy < h * rng.uniform(0.4, 0.9))
+        elif kind == 2:
+            mask = np.ones((h, w), dtype=bool)
+        else:
+            mask = np.zeros((h, w), dtype=bool)
+        mask = mask.astype(np.uint8) * np.uint8(255)
+        fg, bg = cell_masks(mask)
+        pz, uf, vf = voxel_pixels(shape, origin, vs, K, R, t)
+        with np.errstate(invalid="ignore"):
+            touched = ~(pz < 0) & (uf > -1) & (uf < w) & (vf > -1) & (vf < h)
+        ui = np.where(touched, uf, 0).astype(np.int64).clip(0, w - 1)  # (-1, 0) truncates to 0
+        vi = np.where(touched, vf, 0).astype(np.int64).clip(0, h - 1)
+        pix = mask[vi, ui]
+        for i in range(shape[0]):
+            for j0 in range(0, shape[1], UJ):
+                for k0 in range(0, shape[2], UK):
+                    sl = (i, slice(j0, min(shape[1], j0 + UJ)), slice(k0, min(shape[2], k0 + UK)))
+                    v = unit_verdict(origin, vs, K, R, t, w, h, fg, bg, i, j0, k0)
+                    seen[v] += 1
+                    if v == 4:
+                        assert not touched[sl].any(), (seed, "outside", i, j0, k0)
+                    elif v == 1:
+                        assert touched[sl].all() and (pix[sl] == 0).all(), (seed, "empty", i, j0, k0)
+                    elif v == 2:
+                        assert touched[sl].all() and (pix[sl] != 0).all(), (seed, "full", i, j0, k0)
+    assert seen[1] + seen[2] + seen[4] > 0
