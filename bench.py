@@ -12,9 +12,10 @@ Workload (config.workload): BASELINE cfg 3, 512^3 voxels x 72 views, scene S1 "p
 BASELINE cfg 4, 1024^3) whose x-planes are dealt round-robin over the ranks, so every rank
 carves ~512^3 voxels holding the same share of the object; the carve itself needs no collective
 (voxels are independent).  For N > 1 the line carries BOTH ``value`` (carve only) and
-``value_with_assembly`` (carve + int8 all-gather of the labels into global order on every GPU,
-SURVEY 8d's ``t_device + collective``), plus the time of ``gather_to_host`` (the reference's
-``get_values``, cl.py:229-232).
+``value_with_assembly`` (carve + all-gather of the labels at 2 bits each + one kernel that unpacks
+them into global order on every GPU, SURVEY 8d's ``t_device + collective``), the time of
+``gather_to_host`` (the reference's ``get_values``, cl.py:229-232), and ``strong``: BASELINE's own
+metric -- ONE 512^3 x 72 grid split over the N ranks -- with and without the assembly.
 
 Beside the headline, in the same line (N = 1):
   stream   one launch per view as the reference does (cl.py:223-226), the formulation SURVEY 8d's
@@ -23,7 +24,10 @@ Beside the headline, in the same line (N = 1):
            foreground: no all-empty / all-white shortcut applies to most of it);
   average  the `average` kernel (backprojection.c:36-55) on uint8 binary, uint8 grey and float32
            masks, against the VALU issue roofline;
-  cpu_baseline  the oracle on this box's host cores, on a bounded sample of the same workload.
+  e2e      the reference's real interface (cl.py:190-232): 72 uint8 masks in HOST memory through
+           ``process_view`` to int32 labels in HOST memory (PCIe both ways; never ``value``);
+  cpu_baseline  the oracle on this box's host cores, on a bounded sample of the same workload (S1, and
+           S2 "solid" beside it), and the NumPy float32 per-view restatement at cfg 1 (128^3 x 12).
 The ``roofline`` object describes the ``value`` path with ITS OWN algorithmic bytes;
 ``equiv_streaming_note`` restates its speed in units of the streaming roofline (a speed ratio,
 never an HBM-utilisation claim -- SURVEY 8d honesty guard).
@@ -74,6 +78,8 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=10, help="steps per extra scene / averaging form (0 = skip)")
     ap.add_argument("--assembly-steps", type=int, default=20, help="N > 1: steps of carve + all-gather")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--e2e-reps", type=int, default=3, help="host masks -> host labels repetitions (0 = skip)")
+    ap.add_argument("--strong-steps", type=int, default=20, help="N > 1: steps of the 512^3 grid split over the ranks")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--skip-other-path", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option KEY=VALUE (sc_set_option)")
@@ -190,7 +196,32 @@ def cpu_baseline(shape, origin, vs, views, budget_s):
     p1 = max(1, min(nx, planes // 16))
     t1 = run(p1)
     cores = cores_all
-    return {"value": vv / t / 1e6, "unit": "Mvoxel*views/s", "cores": cores, "kind": "port",
+    extra = {}
+    if budget_s >= 4:
+        # S2 "solid" (all-foreground masks: nothing is ever carved, every voxel does every view), a quarter of the budget
+        from plant3dvision_amd import scenes as _sc
+        _, _, _, sviews = _sc.make_scene(tuple(shape), V, "solid")
+        full32 = np.ascontiguousarray(sviews[0][3], dtype=np.int32)
+        p2 = max(1, min(nx, int(planes * 0.25 * budget_s / max(t, 1e-3) / 4)))  # S2 never stops early: ~4x the work per voxel
+        i0 = (nx - p2) // 2
+        vol = oracle_c.OracleVolume(shape, origin, vs, "carving", 0)
+        t0 = time.perf_counter()
+        for (K, R, tq, _) in sviews:
+            vol.process_view(K, R, tq, full32, nthreads=cores, begin=i0 * plane, end=(i0 + p2) * plane)
+        t2 = time.perf_counter() - t0
+        extra["s2"] = {"value": p2 * plane * V / t2 / 1e6, "unit": "Mvoxel*views/s", "cores": cores,
+                       "sample": f"S2 'solid': {p2} central X-planes x {V} views in {t2:.2f} s"}
+        # the "NumPy fallback" BASELINE cfg 1 alludes to (the reference has none): float32, one vectorised pass
+        # per view over the whole 128^3 grid, 12 views, single process (oracle/oracle_np.py)
+        from oracle import oracle_np
+        sh1, o1, vs1, v1 = _sc.make_scene(128, 12, "plant")
+        t0 = time.perf_counter()
+        lab = oracle_np.carve(sh1, o1, vs1, v1)
+        t3 = time.perf_counter() - t0
+        extra["numpy_cfg1"] = {"value": int(np.prod(sh1)) * len(v1) / t3 / 1e6, "unit": "Mvoxel*views/s", "cores": 1,
+                               "seconds": t3, "sample": "BASELINE cfg 1: 128^3 x 12 views, scene S1, oracle/oracle_np.py "
+                               "(NumPy float32, one ufunc per operation)", "carved": int((lab == -1).sum())}
+    return {**extra, "value": vv / t / 1e6, "unit": "Mvoxel*views/s", "cores": cores, "kind": "port",
             "sample": f"{planes} central X-planes of the {nx}x{ny}x{nz} grid x {V} views "
                       f"({vv / 1e6:.0f} Mvoxel*views in {t:.2f} s, mean of {reps} run(s)), "
                       f"oracle/spacecarve_oracle.c, int32 masks as cl.py:215, {cores} threads of "
@@ -226,6 +257,9 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
         K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
         fg = float(np.mean([(m != 0).mean() for _, _, _, m in views]))
         eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
+        # another scene on the same engine: what the engine learnt about the last one (whether the bulk units'
+        # verdicts pay, SC_OPT_BULK_ADAPT) does not carry over -- a Voxels run builds its engine per scan
+        eng.set_option(nat.SC_OPT_BULK_ADAPT, 1)
 
         def step():
             eng.clear()
@@ -317,50 +351,133 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
     return out
 
 
-def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V):
-    """N > 1: carve + the labels in global order on every GPU (int8 all-gather over xGMI + one
-    strided copy), barrier + synchronize on both sides, MAX over ranks; then gather_to_host once."""
+def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
+    """N > 1: carve + the labels in global order on every GPU (all-gather over xGMI at 2 bits per label + ONE
+    kernel that unpacks and interleaves; the int8 form of round 2 beside it), barrier + synchronize on both
+    sides, MAX over ranks; then gather_to_host once."""
     world = sb.world_size
-    pad = sb._planes_max() * sb.shape[1] * sb.shape[2]
     dev = torch.device("cuda", eng.device)
-    recv = torch.empty(pad * world, dtype=torch.int8, device=dev)
-    out = torch.empty(pad * world, dtype=torch.int8, device=dev)
-
-    def step():
-        eng.clear()
-        eng.process_views_device(*call, nat.SC_MASK_U8)
-        return sb.all_gather(compress=True, widen=False, recv=recv, out=out)
+    n_grid = int(np.prod(sb.shape))
 
     def maxed(dt):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def run(step, nsteps):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            full = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = maxed(time.perf_counter() - t0)
+        del full
+        return dt
+
     eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        full = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = maxed(time.perf_counter() - t0)
-    res = {"kind": "int8 all-gather of the labels + plane interleave into global order on every GPU "
-                   "(labels stay int8 on the device; vol2pcd takes 1-byte volumes)",
+    recv2 = torch.empty(sb.packed_rank_bytes(2) * world, dtype=torch.uint8, device=dev)
+    out8 = torch.empty(n_grid, dtype=torch.int8, device=dev)
+
+    def step2():
+        eng.clear()
+        eng.process_views_device(*call, nat.SC_MASK_U8)
+        return sb.all_gather(compress="2bit", widen=False, recv=recv2, out=out8)
+
+    dt = run(step2, steps)
+    res = {"kind": "all-gather of the labels at 2 bits each + one kernel that unpacks them into global order on every "
+                   "GPU (int8 on the device; vol2pcd takes 1-byte volumes)",
            "steps": steps, "ms_per_step": dt / steps * 1e3,
            "value_with_assembly": n_total * V * steps / dt / 1e6,
-           "bytes_received_per_rank": int(recv.numel())}
-    del full
-    dist.barrier()
-    t0 = time.perf_counter()
-    host = sb.gather_to_host(dst=0)
-    dist.barrier()
-    res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
-    res["gather_to_host_note"] = "labels to rank 0's GPU over the collective as int8, one PCIe copy, widened to int32 on the host"
-    del host
+           "bytes_received_per_rank": int(recv2.numel())}
+    del recv2
+    # the int8 wire form (round 2), a few steps, for comparison
+    pad = sb._planes_max() * sb.shape[1] * sb.shape[2]
+    recv = torch.empty(pad * world, dtype=torch.int8, device=dev)
+    out = torch.empty(pad * world, dtype=torch.int8, device=dev)
+
+    def step8():
+        eng.clear()
+        eng.process_views_device(*call, nat.SC_MASK_U8)
+        return sb.all_gather(compress=True, widen=False, recv=recv, out=out)
+
+    n8 = max(2, steps // 4)
+    dt8 = run(step8, n8)
+    res["int8_wire"] = {"ms_per_step": dt8 / n8 * 1e3, "steps": n8, "bytes_received_per_rank": int(recv.numel())}
+    del recv, out, out8
+    if host:
+        dist.barrier()
+        t0 = time.perf_counter()
+        hostvol = sb.gather_to_host(dst=0)
+        dist.barrier()
+        res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
+        res["gather_to_host_note"] = "labels to rank 0's GPU over the collective as int8, one PCIe copy, widened to int32 on the host"
+        del hostvol
     return res
+
+
+def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, steps):
+    """BASELINE.json's metric literally: ONE 512^3 x 72 grid (cfg 3) split over the N ranks (x-planes dealt
+    round-robin), carve only and carve + assembly; barrier + synchronize on both sides, MAX over ranks."""
+    gshape, origin, vs, views = scenes.make_scene((a.n,) * 3, a.views, a.scene)
+    V = len(views)
+    H, W = views[0][3].shape
+    sb = ShardedBackprojection(gshape, origin, vs, rank=rank, world_size=world, device=local_rank)
+    sb.force_collective = bool(a.rccl_rehearsal)
+    eng = sb.engine
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    masks_dev = eng.dev_alloc(stack.nbytes)
+    eng.dev_upload(masks_dev, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    call = (K, R, t, masks_dev, V, H, W)
+    n_total = int(np.prod(gshape))
+    run_steps(eng, nat, *call, 3, 0)
+    eng.synchronize()
+    dt, _ = timed(eng, nat, torch, dist, call, steps, 0, world, time_kernels="span")
+    asm = assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=False)
+    out = {"workload": f"ONE {a.n}^3 x {V} grid split over {world} rank(s), x-planes cyclic ({len(sb.planes)} planes per rank)",
+           "value": n_total * V * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "value_with_assembly": asm["value_with_assembly"], "ms_per_step_with_assembly": asm["ms_per_step"],
+           "unit": "Mvoxel*views/s", "scaling": "strong", "assembly": asm}
+    eng.dev_free(masks_dev)
+    sb.close()
+    return out
+
+
+def e2e_host(a, shape, origin, vs, views, device, reps):
+    """The reference's real interface (cl.py:190-232): V uint8 masks in HOST memory, one ``process_view`` each,
+    then ``get_values``: int32 labels in HOST memory -- mask upload and label read-back over PCIe included
+    (SURVEY 8d ``t_e2e``).  Through the drop-in class, plant-3d-vision_amd/cl.py."""
+    from plant3dvision_amd.cl import Backprojection
+    bp = Backprojection(list(shape), origin, vs, device=device)
+    V = len(views)
+
+    def run():
+        bp.clear()
+        for K, R, t, m in views:
+            bp.process_view(K, R, t, m)
+        return bp.get_values()
+
+    vol = run()  # warm-up: allocations, the pinned ring, touched pages
+    hist = [int((vol == -1).sum()), int((vol == 0).sum()), int((vol == 1).sum())]
+    ts = []
+    for _ in range(reps):
+        bp.recycle(vol)
+        del vol
+        t0 = time.perf_counter()
+        vol = run()
+        ts.append(time.perf_counter() - t0)
+    bp.close()
+    n = int(np.prod(shape))
+    best = min(ts)
+    return {"ms": best * 1e3, "ms_all": [x * 1e3 for x in ts], "value": n * V / best / 1e6, "unit": "Mvoxel*views/s",
+            "reps": reps, "labels_histogram": hist,
+            "note": f"{V} uint8 masks in host memory -> Backprojection.process_view x {V} -> get_values(): int32 "
+                    f"[{shape[0]}][{shape[1]}][{shape[2]}] in host memory; PCIe both ways (labels cross as int8 and are "
+                    f"widened on host threads); best of {reps}"}
 
 
 def main():
@@ -469,6 +586,12 @@ def main():
         asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
         if world == 1:
             asm["rehearsal"] = "process group of one rank on one GPU: the collectives move nothing over xGMI"
+    strong = None
+    if collective and a.strong_steps > 0 and a.path == "fused":
+        strong = strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, a.strong_steps)
+    e2e = None
+    if world == 1 and not a.rccl_rehearsal and a.e2e_reps > 0 and a.path == "fused":
+        e2e = e2e_host(a, gshape, origin, vs, views, local_rank, a.e2e_reps)
     extras = avg = None
     if world == 1 and a.extra_steps > 0 and a.path == "fused":
         extras = extra_scenes(a, nat, torch, eng, gshape, masks_dev, a.extra_steps)
@@ -524,7 +647,10 @@ def main():
             kernel = "carve_kernel_1<false>"
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
+             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+             "traffic_source": (os.path.relpath(a.traffic_json, ROOT) + " (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                "passes, tools/profile_gpu.sh; not measured in this run)") if traffic is not None else None,
+             "kernel": kernel,
              "avg_launch_ms": avg_ms, "launches": launches,
              "algorithmic_bytes_per_launch": bytes_launch, "bytes_model": model,
              "voxel_views_per_launch": units}
@@ -562,7 +688,8 @@ def main():
                                    f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
                        "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
                        "parallelism": f"x-planes cyclic over {world} rank(s); `value` has no collective, "
-                                      f"`value_with_assembly` adds the int8 all-gather",
+                                      f"`value_with_assembly` adds the 2-bit all-gather + unpack; `strong` splits ONE "
+                                      f"{a.n}^3 grid over the ranks",
                        "path": a.path, "views_per_launch": V if a.path == "fused" else 1,
                        "arithmetic": "float32 projection (no contraction, correctly rounded divide) into int32 labels"},
             "roofline": roof(a.path, stats, traffic_for(a.path)),
@@ -579,6 +706,10 @@ def main():
         if asm is not None:
             out["value_with_assembly"] = asm["value_with_assembly"]
             out["assembly"] = asm
+        if strong is not None:
+            out["strong"] = strong
+        if e2e is not None:
+            out["e2e"] = e2e
         if extras is not None:
             out["scenes"] = extras
         if avg is not None:

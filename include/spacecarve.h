@@ -71,61 +71,11 @@ extern "C" {
                                      around each fused batch, SC_KERNEL_STEP (an event pair costs
                                      a few microseconds of stream time)                       */
 #define SC_OPT_MAX_PENDING 4      /* deferred views that force a flush (default 256)          */
-#define SC_OPT_COMPACT 5          /* carve only. 1 (default): a fused launch of >= 6 views is dense
-                                     for its first two views, then finishes the survivors from
-                                     compacted lists; 0: every view is applied densely           */
-
-/* tuning knobs of the fused carve (defaults in parentheses); results never depend on them */
-#define SC_OPT_DENSE_VIEWS 6      /* views applied to every voxel before compaction (2)       */
-#define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
-#define SC_OPT_LIST_BLOCKS 8      /* persistent grid of the list / resume kernels (2048)      */
-#define SC_OPT_VIEW_GROUP 9       /* views per work item in the final survivor stage (16)     */
-#define SC_OPT_BRICK 10           /* 1 (default): for grids with nz <= 4096 and < 2^31 voxels the dense stage
-                                     works on 16x64-voxel bricks with a conservative emptiness
-                                     test per brick; 0: linear blocks only                       */
-#define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
-#define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
-#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1024): the -1 fill of bricks found empty is done by
-                                     store blocks running beside n persistent blocks of the final
-                                     survivor stage; 0: by the dense stage                          */
-#define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
-#define SC_OPT_FULL_BRICKS 19     /* 1 (default): a brick EVERY view of the batch sees whole, in-image, over
-                                     foreground only gets its labels (0 -> 1) without projecting a voxel */
-#define SC_OPT_AVG_BRICK 20       /* averaging. 1 (default): bricks whose footprint in a view is flat (all 0 / all 255 bytes,
-                                     or one float32 value) add that view's value without projecting          */
-#define SC_OPT_AVG_TILE_F32 29     /* averaging with float32 masks. 1 (default): the masks are re-laid in 8x4-pixel tiles
-                                     (one 128-byte line each) with per-region uniformity, and take the brick
-                                     form too (a footprint over ONE value adds it without projecting);
-                                     0: gathered row-major as handed over                                  */
-#define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
-#define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
-#define SC_OPT_PACK_RIDE 22        /* 1 (default): a batch of device-resident 1-byte masks (sc_process_views_device)
-                                     is packed when it is launched, in the order its views are applied: the
-                                     first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
-#define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
-#define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
-                                     that many persistent blocks walking the strips (512 = two per CU: a
-                                     wavefront's stores do not hold it up, so few keep the write path busy) */
-#define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1, 2 (default) or 4         */
-#define SC_OPT_VIEW_BRICK 26        /* 1 (default): a launch of ONE view (the reference's cadence, cl.py:223-226)
-                                     uses the brick verdicts too: bricks the view sees whole over background
-                                     are carved blind and skipped by later views; 0: the streaming kernel
-                                     (every view reads the whole state: the north star's formulation)          */
-#define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1, 2 (default) or 4                  */
-#define SC_OPT_RESERVE_EVENTS 31    /* with SC_OPT_TIME_KERNELS: create n HIP events now (0..65536) so that the timed
-                                       launches that follow find them in the engine's pool instead of creating them */
-#define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
-#define SC_OPT_BULK_MIN 32        /* a wavefront's share of a live brick (a UNIT: 4 columns x 64 voxels) with at least this
-                                     many voxels alive after the dense views is asked about as a whole: every remaining
-                                     view at once, one view per lane, over 8x8-pixel cells of the masks; only the
-                                     undecided views project its voxels (128; 0 = never)                          */
-#define SC_OPT_ITEM_BIAS 33       /* sixteenths (12): a unit's undecided (half, 8 views) pairs become work items of the
-                                     final stage when they number at most this share of what its voxels would cost in
-                                     the survivor lists; otherwise the voxels take the lists                      */
-#define SC_OPT_UNIT_BLOCKS 34     /* blocks of 8 wavefronts giving the units their verdicts (512)                  */
-#define SC_OPT_BULK_ADAPT 35      /* 1 (default): the engine looks at what the units' verdicts of its last batches spared
-                                     the survivor stages and leaves the bulk list out for 64 batches when that was less
-                                     than they cost (a thin plant); 0: always on                                   */
+#define SC_OPT_RESERVE_EVENTS 31  /* with SC_OPT_TIME_KERNELS: create n HIP events now (0..65536) so that the timed
+                                     launches that follow find them in the engine's pool instead of creating them */
+/* The fused carve's tuning knobs (SC_OPT_COMPACT .. SC_OPT_BULK_ADAPT: where work moves between its kernels; results
+ * never depend on them) are sc_set_option keys too, declared in spacecarve_tuning.h -- not part of what a caller of
+ * the reference's interface needs. */
 
 /* kernel ids for sc_kernel_stats */
 #define SC_KERNEL_CARVE 0
@@ -197,6 +147,12 @@ int sc_set_stream(sc_engine *e, void *hip_stream);
  * queue (cl.py:29-30) has no such hazard. */
 int sc_order_after(sc_engine *e, void *producer_stream);
 
+/* The other direction: everything enqueued from now on on `consumer_stream` (NULL = the legacy default stream)
+ * runs AFTER the work the engine has enqueued so far -- for a consumer on another stream of what the engine
+ * leaves in device memory (sc_values_device_ptr, sc_values_packed), and for a producer who wants to reuse a
+ * buffer handed to sc_process_views_device, without waiting on the host. */
+int sc_order_before(sc_engine *e, void *consumer_stream);
+
 /*
  * Backprojection.process_view (cl.py:190-227): one view from a HOST mask.
  * The mask is consumed before the call returns (the caller may free it); the kernel
@@ -213,8 +169,10 @@ int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const 
 
 /*
  * V views whose masks are already resident in device memory on the engine's device,
- * contiguous [V][H][W] (the Masks2D / bench path: no host round trip).  The buffer must
- * stay valid until the next sc_flush / sc_get_values / sc_synchronize returns.
+ * contiguous [V][H][W] (the Masks2D / bench path: no host round trip).  The masks are read on the
+ * engine's stream when the batch is launched (a fused batch packs them at the flush, part of them beside its
+ * dense stage), and sc_flush only enqueues: the buffer must stay valid AND UNCHANGED until sc_synchronize or
+ * sc_get_values* returns -- or until the caller has ordered its own stream behind the engine's work.
  */
 int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R, const float *t,
                             const void *masks_dev, int H, int W, int mask_dtype);
@@ -237,9 +195,31 @@ int sc_get_values(sc_engine *e, void *out);
  */
 int sc_get_values_i8(sc_engine *e, int8_t *out);
 
-/* Flush and return the device pointer of the state slab (valid until sc_destroy);
- * work may still be running on the engine's stream. */
+/* Flush and return a device pointer to the engine's values as planes * ny * nz contiguous elements; work may
+ * still be running on the engine's stream.  When nz is a multiple of 64 this IS the state (valid until
+ * sc_destroy, and it changes as views are applied, like the reference's buffer); otherwise the state's rows are
+ * padded and the pointer is a SNAPSHOT without the padding, made on the engine's stream by this call: valid
+ * until the next call that changes the state or takes another snapshot. */
 int sc_values_device_ptr(sc_engine *e, void **ptr);
+
+/*
+ * Carve labels packed for the wire (multi-GPU assembly; no reference counterpart -- the reference
+ * is single-device).  bits = 2: the three states, label & 3 (-1 -> 3, 0 -> 0, 1 -> 1; SC_ERR_STATE unless
+ * default_value is one of them); bits = 1: the occupancy the consumer binarises to (label == 1, proc3d.py:515).
+ * Voxel v of the engine's voxels (its planes in its own order, no padding) is at bit  bits * (v % (32 / bits))
+ * of 32-bit word  v / (32 / bits).  sc_values_packed flushes, packs on the engine's stream into an engine-owned
+ * device buffer (valid until the next sc_values_packed / sc_destroy; work may still be running) and returns it
+ * with its size, sc_packed_bytes(voxels, bits): whole 16-byte groups.  sc_get_values_packed copies the words to
+ * the host.  sc_unpack_labels is the other end of an all-gather of such buffers: `world` ranks' buffers
+ * rank_bytes apart (rank r's planes are r, r + world, ... of the grid: partition 0; or the slab
+ * [nx r / world, nx (r + 1) / world): partition 1) into ONE [nx][ny][nz] grid in global order on `device`,
+ * as int8 (out_bytes 1) or int32 (4), on hip_stream (NULL: the legacy default stream).
+ */
+int64_t sc_packed_bytes(int64_t voxels, int bits);
+int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes);
+int sc_get_values_packed(sc_engine *e, int bits, void *out);
+int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
+                     int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes);
 
 /* number of voxels this engine owns */
 int64_t sc_num_voxels(const sc_engine *e);
@@ -317,8 +297,9 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
                const double gauss_w[5], int device, double **points_out, double **normals_out,
                int64_t *count);
 const char *sc_vol2pcd_last_error(void);
-/* sc_vol2pcd keeps its device work buffers (49 bytes per voxel of the largest volume seen, per device) between
- * calls; this gives them back. */
+/* sc_vol2pcd keeps its device work buffers (49 bytes per voxel, per device) between calls while they are at most
+ * 1 GiB (larger ones are freed when the call ends); this gives back what is kept.  The caller's current HIP
+ * device is left as it was. */
 void sc_vol2pcd_release(void);
 void sc_free_host(void *p);
 
@@ -370,6 +351,9 @@ const char *sc_png_last_error(void);
  * in sc_create_cyclic / sc_create_slab.  Every view goes to every engine; sc_group_get_values writes
  * the whole [nx][ny][nz] grid in global order (one strided device-to-host copy per device).  The
  * one-process-per-GPU form of the same sharding is plant-3d-vision_amd/sharded.py over RCCL.
+ * A view's arguments are judged once, before any engine takes it.  Should a call still fail on some engine
+ * after others took it (a device error), the planes are in different states: the group then answers
+ * SC_ERR_STATE to everything but sc_group_clear (every engine back to default_value) and sc_group_destroy.
  */
 typedef struct sc_group sc_group;
 int sc_create_sharded(sc_group **out, int64_t nx, int64_t ny, int64_t nz, const float origin[3],

@@ -1,0 +1,65 @@
+/*
+ * spacecarve_tuning.h -- sc_set_option keys that only move work between the kernels of the fused carve /
+ * averaging launch (defaults in parentheses).  RESULTS NEVER DEPEND ON THEM
+ * (tests/test_parity_gpu.py::test_fused_pipeline_knobs_never_change_a_label, tools/fuzz_carve.py); they exist for
+ * the sweeps behind DESIGN.md 4 and for tests that force a path.  The numbers are part of the ABI like the keys of
+ * spacecarve.h (they share sc_set_option's key space) and are never renumbered.
+ */
+#ifndef SPACECARVE_TUNING_H
+#define SPACECARVE_TUNING_H
+
+#define SC_OPT_COMPACT 5          /* carve only. 1 (default): a fused launch of >= 6 views is dense
+                                     for its first two views, then finishes the survivors from
+                                     compacted lists; 0: every view is applied densely           */
+
+#define SC_OPT_DENSE_VIEWS 6      /* views applied to every voxel before compaction (2)       */
+#define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
+#define SC_OPT_LIST_BLOCKS 8      /* persistent grid of the resume kernel and of list stages without store blocks (2048) */
+#define SC_OPT_VIEW_GROUP 9       /* the spans of the final survivor stage are a multiple of this many views (2) */
+#define SC_OPT_BRICK 10           /* 1 (default): for grids with nz <= 4096 and < 2^31 voxels the dense stage
+                                     works on 16x64-voxel bricks with a conservative emptiness
+                                     test per brick; 0: linear blocks only                       */
+#define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
+#define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
+#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1024): the -1 fill of bricks found empty is done by
+                                     store blocks running beside n persistent blocks of the final
+                                     survivor stage; 0: by the dense stage                          */
+#define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
+#define SC_OPT_FULL_BRICKS 19     /* 1 (default): a brick EVERY view of the batch sees whole, in-image, over
+                                     foreground only gets its labels (0 -> 1) without projecting a voxel */
+#define SC_OPT_AVG_BRICK 20       /* averaging. 1 (default): bricks whose footprint in a view is flat (all 0 / all 255 bytes,
+                                     or one float32 value) add that view's value without projecting          */
+#define SC_OPT_AVG_TILE_F32 29     /* averaging with float32 masks. 1 (default): the masks are re-laid in 8x4-pixel tiles
+                                     (one 128-byte line each) with per-region uniformity, and take the brick
+                                     form too (a footprint over ONE value adds it without projecting);
+                                     0: gathered row-major as handed over                                  */
+#define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
+#define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
+#define SC_OPT_PACK_RIDE 22        /* 1 (default): a batch of device-resident 1-byte masks (sc_process_views_device)
+                                     is packed when it is launched, in the order its views are applied: the
+                                     first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
+#define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
+#define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
+                                     that many persistent blocks walking the strips (512 = two per CU: a
+                                     wavefront's stores do not hold it up, so few keep the write path busy) */
+#define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1, 2 (default) or 4         */
+#define SC_OPT_VIEW_BRICK 26        /* 1 (default): a launch of ONE view (the reference's cadence, cl.py:223-226)
+                                     uses the brick verdicts too: bricks the view sees whole over background
+                                     are carved blind and skipped by later views; 0: the streaming kernel
+                                     (every view reads the whole state: the north star's formulation)          */
+#define SC_OPT_STAGE1_VOXELS 30     /* ... in the survivor stages before it: 1, 2 (default) or 4                  */
+#define SC_OPT_FLAG_VIEWS 11      /* views of a batch that may declare a brick empty (8; 0 = all) */
+#define SC_OPT_BULK_MIN 32        /* a wavefront's share of a live brick (a UNIT: 16 columns x 16 voxels) with at least this
+                                     many voxels alive after the dense views is asked about as a whole: every remaining
+                                     view at once, one view per lane, over 8x8-pixel cells of the masks; only the
+                                     undecided views project its voxels (128; 0 = never)                          */
+#define SC_OPT_ITEM_BIAS 33       /* sixteenths (12): a unit's undecided views become work items of the final stage (half a
+                                     unit x up to 16 views each) when those cost at most this share of what its voxels
+                                     would cost in the survivor lists; otherwise the voxels take the lists        */
+#define SC_OPT_UNIT_BLOCKS 34     /* blocks of 8 wavefronts giving the units their verdicts (512)                  */
+#define SC_OPT_BULK_ADAPT 35      /* 1 (default): the engine looks at what the units' verdicts of its last batches spared
+                                     the survivor stages and leaves the bulk list out for 64 batches when that was less
+                                     than they cost (a thin plant); 0: always on                                   */
+
+
+#endif /* SPACECARVE_TUNING_H */

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "sc_set_option": ("i", ["p", "i", "q"]),
     "sc_set_stream": ("i", ["p", "p"]),
     "sc_order_after": ("i", ["p", "p"]),
+    "sc_order_before": ("i", ["p", "p"]),
     "sc_set_lut": ("i", ["p", "p"]),
     "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
@@ -64,6 +65,10 @@ _SIGNATURES = {
     "sc_get_values_i8": ("i", ["p", "p"]),
     "sc_values_device_ptr": ("i", ["p", "p"]),
     "sc_num_voxels": ("q", ["p"]),
+    "sc_packed_bytes": ("q", ["q", "i"]),
+    "sc_values_packed": ("i", ["p", "i", "p", "p"]),
+    "sc_get_values_packed": ("i", ["p", "i", "p"]),
+    "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_fused_counts": ("i", ["p", "p"]),
@@ -324,6 +329,18 @@ class TouchedEmpty:
         return self._arr
 
 
+def packed_bytes(voxels, bits):
+    """Bytes of ``voxels`` labels packed at ``bits`` bits each (whole 16-byte groups)."""
+    return int(backend().call("sc_packed_bytes", int(voxels), int(bits)))
+
+
+def unpack_labels(device, stream_ptr, recv_ptr, rank_bytes, world, partition, shape, bits, out_ptr, out_bytes):
+    """``sc_unpack_labels``: the ranks' packed planes (device memory) -> one grid in global order."""
+    check(backend().call("sc_unpack_labels", int(device), int(stream_ptr or 0), int(recv_ptr), int(rank_bytes), int(world),
+                         0 if partition == "cyclic" else 1, int(shape[0]), int(shape[1]), int(shape[2]), int(bits),
+                         int(out_ptr), int(out_bytes)), "sc_unpack_labels")
+
+
 def view_certified(shape, origin, voxel_size, K, R, t):
     """Does a view with this pose take the kernels' certified (cheaper, same results) projection path on
     this grid?  Host arithmetic only (``sc_view_certified``)."""
@@ -366,7 +383,10 @@ def png_decode_gray8(raw):
     if b.call("sc_png_info", addr(buf), int(buf.size), addr(wh), addr(wh) + 4) != SC_OK:
         return None
     W, H = int(wh[0]), int(wh[1])
-    out = np.empty((H, W), dtype=np.uint8)
+    try:
+        out = np.empty((H, W), dtype=np.uint8)
+    except MemoryError:  # a header that lies about the size: the usual reader gets the file (and its error)
+        return None
     if b.call("sc_png_decode_gray8", addr(buf), int(buf.size), addr(out), W, H) != SC_OK:
         return None
     return out
@@ -457,6 +477,11 @@ class Engine:
         (0 = the legacy default stream, e.g. torch's default stream)."""
         self._call("sc_order_after", int(stream_ptr or 0))
 
+    def order_before(self, stream_ptr):
+        """What ``stream_ptr`` (0 = the legacy default stream) is given from now on runs after everything the
+        engine has enqueued so far."""
+        self._call("sc_order_before", int(stream_ptr or 0))
+
     # -- work -------------------------------------------------------------------------
     def clear(self):
         self._call("sc_clear")
@@ -514,6 +539,20 @@ class Engine:
         out = np.zeros(1, dtype=np.uintp)
         self._call("sc_values_device_ptr", addr(out))
         return int(out[0])
+
+    def values_packed(self, bits=2):
+        """(device pointer, bytes) of the carve labels at ``bits`` (2 or 1) bits each (``sc_values_packed``)."""
+        ptr = np.zeros(1, dtype=np.uintp)
+        nbytes = np.zeros(1, dtype=np.int64)
+        self._call("sc_values_packed", int(bits), addr(ptr), addr(nbytes))
+        return int(ptr[0]), int(nbytes[0])
+
+    def get_values_packed(self, bits=2):
+        """The packed labels as a host array of 32-bit words."""
+        per = 32 // int(bits)
+        out = np.empty((self.num_voxels() + per - 1) // per, dtype=np.uint32)
+        self._call("sc_get_values_packed", int(bits), addr(out))
+        return out
 
     def num_voxels(self):
         return int(self._b.call("sc_num_voxels", self._h))

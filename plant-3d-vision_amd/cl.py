@@ -189,7 +189,7 @@ class Backprojection(object):
     dtype : numpy.int32 ("carving") or numpy.float32 ("averaging")   (cl.py:145-150)
     kernel : str, "carve" or "average" -- the HIP kernel that will run
     values_h : numpy.ndarray, host copy of the volume (refreshed by ``get_values``)
-    values_d : int, device address of the volume (None until first needed)
+    values_d : int, device address of the volume (a property: fetched when read; None before ``init_buffers``)
     """
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, labels=None,
@@ -225,7 +225,6 @@ class Backprojection(object):
         self._spare = None
         self._prefault = None
         self._narrow_h = None
-        self.values_d = None
         self.intrinsics_d = None
         self.rot_d = None
         self.tvec_d = None
@@ -348,8 +347,16 @@ class Backprojection(object):
             nat.widen_i8(self._values_h, self._narrow_h)
         else:
             self._engine.get_values(self._values_h)
-        self.values_d = self._engine.values_device_ptr()
         return self._values_h.reshape(self.shape)
+
+    @property
+    def values_d(self):
+        """Device address of the volume (the reference's ``values_d`` buffer, cl.py:175), fetched when asked for:
+        on a grid whose rows are padded on the device (nz not a multiple of 64) it is a snapshot without the
+        padding made by this call (``sc_values_device_ptr``), valid until the state changes."""
+        if getattr(self, "_engine", None) is None:
+            return None
+        return self._engine.values_device_ptr()
 
     def process_fileset(self, fs, camera_metadata, invert=False):
         """Processes a whole fileset (cl.py:234-257): one volume, or with ``labels`` a
@@ -455,3 +462,7 @@ class Backprojection(object):
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+            try:  # the consumer's cached device buffers go with the volume they were sized for
+                nat.backend().call("sc_vol2pcd_release")
+            except Exception:
+                pass

@@ -12,8 +12,10 @@
 #include <zlib.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "spacecarve.h"
@@ -38,6 +40,11 @@ int parse_header(const uint8_t *d, int64_t len, int *W, int *H) {
     const uint32_t w = be32(d + 16), h = be32(d + 20);
     const int depth = d[24], colour = d[25], comp = d[26], filt = d[27], interlace = d[28];
     if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) return png_fail("bad size");
+    // filter byte + row, all rows: below 2^31 (zlib counts its output in 32 bits; a mask is a few megabytes) and
+    // not absurd for the file at hand -- deflate cannot expand more than 1032 : 1, so a header that declares
+    // more pixels than that is not describing this file
+    const uint64_t need = ((uint64_t)w + 1) * (uint64_t)h;
+    if (need >= (1ull << 31) || need > (uint64_t)len * 1032ull + 65536ull) return png_fail("declared size does not fit the file");
     if (depth != 8 || colour != 0) return png_fail("not 8-bit greyscale");
     if (comp != 0 || filt != 0 || interlace != 0) return png_fail("interlaced or unknown method");
     *W = (int)w;
@@ -70,7 +77,13 @@ int sc_png_decode_gray8(const void *data, int64_t len, uint8_t *out, int W, int 
     if (w != W || h != H) return png_fail("size differs from the header");
     // inflate the concatenated IDAT chunks into filter-byte + row records
     const size_t stride = (size_t)W + 1;
-    std::vector<uint8_t> raw(stride * (size_t)H);
+    std::vector<uint8_t> raw;
+    try {
+        raw.resize(stride * (size_t)H);
+    } catch (const std::bad_alloc &) {  // never across the C boundary
+        snprintf(g_png_err, sizeof g_png_err, "out of memory for a %d x %d image", W, H);
+        return SC_ERR_NOMEM;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit(&zs) != Z_OK) return png_fail("inflateInit failed");

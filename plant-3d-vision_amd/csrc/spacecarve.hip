@@ -46,6 +46,7 @@
 #include <vector>
 
 #include "spacecarve.h"
+#include "spacecarve_tuning.h"
 
 namespace {
 
@@ -2395,6 +2396,110 @@ __global__ __launch_bounds__(kBlock) void depitch_kernel(const uint32_t *__restr
     }
 }
 
+// Carve labels packed for the wire (multi-GPU assembly): BITS = 2 keeps the three states (label & 3:
+// -1 -> 3, 0 -> 0, 1 -> 1), BITS = 1 the occupancy the consumer binarises to (label == 1: proc3d.py:515 reads
+// `volume > 0.5`); voxel v of the engine's planes * ny * nz voxels (no row padding) sits at bit BITS * (v % (32 /
+// BITS)) of word v / (32 / BITS).  One lane makes one word.  Rows that are whole words (nz % (32 / BITS) == 0)
+// are read as 16-byte groups, and a word that lies in a DEAD brick -- some launch found the brick empty, every
+// voxel is -1 until the next clear -- is written without reading its labels: on a plant 94 % of the volume.
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void pack_labels_kernel(const int32_t *__restrict__ labels, uint32_t *__restrict__ out,
+                                                             uint64_t n, uint32_t nz, uint32_t nzp, uint32_t ny,
+                                                             const uint8_t *__restrict__ dead, uint32_t bricks_y,
+                                                             uint32_t bricks_z) {
+    constexpr uint32_t PER = 32u / BITS;
+    const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t v0 = w * PER;
+    if (v0 >= n) return;
+    uint32_t word = 0;
+    const uint64_t row = v0 / nz;
+    const uint32_t k = (uint32_t)(v0 - row * nz);
+    if (nz % PER == 0 && v0 + PER <= n) {  // the word lies inside one row, 16-byte aligned in the pitched state
+        if (dead != nullptr) {
+            const uint32_t il = (uint32_t)(row / ny), j = (uint32_t)(row - (uint64_t)il * ny);
+            if (dead[(il * bricks_y + j / kBrickY) * bricks_z + k / kBrickZ]) {  // PER <= 32 divides 64: one brick
+                out[w] = BITS == 2 ? 0xffffffffu : 0u;
+                return;
+            }
+        }
+        const int4 *src = reinterpret_cast<const int4 *>(labels + row * nzp + k);
+#pragma unroll
+        for (uint32_t q = 0; q < PER / 4; ++q) {
+            const int4 a = src[q];
+            if (BITS == 2)
+                word |= (((uint32_t)a.x & 3u) | (((uint32_t)a.y & 3u) << 2) | (((uint32_t)a.z & 3u) << 4) | (((uint32_t)a.w & 3u) << 6)) << (8 * q);
+            else
+                word |= ((a.x == 1 ? 1u : 0u) | (a.y == 1 ? 2u : 0u) | (a.z == 1 ? 4u : 0u) | (a.w == 1 ? 8u : 0u)) << (4 * q);
+        }
+    } else {
+        uint64_t r = row;
+        uint32_t kk = k;
+        for (uint32_t q = 0; q < PER && v0 + q < n; ++q) {
+            const int32_t a = labels[r * nzp + kk];
+            word |= (BITS == 2 ? ((uint32_t)a & 3u) : (a == 1 ? 1u : 0u)) << (BITS * q);
+            if (++kk == nz) { kk = 0; ++r; }
+        }
+    }
+    out[w] = word;
+}
+
+// The other end of the wire: `world` ranks' packed planes, as an all-gather leaves them ([world][rank_words]
+// words, rank r's planes in its own order), into ONE grid in global order -- plane i of the grid is plane i / world
+// of rank i % world (plane-cyclic) or plane i - first(r) of the rank whose slab holds it -- unpacked to int8 or
+// int32 on the way.  One lane makes 16 consecutive voxels of the output (one 16-byte store as int8, four as
+// int32); planes of whole words (ny * nz % (32 / BITS) == 0) take one word each, other shapes voxel by voxel.
+template <int BITS, typename OUT>
+__global__ __launch_bounds__(kBlock) void unpack_labels_kernel(const uint32_t *__restrict__ recv, OUT *__restrict__ out,
+                                                               uint64_t rank_words, uint32_t world, uint32_t nx,
+                                                               uint64_t plane, int cyclic) {
+    constexpr uint32_t PER = 32u / BITS;
+    const uint64_t n = (uint64_t)nx * plane;
+    const uint64_t v0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u;
+    if (v0 >= n) return;
+    auto locate = [&](uint64_t v, uint32_t &r, uint64_t &src) {
+        const uint32_t i = (uint32_t)(v / plane);
+        const uint64_t within = v - (uint64_t)i * plane;
+        uint32_t p;
+        if (cyclic) {
+            r = i % world;
+            p = i / world;
+        } else {  // slabs [nx r / world, nx (r + 1) / world)
+            r = (uint32_t)(((uint64_t)i * world + world - 1) / nx);
+            while ((uint64_t)nx * r / world > i) --r;
+            while ((uint64_t)nx * (r + 1) / world <= i) ++r;
+            p = i - (uint32_t)((uint64_t)nx * r / world);
+        }
+        src = (uint64_t)p * plane + within;
+    };
+    auto decode = [](uint32_t bits) -> OUT {
+        if (BITS == 2) return (OUT)((bits & 3u) == 3u ? -1 : (int)(bits & 3u));
+        return (OUT)(bits & 1u);
+    };
+    OUT vals[16];
+    if (plane % PER == 0 && v0 + 16 <= n) {  // 16 | PER: the 16 voxels share a plane and a word
+        uint32_t r;
+        uint64_t src;
+        locate(v0, r, src);
+        const uint32_t word = recv[(uint64_t)r * rank_words + src / PER] >> (BITS * (uint32_t)(src % PER));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vals[q] = decode(word >> (BITS * q));
+        if (sizeof(OUT) == 1) {
+            *reinterpret_cast<uint4 *>(out + v0) = *reinterpret_cast<const uint4 *>(vals);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4 *>(out + v0 + 4 * q) = *reinterpret_cast<const uint4 *>(vals + 4 * q);
+        }
+        return;
+    }
+    for (uint32_t q = 0; q < 16 && v0 + q < n; ++q) {
+        uint32_t r;
+        uint64_t src;
+        locate(v0 + q, r, src);
+        out[v0 + q] = decode(recv[(uint64_t)r * rank_words + src / PER] >> (BITS * (uint32_t)(src % PER)));
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(uint32_t *__restrict__ dst, uint64_t n,
                                                       uint32_t bits) {
     uint64_t idx = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -2536,6 +2641,7 @@ struct sc_engine {
                                // the flags kernel, the others beside the dense stage (0: all ahead)
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
+    uint32_t *packed_labels = nullptr;  // sc_values_packed: the labels at 2 or 1 bits each
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
     uint32_t *bulk = nullptr;  // units (a wavefront's share of a live brick) finished as a whole (counts in ctl->count[3])
     uint32_t bulkcap = 0;      // ... per sub-list
@@ -3799,6 +3905,7 @@ void sc_destroy(sc_engine *e) {
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->narrow) (void)hipFree(e->narrow);
+    if (e->packed_labels) (void)hipFree(e->packed_labels);
     if (e->dense) (void)hipFree(e->dense);
     if (e->verd) (void)hipFree(e->verd);
     if (e->verdf) (void)hipFree(e->verdf);
@@ -4005,6 +4112,21 @@ int sc_order_after(sc_engine *e, void *producer_stream) {
     return SC_OK;
 }
 
+int sc_order_before(sc_engine *e, void *consumer_stream) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    int rc = use_device(e);
+    if (rc) return rc;
+    hipStream_t cons = static_cast<hipStream_t>(consumer_stream);
+    if (cons != nullptr && cons == e->stream) return SC_OK;  // same stream: already in order
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t he = hipEventRecord(ev, e->stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(cons, ev, 0);
+    (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+    if (he != hipSuccess) return fail(SC_ERR_DEVICE, "ordering the consumer stream behind the engine failed: %s", hipGetErrorString(he));
+    return SC_OK;
+}
+
 int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
                     const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes) {
     int rc = check_view_args(e, K, R, t, mask, H, W);
@@ -4199,6 +4321,85 @@ int sc_values_device_ptr(sc_engine *e, void **ptr) {
     rc = materialize(e);
     if (rc) return rc;
     return dense_state(e, ptr);  // planes * ny * nz elements, no row padding
+}
+
+int64_t sc_packed_bytes(int64_t voxels, int bits) {
+    if (voxels < 0 || (bits != 1 && bits != 2)) return -1;
+    const int64_t per = 32 / bits;
+    return ((voxels + per - 1) / per * 4 + 15) / 16 * 16;  // whole words, whole 16-byte groups
+}
+
+int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes) {
+    if (!e || !ptr || !bytes) return fail(SC_ERR_INVALID, "null argument");
+    if (bits != 1 && bits != 2) return fail(SC_ERR_INVALID, "bits must be 1 or 2");
+    if (e->mode != SC_MODE_CARVE) return fail(SC_ERR_STATE, "packed labels are carve labels");
+    const int32_t init = init_bits_i32(e);
+    if (bits == 2 && (init < -1 || init > 1 || (float)init != e->default_value))
+        return fail(SC_ERR_STATE, "default_value %g is not one of -1, 0, 1: two bits cannot hold it", (double)e->default_value);
+    int rc = sc_flush(e);
+    if (rc) return rc;
+    rc = materialize(e);
+    if (rc) return rc;
+    const int64_t nbytes = sc_packed_bytes(e->n, bits);
+    if (!e->packed_labels) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->packed_labels), (size_t)sc_packed_bytes(e->n, 2)));
+    const uint64_t words = ((uint64_t)e->n + (32 / bits) - 1) / (32 / bits);
+    // bricks an earlier launch found empty are all -1 until the next clear: not read (see the kernel)
+    const uint32_t bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
+    const uint8_t *dead = (e->dead && e->dead_clean) ? e->dead : nullptr;
+    const dim3 grid((uint32_t)((words + kBlock - 1) / kBlock));
+    if ((uint64_t)grid.x * kBlock < words) return fail(SC_ERR_INVALID, "grid too large for one launch");
+    if (bits == 2)
+        hipLaunchKernelGGL(pack_labels_kernel<2>, grid, dim3(kBlock), 0, e->stream, static_cast<const int32_t *>(e->state),
+                           e->packed_labels, (uint64_t)e->n, (uint32_t)e->nz, (uint32_t)e->nzp, (uint32_t)e->ny, dead, bys, bzs);
+    else
+        hipLaunchKernelGGL(pack_labels_kernel<1>, grid, dim3(kBlock), 0, e->stream, static_cast<const int32_t *>(e->state),
+                           e->packed_labels, (uint64_t)e->n, (uint32_t)e->nz, (uint32_t)e->nzp, (uint32_t)e->ny, dead, bys, bzs);
+    HIP_TRY(hipGetLastError());
+    // (the tail of the last 16-byte group is never read by a consumer that knows the voxel count)
+    *ptr = e->packed_labels;
+    *bytes = nbytes;
+    return SC_OK;
+}
+
+int sc_get_values_packed(sc_engine *e, int bits, void *out) {
+    if (!out) return fail(SC_ERR_INVALID, "null argument");
+    void *ptr = nullptr;
+    int64_t bytes = 0;
+    int rc = sc_values_packed(e, bits, &ptr, &bytes);
+    if (rc) return rc;
+    const int64_t words = (e->n + (32 / bits) - 1) / (32 / bits);
+    HIP_TRY(hipMemcpyAsync(out, ptr, (size_t)words * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SC_OK;
+}
+
+int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
+                     int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes) {
+    if (!recv_dev || !out_dev) return fail(SC_ERR_INVALID, "null argument");
+    if (bits != 1 && bits != 2) return fail(SC_ERR_INVALID, "bits must be 1 or 2");
+    if (out_bytes != 1 && out_bytes != 4) return fail(SC_ERR_INVALID, "output elements are int8 (1) or int32 (4)");
+    if (partition != 0 && partition != 1) return fail(SC_ERR_INVALID, "partition: 0 plane-cyclic, 1 slabs");
+    if (world < 1 || nx < world || ny < 1 || nz < 1 || rank_bytes < 0 || (rank_bytes & 3))
+        return fail(SC_ERR_INVALID, "bad shape / world / stride");
+    const uint64_t plane = (uint64_t)ny * (uint64_t)nz, n = (uint64_t)nx * plane;
+    const uint64_t pmax = (uint64_t)(nx + world - 1) / world;
+    if ((uint64_t)rank_bytes * 8 < pmax * plane * (uint64_t)bits) return fail(SC_ERR_INVALID, "rank stride too small for its planes");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t lanes = (n + 15) / 16, blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffULL) return fail(SC_ERR_INVALID, "grid too large for one launch");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const uint32_t *recv = static_cast<const uint32_t *>(recv_dev);
+    const uint64_t rw = (uint64_t)rank_bytes / 4;
+#define LAUNCH_UNPACK(B, T)                                                                                        \
+    hipLaunchKernelGGL((unpack_labels_kernel<B, T>), dim3((uint32_t)blocks), dim3(kBlock), 0, st, recv,              \
+                       static_cast<T *>(out_dev), rw, (uint32_t)world, (uint32_t)nx, plane, partition == 0 ? 1 : 0)
+    if (bits == 2 && out_bytes == 1) LAUNCH_UNPACK(2, int8_t);
+    else if (bits == 2) LAUNCH_UNPACK(2, int32_t);
+    else if (out_bytes == 1) LAUNCH_UNPACK(1, int8_t);
+    else LAUNCH_UNPACK(1, int32_t);
+#undef LAUNCH_UNPACK
+    HIP_TRY(hipGetLastError());
+    return SC_OK;
 }
 
 int64_t sc_num_voxels(const sc_engine *e) { return e ? e->n : 0; }
@@ -4466,6 +4667,10 @@ struct sc_group {
     std::vector<sc_engine *> eng;
     int64_t nx = 0, ny = 0, nz = 0;
     int partition = 0;
+    // a call that failed on engine k after engines 0 .. k-1 took it leaves the x-planes in different states
+    // (different view sets, tables or options): the group then refuses everything but a clear, which puts
+    // every engine back to default_value, and its destruction
+    bool mixed = false;
 };
 
 extern "C" {
@@ -4509,27 +4714,63 @@ sc_engine *sc_group_engine(sc_group *g, int i) {
     return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[(size_t)i] : nullptr;
 }
 
+#define SC_GROUP_CHECK(g)                                                                                   \
+    do {                                                                                                    \
+        if (!(g)) return fail(SC_ERR_INVALID, "null group");                                                \
+        if ((g)->mixed)                                                                                     \
+            return fail(SC_ERR_STATE, "an earlier call failed on some engines of the group only: its planes are in " \
+                                      "different states; sc_group_clear it (or destroy it)");               \
+    } while (0)
+
 #define SC_GROUP_EACH(call)                                   \
     do {                                                      \
-        if (!g) return fail(SC_ERR_INVALID, "null group");    \
+        SC_GROUP_CHECK(g);                                    \
+        size_t done_ = 0;                                     \
         for (auto *e : g->eng) {                              \
             int rc_ = (call);                                 \
-            if (rc_) return rc_;                              \
+            if (rc_) {                                        \
+                if (done_ > 0) g->mixed = true;               \
+                return rc_;                                   \
+            }                                                 \
+            ++done_;                                          \
         }                                                     \
         return SC_OK;                                         \
     } while (0)
 
-int sc_group_clear(sc_group *g) { SC_GROUP_EACH(sc_clear(e)); }
+int sc_group_clear(sc_group *g) {
+    if (!g) return fail(SC_ERR_INVALID, "null group");
+    int first = SC_OK;
+    for (auto *e : g->eng) {  // every engine, whatever the others say
+        int rc = sc_clear(e);
+        if (rc && !first) first = rc;
+    }
+    g->mixed = first != SC_OK;
+    return first;
+}
 int sc_group_flush(sc_group *g) { SC_GROUP_EACH(sc_flush(e)); }
 int sc_group_set_option(sc_group *g, int key, int64_t value) { SC_GROUP_EACH(sc_set_option(e, key, value)); }
-int sc_group_set_lut(sc_group *g, const float *lut256) { SC_GROUP_EACH(sc_set_lut(e, lut256)); }
+int sc_group_set_lut(sc_group *g, const float *lut256) {
+    if (g && !lut256) return fail(SC_ERR_INVALID, "null argument");
+    SC_GROUP_EACH(sc_set_lut(e, lut256));
+}
 int sc_group_process_view(sc_group *g, const float K[4], const float R[9], const float t[3], const void *mask,
                           int H, int W, int mask_dtype, int64_t row_stride_bytes) {
+    SC_GROUP_CHECK(g);
+    if (!g->eng.empty()) {  // the arguments are judged once, before any engine takes the view
+        int rc = check_view_args(g->eng[0], K, R, t, mask, H, W);
+        if (rc) return rc;
+        for (auto *e : g->eng) {
+            rc = check_dtype(e, mask_dtype);
+            if (rc) return rc;
+        }
+        const int64_t row = (int64_t)W * (int64_t)elem_size(mask_dtype);
+        if (row_stride_bytes != 0 && row_stride_bytes < row) return fail(SC_ERR_INVALID, "row stride smaller than a row");
+    }
     SC_GROUP_EACH(sc_process_view(e, K, R, t, mask, H, W, mask_dtype, row_stride_bytes));
 }
 
 int sc_group_synchronize(sc_group *g) {
-    if (!g) return fail(SC_ERR_INVALID, "null group");
+    SC_GROUP_CHECK(g);
     for (auto *e : g->eng) {  // every device launches before any is waited for
         int rc = sc_flush(e);
         if (rc) return rc;
@@ -4543,6 +4784,7 @@ int sc_group_synchronize(sc_group *g) {
 
 int sc_group_get_values(sc_group *g, void *out) {
     if (!g || !out) return fail(SC_ERR_INVALID, "null argument");
+    SC_GROUP_CHECK(g);
     const size_t plane = (size_t)g->ny * (size_t)g->nz * 4;
     const int ndev = (int)g->eng.size();
     for (auto *e : g->eng) {  // launch everywhere first: the devices work side by side

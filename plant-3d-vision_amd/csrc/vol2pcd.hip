@@ -39,9 +39,9 @@ constexpr int kBlk = 8;  // activity is tracked per 8x8x8 block of voxels
 
 int fail_v(int code, const char *msg);  // defined below
 
-// The work buffers (49 bytes per voxel: 6.6 GB at 512^3) are kept between calls -- allocating and freeing
-// them was 2.8 of a call's 4.6 ms -- one per device, growing only, handed out to one caller at a time
-// (a second caller on the same device takes its own, freed at the end of the call).
+// The work buffers (49 bytes per voxel) are kept between calls while they are small (up to 1 GiB: volumes up
+// to ~280^3) -- allocating and freeing them was 2.8 of a call's 4.6 ms -- one per device, handed out to one
+// caller at a time (a second caller on the same device takes its own, freed at the end of the call).
 // sc_vol2pcd_release() gives them back.
 struct ScratchSlot { char *base = nullptr; size_t cap = 0; bool busy = false; };
 std::mutex g_scratch_mu;
@@ -72,11 +72,22 @@ char *scratch_take(int device, size_t bytes, bool *cached) {
     return p;
 }
 
+// Buffers above this size go back to the device when the call ends: 49 bytes per voxel is 6.6 GB at 512^3 and
+// 52 GB at 1024^3 -- HBM a Voxels -> PointCloud worker would hold while later engines, survivor lists and
+// two-engine runs allocate -- against 1 ms of a 4.6 ms call saved by keeping them.
+constexpr size_t kScratchKeepMax = (size_t)1 << 30;
+
 void scratch_give(int device, char *p, bool cached) {
     if (!p) return;
     if (cached) {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
-        g_scratch[device].busy = false;
+        ScratchSlot &sl = g_scratch[device];
+        sl.busy = false;
+        if (sl.cap > kScratchKeepMax) {
+            (void)hipFree(sl.base);
+            sl.base = nullptr;
+            sl.cap = 0;
+        }
     } else {
         (void)hipFree(p);
     }
@@ -703,6 +714,8 @@ done:
 
 void sc_vol2pcd_release(void) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
+    int current = -1;
+    const bool restore = hipGetDevice(&current) == hipSuccess;  // the caller's current device stays what it was
     for (int d = 0; d < 64; ++d) {
         ScratchSlot &sl = g_scratch[d];
         if (sl.base && !sl.busy && hipSetDevice(d) == hipSuccess) {
@@ -711,6 +724,7 @@ void sc_vol2pcd_release(void) {
             sl.cap = 0;
         }
     }
+    if (restore) (void)hipSetDevice(current);
 }
 
 }  // extern "C"

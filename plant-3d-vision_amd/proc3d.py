@@ -38,6 +38,13 @@ def gaussian_weights(sigma=1.0, truncate=4.0):
     return np.ascontiguousarray(phi[radius:], dtype=np.float64)
 
 
+def release_device_buffers():
+    """Give back the device work buffers ``vol2pcd`` keeps between calls (``sc_vol2pcd_release``; it keeps them
+    only while they are at most 1 GiB).  ``Backprojection.close`` calls this too."""
+    from . import _native as nat
+    nat.backend().call("sc_vol2pcd_release")
+
+
 def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=True):
     """Converts a volume into a point-cloud with normals, on the GPU
     (``plant3dvision/proc3d.py:490-570``; same signature, ``device`` / ``as_open3d`` added).

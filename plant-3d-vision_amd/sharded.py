@@ -63,7 +63,7 @@ class ShardedBackprojection:
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, rank=None,
                  world_size=None, device=None, engine_factory=None, views_per_launch=0,
-                 partition="cyclic", log=False):
+                 partition="cyclic", log=False, unpack_fn=None):
         if rank is None or world_size is None:
             import torch.distributed as dist
             rank = dist.get_rank() if dist.is_initialized() else 0
@@ -99,6 +99,8 @@ class ShardedBackprojection:
         if views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(views_per_launch))
         self._on_gpu = engine_factory is None
+        #: host tensors only (CPU tests of the host logic over gloo): what stands in for ``sc_unpack_labels``
+        self._unpack_fn = unpack_fn
 
     @property
     def engine(self):
@@ -178,6 +180,64 @@ class ShardedBackprojection:
             full[pl.start:pl.stop] = recv[r, : len(pl)]
         return full.view(nx, ny, nz)
 
+    def packed_rank_bytes(self, bits):
+        """Bytes one rank contributes to a packed all-gather (its planes padded to the largest plane count)."""
+        return nat.packed_bytes(self._planes_max() * self.shape[1] * self.shape[2], bits)
+
+    def _all_gather_packed(self, bits, widen, recv, out):
+        """Labels at 2 bits each (or 1: the occupancy ``label == 1`` the consumer binarises to, proc3d.py:515)
+        over the wire -- 1/16 (1/32) of the int32 planes: 32 MiB per rank at 1024^3 / 8 -- and ONE kernel
+        (``sc_unpack_labels``) that unpacks and puts the planes in global order, as int8 or, ``widen``, int32."""
+        import torch
+        import torch.distributed as dist
+        if self.dtype != np.int32:
+            raise ValueError("packed labels are carve labels")
+        W = self.world_size
+        rank_bytes = self.packed_rank_bytes(bits)
+        tstream = None
+        if self._on_gpu:
+            ptr, nbytes = self._engine.values_packed(bits)
+            # packed on the engine's stream; the collective and the unpack run on torch's: ordered on the device,
+            # nothing waits on the host
+            tstream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+            self._engine.order_before(tstream)
+            local = torch.as_tensor(_DeviceBuffer(ptr, nbytes, "|u1"), device=f"cuda:{self.device}")
+        else:
+            local = torch.from_numpy(np.ascontiguousarray(self._engine.get_values_packed(bits)).view(np.uint8))
+        n_out = int(np.prod(self.shape))
+        out_dtype = torch.int32 if widen else torch.int8
+        if out is None or out.dtype != out_dtype or out.numel() < n_out:
+            out = torch.empty(n_out, dtype=out_dtype, device=local.device)
+        single = W == 1 and not self.force_collective
+        if single:
+            recv = local
+            rank_bytes = int(local.numel())
+        else:
+            if recv is None or recv.dtype != torch.uint8 or recv.numel() < rank_bytes * W:
+                recv = torch.empty(rank_bytes * W, dtype=torch.uint8, device=local.device)
+            recv = recv[: rank_bytes * W]
+            send = local
+            if local.numel() != rank_bytes:  # a rank with one plane fewer, or a tail shorter than the padding
+                send = torch.zeros(rank_bytes, dtype=torch.uint8, device=local.device)
+                send[: min(local.numel(), rank_bytes)] = local[:rank_bytes]
+            if dist.get_backend() == "gloo" and recv.is_cuda:  # rehearsal on one box: through the host
+                hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_gather_into_tensor(hrecv, send.cpu())
+                recv.copy_(hrecv)
+            else:
+                dist.all_gather_into_tensor(recv, send)
+        if recv.is_cuda:
+            nat.unpack_labels(self.device, torch.cuda.current_stream(recv.device).cuda_stream, recv.data_ptr(), rank_bytes, W,
+                              self.partition, self.shape, bits, out.data_ptr(), 4 if widen else 1)
+            if tstream is not None:  # the engine's next pack must not overwrite what the collective still reads
+                self._engine.order_after(tstream)
+        else:
+            if self._unpack_fn is None:
+                raise RuntimeError("host tensors: no HIP unpack (the product path keeps the labels on the device)")
+            out[:n_out] = torch.from_numpy(self._unpack_fn(recv.numpy(), rank_bytes, W, self.partition, self.shape, bits,
+                                                            np.int32 if widen else np.int8).reshape(-1))
+        return out[:n_out].view(self.shape)
+
     def all_gather(self, compress=False, widen=True, recv=None, out=None):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
 
@@ -185,10 +245,16 @@ class ShardedBackprojection:
         is): 4x less xGMI traffic; ``widen`` turns the assembled grid back into int32 (the
         reference's dtype, cl.py:145-147) -- a device consumer that takes 1-byte volumes
         (``vol2pcd``) passes ``widen=False`` and spares the 4 bytes per voxel.
-        recv / out: reusable buffers of ``W * P * ny * nz`` elements of the wire dtype.
+        compress="2bit" sends them at 2 bits each, "1bit" the occupancy ``label == 1`` alone (what
+        ``vol2pcd`` binarises to): 16x / 32x less traffic, packed by the engine and unpacked into global
+        order by one kernel (``_all_gather_packed``).
+        recv / out: reusable buffers (``W * P * ny * nz`` elements of the wire dtype; packed: recv
+        ``W * packed_rank_bytes(bits)`` bytes, out ``nx * ny * nz`` int8 / int32).
         """
         import torch
         import torch.distributed as dist
+        if compress in ("2bit", "1bit"):
+            return self._all_gather_packed(2 if compress == "2bit" else 1, widen, recv, out)
         local = self._slab_tensor()
         if compress:
             if self.dtype != np.int32:

@@ -75,11 +75,45 @@ class OracleEngine:
     def values_device_ptr(self):
         return 0
 
+    def get_values_packed(self, bits=2):
+        """NumPy restatement of ``pack_labels_kernel``: label & 3 at 2 bits, label == 1 at 1 bit, voxel v at bit
+        bits * (v % (32 / bits)) of word v / (32 / bits)."""
+        return pack_labels_np(self.get_values(), bits)
+
     def num_voxels(self):
         return int(np.prod(self.slab_shape))
 
     def close(self):
         pass
+
+
+def pack_labels_np(values, bits):
+    v = np.asarray(values, dtype=np.int64).reshape(-1)
+    per = 32 // bits
+    code = (v & 3) if bits == 2 else (v == 1).astype(np.int64)
+    pad = (-code.size) % per
+    code = np.concatenate([code, np.zeros(pad, dtype=np.int64)]).reshape(-1, per)
+    shifts = (np.arange(per, dtype=np.int64) * bits)[None, :]
+    return (code << shifts).sum(axis=1).astype(np.uint32)
+
+
+def unpack_labels_np(recv_bytes, rank_bytes, world, partition, shape, bits, dtype):
+    """NumPy restatement of ``unpack_labels_kernel``: the ranks' packed planes -> one grid in global order."""
+    from plant3dvision_amd.sharded import rank_planes
+    nx, ny, nz = shape
+    plane = ny * nz
+    per = 32 // bits
+    full = np.empty((nx, plane), dtype=dtype)
+    buf = np.ascontiguousarray(recv_bytes).view(np.uint8)
+    for r in range(world):
+        words = buf[r * rank_bytes:(r + 1) * rank_bytes].view(np.uint32).astype(np.int64)
+        pl = rank_planes(nx, world, r, partition)
+        nv = len(pl) * plane
+        idx = np.arange(nv, dtype=np.int64)
+        code = (words[idx // per] >> ((idx % per) * bits)) & ((1 << bits) - 1)
+        lab = np.where(code == 3, -1, code) if bits == 2 else code
+        full[pl.start:pl.stop:pl.step] = lab.reshape(len(pl), plane).astype(dtype)
+    return full.reshape(nx, ny, nz)
 
 
 class OracleBackprojection(Backprojection):

@@ -1158,6 +1158,40 @@ def test_bricks_no_view_sees_keep_their_labels(gpu_device, kind, default_value):
     assert np.array_equal(got, want), (kind, default_value, "host masks")
 
 
+@pytest.mark.parametrize("shape,kind", [((12, 32, 128), "plant"), ((7, 21, 70), "plant"), ((5, 17, 1), "solid"),
+                                        ((6, 33, 129), "dense"), ((9, 16, 64), "empty")])
+@pytest.mark.parametrize("default_value", [0, 1, -1])
+def test_labels_packed_at_two_bits_and_one(gpu_device, shape, kind, default_value):
+    """``sc_get_values_packed``: label & 3 at two bits per voxel (the three states), label == 1 at one bit,
+    rows without their padding; bricks a launch found empty are written without being read.  And back:
+    ``sc_unpack_labels`` on one rank's buffer gives the labels again (int8 and int32)."""
+    from tests.helpers import pack_labels_np
+    sh, origin, vs, views = scene(shape, 9, kind)
+    want = oracle_c.carve(sh, origin, vs, views, default_value, nthreads=4)
+    e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=default_value)
+    for rnd in range(2):  # fused batch on a fresh volume, then view by view on the stored one (dead bricks)
+        e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, rnd)
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        for bits in (2, 1):
+            got = e.get_values_packed(bits)
+            assert np.array_equal(got, pack_labels_np(want, bits)), (bits, rnd)
+            ptr, nbytes = e.values_packed(bits)
+            assert nbytes == nat.packed_bytes(want.size, bits)
+            for out_dtype in (np.int8, np.int32):
+                out = e.dev_alloc(want.size * np.dtype(out_dtype).itemsize)
+                nat.unpack_labels(0, 0, ptr, nbytes, 1, "cyclic", sh, bits, out, np.dtype(out_dtype).itemsize)
+                back = np.empty(want.shape, dtype=out_dtype)
+                e.dev_download(back, out)
+                e.dev_free(out)
+                assert np.array_equal(back, want if bits == 2 else (want == 1)), (bits, out_dtype)
+    e.close()
+    bad = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=7)
+    with pytest.raises(nat.SpaceCarveError):
+        bad.get_values_packed(2)
+    bad.close()
+
+
 @pytest.mark.parametrize("shape", [(9, 21, 70), (5, 17, 1), (4, 16, 64), (6, 33, 129), (3, 40, 191)])
 def test_row_padding_never_shows(gpu_device, shape):
     """The state's rows are padded to multiples of 64 voxels on the device; every way out of the engine

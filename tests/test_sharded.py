@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import oracle_c
 from plant3dvision_amd.sharded import ShardedBackprojection, rank_planes, slab_bounds
-from tests.helpers import OracleEngine, scene
+from tests.helpers import OracleEngine, scene, unpack_labels_np
 
 
 def _free_port():
@@ -54,7 +54,7 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
             rng = np.random.default_rng(1)
             views = [(K, R, t, rng.random(m.shape, dtype=np.float32)) for K, R, t, m in views]
         sb = ShardedBackprojection(shape, origin, vs, type=mode, engine_factory=OracleEngine,
-                                   partition=partition)
+                                   partition=partition, unpack_fn=unpack_labels_np)
         assert (sb.rank, sb.world_size) == (rank, world)
         for K, R, t, m in views:
             sb.process_view(K, R, t, m)
@@ -75,6 +75,19 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
             b = sb.all_gather(recv=recv, out=out)
             assert a.data_ptr() == b.data_ptr() and torch.equal(a, b)
             res["host32"] = sb.gather_to_host(dst=world - 1, compress=False)
+            # labels at 2 bits over the wire (1 bit: the occupancy), unpacked into global order
+            p2 = sb.all_gather(compress="2bit")
+            assert p2.dtype == torch.int32
+            res["ag2"] = p2.numpy()
+            p2n = sb.all_gather(compress="2bit", widen=False)
+            assert p2n.dtype == torch.int8
+            res["ag2n"] = p2n.numpy()
+            res["ag1"] = sb.all_gather(compress="1bit", widen=False).numpy()
+            rb = sb.packed_rank_bytes(2)
+            recv2 = torch.empty(rb * world, dtype=torch.uint8)
+            out2 = torch.empty(int(np.prod(shape)), dtype=torch.int8)
+            a2 = sb.all_gather(compress="2bit", widen=False, recv=recv2, out=out2)
+            assert a2.data_ptr() == out2.data_ptr()
         q.put(res)
     finally:
         dist.barrier()
@@ -110,6 +123,8 @@ def test_gloo_sharded_equals_single(world, shape, mode, partition):
         if mode == "carving":
             assert np.array_equal(res["ag8"], want)
             assert res["ag8n"].dtype == np.int8 and np.array_equal(res["ag8n"], want)
+            assert np.array_equal(res["ag2"], want) and np.array_equal(res["ag2n"], want)
+            assert np.array_equal(res["ag1"], (want == 1).astype(np.int8))
             if res["rank"] == world - 1:
                 assert res["host32"].dtype == np.int32 and np.array_equal(res["host32"], want)
             else:
@@ -149,7 +164,12 @@ def _gpu_worker(rank, world, port, shape, partition, q):
         assert full.is_cuda and full.dtype == torch.int32
         narrow = sb.all_gather(compress=True, widen=False)
         assert narrow.is_cuda and narrow.dtype == torch.int8
+        p2 = sb.all_gather(compress="2bit", widen=False)
+        assert p2.is_cuda and p2.dtype == torch.int8
+        p2w = sb.all_gather(compress="2bit")
+        p1 = sb.all_gather(compress="1bit", widen=False)
         q.put({"rank": rank, "ag": full.cpu().numpy(), "ag8n": narrow.cpu().numpy(),
+               "ag2n": p2.cpu().numpy(), "ag2": p2w.cpu().numpy(), "ag1": p1.cpu().numpy(),
                "ar": sb.all_reduce().cpu().numpy(), "host": sb.gather_to_host(dst=0)})
         sb.close()
     finally:
@@ -177,6 +197,8 @@ def test_two_ranks_over_hip_engines_sharing_the_gpu(gpu_device, partition, shape
     for res in results:
         assert np.array_equal(res["ag"], want) and np.array_equal(res["ar"], want)
         assert res["ag8n"].dtype == np.int8 and np.array_equal(res["ag8n"], want)
+        assert np.array_equal(res["ag2n"], want) and res["ag2"].dtype == np.int32 and np.array_equal(res["ag2"], want)
+        assert np.array_equal(res["ag1"], (want == 1).astype(np.int8))
         if res["rank"] == 0:
             assert res["host"].dtype == np.int32 and np.array_equal(res["host"], want)
         else:
@@ -237,6 +259,12 @@ def test_collectives_through_rccl_with_a_process_group_of_one(gpu_device):
             assert full.is_cuda and full.dtype == torch.int32 and np.array_equal(full.cpu().numpy(), want)
             narrow = sb.all_gather(compress=True, widen=False)
             assert narrow.dtype == torch.int8 and np.array_equal(narrow.cpu().numpy(), want)
+            p2 = sb.all_gather(compress="2bit", widen=False)
+            assert p2.is_cuda and p2.dtype == torch.int8 and np.array_equal(p2.cpu().numpy(), want)
+            p2w = sb.all_gather(compress="2bit")
+            assert p2w.dtype == torch.int32 and np.array_equal(p2w.cpu().numpy(), want)
+            p1 = sb.all_gather(compress="1bit", widen=False)
+            assert np.array_equal(p1.cpu().numpy(), (want == 1).astype(np.int8))
             assert np.array_equal(sb.all_reduce().cpu().numpy(), want)
             host = sb.gather_to_host(dst=0)
             assert host.dtype == np.int32 and np.array_equal(host, want)

@@ -181,3 +181,116 @@ def test_displacement_shifts_the_grid(task_env):
     assert g == [5, 5, 5] and o == [2.0, 0, 0]
     g, o = mod.grid_from_bounding_box({"x": [0, 4], "y": [0, 4], "z": [0, 4]}, 1.0, None)
     assert o == [0, 0, 0]
+
+
+# -- the same boundary over the HIP engine, from files on disk (GPU box) ---------------------------------------
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def task_env_hip():
+    """As ``task_env``, but nothing is injected: ``Voxels.run`` builds the product's ``Backprojection`` (HIP)."""
+    sys.path.insert(0, STUBS)
+    for name in [m for m in sys.modules if m.split(".")[0] in ("luigi", "romitask", "plantdb", "plant3dvision")]:
+        del sys.modules[name]
+    import romitask
+    from plant3dvision_amd.tasks import cl as mod
+    mod = importlib.reload(mod)
+    assert mod.Voxels is not None and mod.BACKPROJECTION_CLS is None
+    yield mod, romitask
+    sys.path.remove(STUBS)
+    for name in [m for m in sys.modules if m.split(".")[0] in ("luigi", "romitask", "plantdb", "plant3dvision")]:
+        del sys.modules[name]
+    importlib.reload(mod)
+
+
+def _write_png_gray8(path, a):
+    """8-bit greyscale PNG, filter 0 on every row (what a ``Masks`` fileset holds on disk)."""
+    import struct
+    import zlib
+    h, w = a.shape
+    raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.gpu
+def test_voxels_task_over_the_hip_engine_from_png_files(gpu_device, task_env_hip, tmp_path):
+    """``Voxels(RomiTask).run()`` (reference ``tasks/cl.py:99-186``) with the product's own device layer behind
+    it: the masks of ``tests/testdata/virtual_plant`` (committed as ``tests/golden/virtual_plant_inputs.npz``)
+    written as PNG files, a scan whose ``Masks`` files hand out those bytes (``read_raw``) with the camera
+    metadata of the reference's ``metadata/images/*.json``, the bounding box in the scan metadata; carving one
+    channel, carving the inverted background, labelled averaging -- against the committed expected volumes,
+    and the file / metadata contract (volume vs NPZ, ``voxel_size`` / ``origin``)."""
+    mod, romitask = task_env_hip
+    data = np.load(os.path.join(GOLDEN, "virtual_plant_inputs.npz"))
+    exp = np.load(os.path.join(GOLDEN, "virtual_plant_expected.npz"))
+
+    class DiskFile(romitask._File):
+        def __init__(self, fid, path, md):
+            super().__init__(fid, None, md)
+            self.path = path
+
+        def read_raw(self):
+            with open(self.path, "rb") as f:
+                return f.read()
+
+    bbox = {a: [float(data["bbox"][q, 0]), float(data["bbox"][q, 1])] for q, a in enumerate("xyz")}
+    scan = romitask._Scan("virtual_plant", {"bounding_box": bbox})
+    masks = scan.fileset("Masks")
+    for ch in ("stem", "background"):
+        for q in range(data[f"masks_{ch}"].shape[0]):
+            path = str(tmp_path / f"{q:05d}_{ch}.png")
+            _write_png_gray8(path, data[f"masks_{ch}"][q])
+            cam = {"camera_model": {"params": [float(x) for x in data[f"K_{ch}"][q]]},
+                   "rotmat": [[float(x) for x in row] for row in data[f"R_{ch}"][q]],
+                   "tvec": [float(x) for x in data[f"t_{ch}"][q]]}
+            masks._files.append(DiskFile(f"{q:05d}_{ch}", path, {"camera": cam, "channel": ch}))
+    scan.fileset("Colmap")
+    scan.fileset("images")
+    romitask.DB.scan = scan
+    want_md = {"voxel_size": 1.0, "origin": [float(x) for x in exp["origin_vs10"]]}
+
+    # carving one channel (the scan's bounding box: source 2 of the reference's cascade, :108)
+    mod.Voxels(voxel_size=1.0, camera_metadata="camera", query={"channel": "stem"}).run()
+    f = scan.fileset("Voxels")._files[-1]
+    kind, vol = f.written
+    assert kind == "volume" and vol.dtype == np.int32 and list(vol.shape) == [int(x) for x in exp["shape_vs10"]]
+    assert np.array_equal(vol, exp["carve_stem_vs10"].astype(np.int32))
+    assert f.get_metadata() == want_md
+    # the background channel, inverted on the way (cl.py:300-301)
+    mod.Voxels(voxel_size=1.0, camera_metadata="camera", query={"channel": "background"}, invert=True).run()
+    kind, vol = scan.fileset("Voxels")._files[-1].written
+    assert kind == "volume" and np.array_equal(vol, exp["carve_background_invert_vs10"].astype(np.int32))
+    # half the voxel size: another grid from the same box
+    mod.Voxels(voxel_size=0.5, camera_metadata="camera", query={"channel": "stem"}).run()
+    f = scan.fileset("Voxels")._files[-1]
+    assert np.array_equal(f.written[1], exp["carve_stem_vs05"].astype(np.int32))
+    assert f.get_metadata() == {"voxel_size": 0.5, "origin": [float(x) for x in exp["origin_vs05"]]}
+    # labelled averaging without the log: one float64 array per label in an NPZ (:176-182)
+    mod.Voxels(voxel_size=1.0, camera_metadata="camera", type="averaging", log=False, labels=["stem", "background"]).run()
+    kind, vol = scan.fileset("Voxels")._files[-1].written
+    assert kind == "npz" and list(vol) == ["stem", "background"]
+    assert vol["stem"].dtype == np.float64 and np.array_equal(vol["stem"], exp["average_stem_nolog_vs10"].astype(np.float64))
+    shape = [int(x) for x in exp["shape_vs10"]]
+    origin = [float(x) for x in exp["origin_vs10"]]
+
+    def views_of(ch, conv):
+        return [(data[f"K_{ch}"][q].astype(np.float32), data[f"R_{ch}"][q].reshape(9).astype(np.float32),
+                 data[f"t_{ch}"][q].astype(np.float32), conv(data[f"masks_{ch}"][q])) for q in range(data[f"masks_{ch}"].shape[0])]
+
+    want_bg = oracle_c.average(shape, origin, 1.0, views_of("background", img_as_float32)).astype(np.float64)
+    assert np.array_equal(vol["background"], want_bg)
+    # ... and with it (the default): exp of the summed logs, clipped to 1 (:172-174)
+    mod.Voxels(voxel_size=1.0, camera_metadata="camera", type="averaging", labels=["stem"]).run()
+    kind, vol = scan.fileset("Voxels")._files[-1].written
+    with np.errstate(divide="ignore"):
+        want = np.exp(oracle_c.average(shape, origin, 1.0, views_of("stem", lambda m: np.log(EPS + img_as_float32(m)))).astype(np.float64))
+    want[want > 1] = 1.0
+    assert kind == "npz" and np.array_equal(vol["stem"], want)
