@@ -177,6 +177,19 @@ int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const 
 int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R, const float *t,
                             const void *masks_dev, int H, int W, int mask_dtype);
 
+/*
+ * The labels of one scan at once: L averaging engines of one grid on one device (one per label, each with its
+ * table, sc_set_lut), V views with ONE set of poses, masks_dev[l] = label l's uint8 masks [V][H][W] in device
+ * memory (SC_MASK_U8_LUT).  The reference runs the view loop once per label over the same cameras
+ * (Backprojection.process_fileset, cl.py:248-255); here a voxel is projected once per view and every label's
+ * mask is read at that pixel -- each label's sum is the same additions in the same order as its own
+ * sc_process_views_device + sc_flush would make, bit for bit.  Launches at once (asynchronous); every engine's
+ * stream is ordered behind the work.  Engines or masks that do not fit the one-launch form (different grids or
+ * freshness, views pending, rows that are not whole 16-byte groups) are processed label by label instead.
+ */
+int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, const float *R, const float *t,
+                      const void *const *masks_dev, int H, int W);
+
 /* Launch everything still deferred (asynchronous on the engine's stream). */
 int sc_flush(sc_engine *e);
 /* sc_flush + wait for the stream: the role of queue.finish() (cl.py:226). */

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views_device": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i"]),
+    "sc_average_labels": ("i", ["p", "i", "i", "p", "p", "p", "p", "i", "i"]),
     "sc_flush": ("i", ["p"]),
     "sc_synchronize": ("i", ["p"]),
     "sc_get_values": ("i", ["p", "p"]),
@@ -327,6 +328,20 @@ class TouchedEmpty:
             th.join()
         self._threads = []
         return self._arr
+
+
+def average_labels(engines, K, R, t, mask_ptrs, n_views, H, W):
+    """``sc_average_labels``: the labels of one scan in one launch -- ``engines[l]`` (averaging, its table set)
+    takes ``mask_ptrs[l]`` (uint8 ``[n_views][H][W]`` in device memory); one set of poses."""
+    K, R, t = Engine._pose(K, R, t)
+    if K.size != 4 * n_views or R.size != 9 * n_views or t.size != 3 * n_views:
+        raise ValueError("pose arrays do not match the view count")
+    if len(engines) != len(mask_ptrs) or not engines:
+        raise ValueError("one mask stack per engine")
+    handles = np.array([int(e._h) for e in engines], dtype=np.uintp)
+    ptrs = np.array([int(p) for p in mask_ptrs], dtype=np.uintp)
+    check(backend().call("sc_average_labels", addr(handles), len(engines), int(n_views), addr(K), addr(R), addr(t),
+                         addr(ptrs), int(H), int(W)), "sc_average_labels")
 
 
 def packed_bytes(voxels, bits):

@@ -2258,6 +2258,156 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
     }
 }
 
+// ---- several labels at once --------------------------------------------------------------------------------
+// The label volumes of one scan share their cameras (the reference's process_fileset runs the same poses once
+// per label, cl.py:248-255): here a voxel is projected ONCE per view and the L labels' masks are gathered at
+// that pixel into L sums -- each sum the same float32 additions in the same view order as its own launch would
+// make (bit-identical per label by construction).  Brick form as above: a view is projected for a brick only
+// if some label's footprint there is mixed; a label whose footprint is flat adds its table value.
+#ifndef SC_MAXLABELS
+#define SC_MAXLABELS 4
+#endif
+constexpr int kMaxLabels = SC_MAXLABELS;
+struct MultiArgs {
+    float *values[kMaxLabels];
+    const ViewDesc *views[kMaxLabels];  // label l's descriptors (its own tiled masks; the poses are the same)
+    const uint8_t *verd[kMaxLabels];    // [bricks][views] verdicts of label l (avg_flags_kernel)
+    const float *lut[kMaxLabels];
+    float init[kMaxLabels];
+};
+
+// The verdicts of the L labels about every (brick, view): the footprint -- a matter of the pose -- is worked out
+// once, the labels differ in the uniformity flags under it (avg_flags_kernel, uint8 masks).
+template <int L>
+__global__ __launch_bounds__(kBlock) void avg_flags_multi_kernel(MultiArgs a, GridDesc g, int nviews, uint32_t bricks_y,
+                                                                 uint32_t bricks_z, uint32_t nbricks, uint8_t *const *verd_out) {
+    const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t vi = blockIdx.y;  // block-uniform view: scalar descriptor
+    if (lb >= nbricks) return;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    const ViewDesc d = a.views[0][vi];
+    const Footprint fpr = brick_footprint(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ));
+    const int occ_tx = (d.W + 31) >> 5;
+    uint32_t v[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) v[l] = fpr.outside ? 4u : 0u;
+    if (!fpr.outside && fpr.ok) {
+        uint32_t any[L], all[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) { any[l] = 0; all[l] = 3; }
+        for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
+            for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const uint32_t o = a.views[l][vi].occ[ty * occ_tx + tx];
+                    any[l] |= o;
+                    all[l] &= o;
+                }
+            }
+#pragma unroll
+        for (int l = 0; l < L; ++l) v[l] = (any[l] & 1u) == 0 ? 1u : ((all[l] & 2u) != 0 ? 2u : 0u);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) const_cast<uint8_t *>(a.verd[l])[(size_t)lb * (uint32_t)nviews + vi] = (uint8_t)v[l];
+}
+
+template <int L, bool FRESH>
+__global__ __launch_bounds__(kBlock) void average_multi_kernel(MultiArgs a, GridDesc g, int nviews, uint32_t bricks_y,
+                                                               uint32_t bricks_z) {
+    __shared__ float lut_s[L][256];
+#pragma unroll
+    for (int l = 0; l < L; ++l) lut_s[l][threadIdx.x] = a.lut[l][threadIdx.x];  // kBlock == 256
+    __syncthreads();
+    const uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nzp + k0;  // the pitch is a multiple of 64: 16-byte groups
+    float val[L][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[l][e] = a.init[l];
+        if (!FRESH && inside) {
+            const float4 q = *reinterpret_cast<const float4 *>(a.values[l] + elem);
+            val[l][0] = q.x; val[l][1] = q.y; val[l][2] = q.z; val[l][3] = q.w;
+        }
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;
+    for (int v0 = 0; v0 < nviews; v0 += 64) {
+        // the verdicts of up to 64 views per label, one per lane, handed out with v_readlane
+        const int nv = min(64, nviews - v0);
+        uint32_t mine[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) mine[l] = ((int)lane < nv) ? a.verd[l][(size_t)lb * (uint32_t)nviews + v0 + (int)lane] : 0u;
+        for (int q = 0; q < nv; ++q) {
+            uint32_t c[L];
+            bool mixed = false;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                c[l] = __builtin_amdgcn_readlane(mine[l], q);  // wave-uniform (brick-uniform)
+                mixed |= c[l] == 0u;
+            }
+            if (c[0] == 4u) continue;  // OUTSIDE is a matter of the pose: no label's picture holds a voxel of the brick (:50-52)
+            if (!mixed) {  // every label's footprint is flat: the labels' table values, nothing projected
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const float add = c[l] == 1u ? lut_s[l][0] : lut_s[l][255];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[l][e] = val[l][e] + add;  // :54, every voxel is in-image
+                }
+                continue;
+            }
+            const ViewDesc d = a.views[0][v0 + q];  // the pose, and the picture's geometry
+            const float ax = d.R[0] * x + d.R[1] * y, ay = d.R[3] * x + d.R[4] * y, az = d.R[6] * x + d.R[7] * y;
+            bool ok[4];
+            uint32_t off[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int u, v;
+                ok[e] = project(ax, ay, az, z[e], d, u, v);
+                off[e] = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
+                         (uint32_t)((v & 7) * 16 + (u & 15));
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                if (c[l] != 0u) {  // flat for this label: every voxel is in-image and adds the one value
+                    const float add = c[l] == 1u ? lut_s[l][0] : lut_s[l][255];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[l][e] = val[l][e] + add;
+                    continue;
+                }
+                const uint8_t *m = static_cast<const uint8_t *>(a.views[l][v0 + q].mask);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t b = 0;
+                    if (ok[e]) b = m[off[e]];
+                    const float add = lut_s[l][b];
+                    if (ok[e]) val[l][e] = val[l][e] + add;  // :54
+                }
+            }
+        }
+    }
+    if (inside) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            *reinterpret_cast<float4 *>(a.values[l] + elem) = make_float4(val[l][0], val[l][1], val[l][2], val[l][3]);
+    }
+}
+
 // Self-test of the shared-reciprocal division against the compiler's IEEE division.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -4257,6 +4407,175 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
         if (rc) return rc;
     }
     return SC_OK;
+}
+
+// The first nv pending descriptors of an engine into its device ring, by a copy on its stream.
+static int stage_descriptors(sc_engine *e, size_t nv, const ViewDesc **out) {
+    if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->views_head = 0;
+    }
+    if (nv > e->views_cap) {
+        if (e->views_dev) (void)hipFree(e->views_dev);
+        if (e->views_pin) (void)hipHostFree(e->views_pin);
+        e->views_dev = e->views_pin = nullptr;
+        e->views_cap = 0;
+        size_t cap = std::max<size_t>(nv * 4, 1024);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->views_dev), cap * sizeof(ViewDesc)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->views_pin), cap * sizeof(ViewDesc), hipHostMallocDefault));
+        e->views_cap = cap;
+    }
+    ViewDesc *pin = e->views_pin + e->views_head, *dev = e->views_dev + e->views_head;
+    memcpy(pin, e->pending.data(), nv * sizeof(ViewDesc));
+    e->views_head += nv;
+    HIP_TRY(hipMemcpyAsync(dev, pin, nv * sizeof(ViewDesc), hipMemcpyHostToDevice, e->stream));
+    *out = dev;
+    return SC_OK;
+}
+
+int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, const float *R, const float *t,
+                      const void *const *masks_dev, int H, int W) {
+    if (!engines || !masks_dev || L < 1) return fail(SC_ERR_INVALID, "bad label set");
+    for (int l = 0; l < L; ++l) {
+        int rc = check_view_args(engines[l], K, R, t, masks_dev[l], H, W);
+        if (rc) return rc;
+        rc = check_dtype(engines[l], SC_MASK_U8_LUT);
+        if (rc) return rc;
+    }
+    if (V < 0) return fail(SC_ERR_INVALID, "negative view count");
+    if (V == 0) return SC_OK;
+    sc_engine *e0 = engines[0];
+    const int64_t row = W, view = (int64_t)W * H;
+    // one launch needs: labels in groups of 2 .. 4 on one device, one grid, the same freshness, nothing pending,
+    // the brick form's conditions (flush), whole 16-pixel rows; anything else goes label by label
+    // (up to 4 labels: measured on a 6-label segmentation -- groups of 4 + 2, 3 + 3 or 2 + 2 + 2 -- the shared
+    // launches took 16.5-17.4 ms where six launches of their own take 14.3: the labels' footprints are mixed in
+    // different places, so the union of the (brick, view) pairs to project is nearly their sum, and every label
+    // is dragged through every pair.  3 labels: 3.6 ms against 4.5.)
+    bool fused = L >= 2 && L <= kMaxLabels && V > 1 && e0->avg_brick && (uint64_t)e0->npitch < 0x80000000ull &&
+                 (W % 16) == 0 && V <= 4096;
+    const uint32_t abys = (uint32_t)((e0->ny + kBrickY - 1) / kBrickY), abzs = (uint32_t)((e0->nz + kBrickZ - 1) / kBrickZ);
+    fused = fused && (uint64_t)e0->planes * abys * abzs < 0x80000000ull;
+    for (int l = 0; l < L && fused; ++l) {
+        const sc_engine *e = engines[l];
+        fused = e->device == e0->device && e->nx == e0->nx && e->ny == e0->ny && e->nz == e0->nz && e->i0 == e0->i0 &&
+                e->istride == e0->istride && e->planes == e0->planes && e->vs == e0->vs &&
+                memcmp(e->origin, e0->origin, sizeof e->origin) == 0 && e->fresh == e0->fresh && e->pending.empty() &&
+                !e->deferred.on && e->avg_brick && (reinterpret_cast<uintptr_t>(masks_dev[l]) % 16) == 0;
+        for (int m = 0; m < l && fused; ++m) fused = engines[m] != e;
+    }
+    if (!fused) {
+        for (int l = 0; l < L; ++l) {
+            int rc = sc_process_views_device(engines[l], V, K, R, t, masks_dev[l], H, W, SC_MASK_U8_LUT);
+            if (rc) return rc;
+            rc = sc_flush(engines[l]);
+            if (rc) return rc;
+        }
+        return SC_OK;
+    }
+    int rc = use_device(e0);
+    if (rc) return rc;
+    // everything of this call runs on the first engine's stream, behind what the others have on theirs; their
+    // streams take up again behind it
+    hipStream_t main = e0->stream;
+    std::vector<hipStream_t> own((size_t)L);
+    for (int l = 0; l < L; ++l) {
+        own[(size_t)l] = engines[l]->stream;
+        if (l > 0 && own[(size_t)l] != main) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t he = hipEventRecord(ev, own[(size_t)l]);
+            if (he == hipSuccess) he = hipStreamWaitEvent(main, ev, 0);
+            (void)hipEventDestroy(ev);
+            if (he != hipSuccess) return fail(SC_ERR_DEVICE, "stream ordering failed: %s", hipGetErrorString(he));
+        }
+        engines[l]->stream = main;
+    }
+    auto restore = [&]() {
+        for (int l = 0; l < L; ++l) engines[l]->stream = own[(size_t)l];
+    };
+    const GridDesc g = grid_desc(e0);
+    const uint32_t anb = (uint32_t)((uint64_t)e0->planes * abys * abzs);
+    const size_t need = (size_t)anb * (size_t)V;
+    const ViewDesc *vd[64];
+    rc = SC_OK;
+    for (int l = 0; l < L && rc == SC_OK; ++l) {
+        sc_engine *e = engines[l];
+        rc = enqueue_tile8(e, V, K, R, t, masks_dev[l], H, W, row, view);
+        if (rc) break;
+        if (e->pending[0].occ == nullptr) { rc = fail(SC_ERR_STATE, "no uniformity flags"); break; }
+        rc = stage_descriptors(e, (size_t)V, &vd[l < 64 ? l : 0]);
+        if (rc) break;
+        if (need > e->verd_cap) {
+            hipError_t he = hipStreamSynchronize(main);
+            if (e->verd) (void)hipFree(e->verd);
+            e->verd = nullptr;
+            e->verd_cap = 0;
+            if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->verd), need);
+            if (he != hipSuccess) { rc = fail(SC_ERR_NOMEM, "verdict buffer: %s", hipGetErrorString(he)); break; }
+            e->verd_cap = need;
+        }
+    }
+    if (rc == SC_OK && L > 64) rc = fail(SC_ERR_INVALID, "more than 64 labels");
+    for (int l0 = 0; l0 < L && rc == SC_OK; l0 += kMaxLabels) {
+        const int n = std::min(kMaxLabels, L - l0);
+        if (n == 1) {  // a label left over: its own launches
+            sc_engine *e = engines[l0];
+            hipLaunchKernelGGL(avg_flags_kernel, dim3((anb + kBlock - 1) / kBlock, (uint32_t)V), dim3(kBlock), 0, main, g, vd[l0],
+                               V, abys, abzs, anb, e->verd, static_cast<uint32_t *>(nullptr));
+            if (e->fresh)
+                hipLaunchKernelGGL(average_brick_kernel<true>, dim3(anb), dim3(kBlock), 0, main, static_cast<float *>(e->state), g,
+                                   vd[l0], V, e->default_value, e->lut_dev, abys, abzs, e->verd, static_cast<uint32_t *>(nullptr));
+            else
+                hipLaunchKernelGGL(average_brick_kernel<false>, dim3(anb), dim3(kBlock), 0, main, static_cast<float *>(e->state), g,
+                                   vd[l0], V, e->default_value, e->lut_dev, abys, abzs, e->verd, static_cast<uint32_t *>(nullptr));
+            continue;
+        }
+        MultiArgs a;
+        memset(&a, 0, sizeof a);
+        for (int q = 0; q < n; ++q) {
+            sc_engine *e = engines[l0 + q];
+            a.values[q] = static_cast<float *>(e->state);
+            a.views[q] = vd[l0 + q];
+            a.verd[q] = e->verd;
+            a.lut[q] = e->lut_dev;
+            a.init[q] = e->default_value;
+        }
+#define LAUNCH_MULTI(N)                                                                                              \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((avg_flags_multi_kernel<N>), dim3((anb + kBlock - 1) / kBlock, (uint32_t)V), dim3(kBlock), 0, main, a, g, \
+                           V, abys, abzs, anb, static_cast<uint8_t *const *>(nullptr));                              \
+        if (e0->fresh) hipLaunchKernelGGL((average_multi_kernel<N, true>), dim3(anb), dim3(kBlock), 0, main, a, g, V, abys, abzs); \
+        else hipLaunchKernelGGL((average_multi_kernel<N, false>), dim3(anb), dim3(kBlock), 0, main, a, g, V, abys, abzs);          \
+    } while (0)
+        if (n == 2) LAUNCH_MULTI(2);
+#if SC_MAXLABELS >= 3
+        else if (n == 3) LAUNCH_MULTI(3);
+#endif
+#if SC_MAXLABELS >= 4
+        else LAUNCH_MULTI(4);
+#endif
+#undef LAUNCH_MULTI
+    }
+    if (rc == SC_OK && hipGetLastError() != hipSuccess) rc = fail(SC_ERR_DEVICE, "multi-label launch failed");
+    // the other engines' own streams wait for the first one's
+    if (rc == SC_OK) {
+        hipEvent_t ev;
+        hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventRecord(ev, main);
+        for (int l = 1; l < L && he == hipSuccess; ++l)
+            if (own[(size_t)l] != main) he = hipStreamWaitEvent(own[(size_t)l], ev, 0);
+        if (he == hipSuccess) (void)hipEventDestroy(ev);
+        if (he != hipSuccess) rc = fail(SC_ERR_DEVICE, "stream ordering failed: %s", hipGetErrorString(he));
+    }
+    for (int l = 0; l < L; ++l) {
+        sc_engine *e = engines[l];
+        e->pending.clear();
+        if (rc == SC_OK) e->fresh = false;
+        arena_reset(e);  // (on the first engine's stream, which every later use of this engine's arena is behind)
+    }
+    restore();
+    return rc;
 }
 
 int sc_flush(sc_engine *e) {

@@ -247,6 +247,33 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
         return vol
 
     out = {}
+    if mode == nat.SC_MODE_AVERAGE and 1 < len(masks) <= 4 and overlap:
+        # The labels share their cameras: ONE launch projects every voxel once per view and reads all the
+        # labels' masks at that pixel (``sc_average_labels``; each label's sum is the same additions in the same
+        # order as its own launch would make), one engine -- one device volume -- per label.  The volumes then
+        # cross PCIe one after the other, the ``exp`` / clip of one on a helper thread beside the next copy.
+        # (Up to 4 labels: with 6 the shared launch lost to six of their own, 16.5 against 14.3 ms on the device.)
+        try:
+            srcs = []
+            dests = []
+            for label, m in masks.items():
+                eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)
+                engines.append(eng)
+                eng.set_lut(lut)
+                eng.order_after(producer)  # the masks are complete before the engines read them
+                srcs.append((255 - m) if invert else m)
+                dests.append(nat.TouchedEmpty(vol_shape, vol_dtype))
+            nat.average_labels(engines, K, R, t, [x.data_ptr() for x in srcs], n_img, H, W)
+            with ThreadPoolExecutor(max_workers=2) as helper:
+                futs = [helper.submit(finish, eng, dest, None, src)
+                        for eng, dest, src in zip(engines, dests, srcs)]
+                for label, fut in zip(masks, futs):
+                    out[label] = fut.result()
+            del srcs
+        finally:
+            for eng in engines:
+                eng.close()
+        return out
     try:
         for _ in range(2 if overlap and len(masks) > 1 else 1):
             eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)

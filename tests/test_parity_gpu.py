@@ -553,6 +553,52 @@ def test_average_brick_form_on_flat_masks(gpu_device, shape, kw, log, kind):
         e.close()
 
 
+@pytest.mark.parametrize("L", [2, 3, 4, 5])  # 5: more than one launch takes -- label by label
+@pytest.mark.parametrize("shape,kw", [((6, 32, 128), dict()), ((5, 37, 131), dict(width=320, height=208, fx=260.0, fy=260.0, cx=160.0, cy=104.0)),
+                                      ((4, 20, 70), dict(width=330, height=207, fx=260.0, fy=260.0, cx=165.0, cy=103.0))])  # odd width: label by label
+def test_labels_of_one_scan_in_one_launch(gpu_device, L, shape, kw):
+    """``sc_average_labels``: L averaging engines, one set of poses, a voxel projected once per view and every
+    label's mask read at that pixel -- each label's volume bit-identical to the oracle's (the same float32
+    additions in the same order as its own launch), on fresh volumes and on a second batch over the stored sums;
+    binary, grey, all-black and all-white labels together (flat and mixed footprints in one launch)."""
+    sh, origin, vs, views = scene(shape, 9, "plant", **kw)
+    H, W = views[0][3].shape
+    rng = np.random.default_rng(31)
+    stacks = []
+    for l in range(L):
+        kind = l % 5
+        if kind == 0:
+            st = np.stack([m for _, _, _, m in views])
+        elif kind == 1:
+            st = rng.integers(0, 256, (len(views), H, W), dtype=np.uint8)
+        elif kind == 2:
+            st = np.stack([np.invert(m) for _, _, _, m in views])
+        elif kind == 3:
+            st = np.full((len(views), H, W), 255, dtype=np.uint8)
+        else:
+            st = np.zeros((len(views), H, W), dtype=np.uint8)
+        stacks.append(np.ascontiguousarray(st))
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    for log in (False, True):
+        table = averaging_table(log)
+        engines = [nat.Engine(sh, origin, vs, nat.SC_MODE_AVERAGE, default_value=float(l)) for l in range(L)]
+        ptrs = []
+        for e, st in zip(engines, stacks):
+            e.set_lut(table)
+            ptr = e.dev_alloc(st.nbytes)
+            e.dev_upload(ptr, st)
+            ptrs.append(ptr)
+        for rnd in range(2):
+            nat.average_labels(engines, K, R, t, ptrs, len(views), H, W)
+            for l, (e, st) in enumerate(zip(engines, stacks)):
+                fv = [(Kq, Rq, tq, table[st[q]]) for q, (Kq, Rq, tq, _) in enumerate(views)]
+                want = oracle_c.average(sh, origin, vs, fv * (rnd + 1), default_value=float(l))
+                assert np.array_equal(e.get_values().view(np.uint32), want.view(np.uint32)), (L, l, log, rnd)
+        for e, ptr in zip(engines, ptrs):
+            e.dev_free(ptr)
+            e.close()
+
+
 def test_average_mixed_uint8_and_float_views(gpu_device):
     shape, origin, vs, views = scene(18, 6, "noise", width=64, height=48, fx=50.0, fy=50.0, cx=32.0, cy=24.0)
     rng = np.random.default_rng(4)

@@ -49,6 +49,42 @@ def main():
                                           log=a.type == "averaging")
         res["volume_incl_readback_s"] = time.perf_counter() - t2
         vols1 = None
+    # device time alone: the labels in one launch (sc_average_labels) against one launch per label
+    if a.type == "averaging" and len(use) > 1:
+        from plant3dvision_amd import _native as nat
+        from plant3dvision_amd.cl import averaging_table
+        K = np.array([c["camera_model"]["params"][0:4] for c in cams], dtype=np.float32)
+        R = np.array([sum(c["rotmat"], []) for c in cams], dtype=np.float32)
+        t = np.array([c["tvec"] for c in cams], dtype=np.float32)
+        engs = [nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE) for _ in use]
+        for e in engs:
+            e.set_lut(averaging_table(True))
+        ptrs = [masks[name].data_ptr() for name in use]
+        sync()
+
+        def shared():
+            for e in engs:
+                e.clear()
+            nat.average_labels(engs, K, R, t, ptrs, a.views, S, S)
+            for e in engs:
+                e.synchronize()
+
+        def one_by_one():
+            for e, p in zip(engs, ptrs):
+                e.clear()
+                e.process_views_device(K, R, t, p, a.views, S, S, nat.SC_MASK_U8_LUT)
+                e.flush()
+            for e in engs:
+                e.synchronize()
+
+        for fn, key in ((shared, "device_ms_labels_in_one_launch"), (one_by_one, "device_ms_label_by_label")):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            res[key] = (time.perf_counter() - t0) / 5 * 1e3
+        for e in engs:
+            e.close()
     v = vols["background"]
     nvv = int(np.prod(shape)) * a.views
     res.update({"workload": f"{a.views} images {S}x{S} -> stand-in net (6 labels) -> {len(use)} label(s) {use} -> {a.n}^3 {a.type} "
