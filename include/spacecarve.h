@@ -314,6 +314,10 @@ const char *sc_vol2pcd_last_error(void);
  * 1 GiB (larger ones are freed when the call ends); this gives back what is kept.  The caller's current HIP
  * device is left as it was. */
 void sc_vol2pcd_release(void);
+/* Largest device work buffers a sc_vol2pcd call may take, in bytes (default 8 GiB; 0 = no limit).  A volume that
+ * needs more (49 bytes per voxel) goes through in x-slabs with a halo of the pipeline's reach on either side:
+ * same points, same order. */
+void sc_vol2pcd_set_scratch_limit(int64_t bytes);
 void sc_free_host(void *p);
 
 /*

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "sc_vol2pcd": ("i", ["p", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_vol2pcd_last_error": ("s", []),
     "sc_vol2pcd_release": ("v", []),
+    "sc_vol2pcd_set_scratch_limit": ("v", ["q"]),
     "sc_free_host": ("v", ["p"]),
     "sc_label_points": ("i", ["p", "q", "i", "i", "p", "p", "p", "p", "i", "i", "i", "i", "p", "p"]),
     "sc_label_points_last_error": ("s", []),

@@ -45,6 +45,13 @@ def release_device_buffers():
     nat.backend().call("sc_vol2pcd_release")
 
 
+def set_scratch_limit(nbytes):
+    """Largest device work buffers a ``vol2pcd`` call may take (default 8 GiB; 0 = no limit): a volume that needs
+    more -- 49 bytes per voxel -- goes through in x-slabs with a halo, same points in the same order."""
+    from . import _native as nat
+    nat.backend().call("sc_vol2pcd_set_scratch_limit", int(nbytes))
+
+
 def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=True):
     """Converts a volume into a point-cloud with normals, on the GPU
     (``plant3dvision/proc3d.py:490-570``; same signature, ``device`` / ``as_open3d`` added).
