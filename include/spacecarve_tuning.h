@@ -61,5 +61,8 @@
                                      the survivor stages and leaves the bulk list out for 64 batches when that was less
                                      than they cost (a thin plant); 0: always on                                   */
 
+#define SC_OPT_UNIT_CULL 37       /* 1 (default): between the flags kernel and the dense stage the four units of every live
+                                     brick are asked again, one by one and over 8x8-pixel cells, by the views packed
+                                     ahead; a unit some view finds empty is carved whole, not projected; 0: not   */
 
 #endif /* SPACECARVE_TUNING_H */

@@ -109,6 +109,7 @@ struct ListCtl {
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
     uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
     uint32_t pad[26];
+    ListCounter xcd_next[8];     // dense stage: the next run-local entry of the live list for the wavefronts of XCD k
     ListCounter cand;            // .n non-zero: the flags kernel left FULL candidates open (the confirm kernel has work).
                                  // A flag on a line of its own, read before it is written: as a count (an atomic per
                                  // block, 11 ns each on one address) it cost 22 us when every brick is a candidate,
@@ -899,7 +900,7 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
                                              uint32_t k0, uint32_t lb, uint32_t lane,
-                                             const uint16_t *order = nullptr, bool seen = false) {
+                                             const uint16_t *order = nullptr, bool seen = false, uint32_t unit = 0) {
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
     // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
@@ -983,7 +984,7 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
             pos = __shfl(pos, 0);
             bulked = pos < ap.bulkcap;  // (a full sub-list: the voxels take the ordinary lists)
             if (bulked && lane == 0)
-                ap.bulk[(size_t)ap.sub * ap.bulkcap + pos] = lb * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                ap.bulk[(size_t)ap.sub * ap.bulkcap + pos] = lb * 4u + unit;
         }
         if (total != 0 && !bulked) {  // wave-uniform
             uint32_t base = 0;
@@ -1319,9 +1320,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              uint32_t bricks_y, uint32_t bricks_z,
                                                              const uint8_t *__restrict__ flags,
                                                              const uint32_t *__restrict__ live,
-                                                             const ListCtl *ctl, uint32_t nwalkers,
+                                                             ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
-                                                             uint32_t parity) {
+                                                             uint32_t parity, int nverd) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
@@ -1338,23 +1339,67 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                             Fill{init == 0 ? 1 : init, FRESH ? 1 : 0, init});
         return;
     }
+    // Walkers are WAVEFRONTS: each takes the next live brick of its XCD's runs (runs of kXcdRun consecutive entries --
+    // neighbouring bricks, which project onto the same mask lines -- stay on one XCD; a ticket counter per XCD), asks
+    // the views packed ahead about the brick's four UNITS (16 columns x 16 voxels) at the cell level, one (unit, view)
+    // pair per lane, carves the units some view finds empty without projecting a voxel -- two thirds of a plant's:
+    // the brick is live because a 32x32 tile under it touches the plant, the unit lies beside it -- and projects the
+    // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
+    // tickets keep every wavefront busy whatever the bricks hold.)
     const uint32_t nlive = ctl->nlive[parity];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t per_plane = bricks_y * bricks_z;
-    // block b of XCD (b & 7) takes entries  run * kXcdRun + i  of the runs dealt to that XCD
-    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3, per_xcd = nwalkers >> 3;
-    for (uint32_t t = seq; ; t += per_xcd) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    // (the first ticket of a wavefront is its own number among the XCD's: a thousand atomics on one address at the
+    // kernel's start would take longer than the first bricks)
+    const uint32_t per_xcd = (nwalkers >> 3) * (kBlock / 64);
+    bool first = true;
+    uint32_t misses = 0, turn = 0;
+    for (;;) {
+        uint32_t t = (blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
+        if (!first) {
+            if (lane == 0) t = per_xcd + atomicAdd(&ctl->xcd_next[xcd].n, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+        }
+        first = false;
+        t = __builtin_amdgcn_readfirstlane(t);
         const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
         if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
         if (entry >= nlive) continue;
-        const uint32_t lb = live[entry];
+        const uint32_t lb = __builtin_amdgcn_readfirstlane(live[entry]);
         const uint32_t il = lb / per_plane;
         const uint32_t rem = lb - il * per_plane;
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
-        // wavefront w: all 16 columns of the brick, voxels 16 w .. 16 w + 15 of each (lane = column * 4 + group
-        // of 4 voxels) -- a square patch of the plane, the UNIT the bulk list speaks of (see Append)
+        uint32_t culled = 0;
+        // (a wavefront whose last 8 bricks had no unit to cull -- masks without structure -- asks only about every
+        // eighth brick from then on: the verdicts cost a tenth of the projections they cannot spare there)
+        const bool ask = nverd > 0 && (misses < 8u || (turn & 7u) == 0u);
+        ++turn;
+        if (ask) {  // wave-uniform
+            const uint32_t u = lane >> 4, vq = lane & 15u;
+            uint32_t v = 0u;
+            if ((int)vq < nverd) {
+                const ViewDesc d = views[vq];  // one descriptor per lane
+                const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+                v = rect_verdict_cells(d, g, x, (int)(by * kBrickY), (int)(by * kBrickY) + kBrickY - 1,
+                                       (int)(bz * kBrickZ + u * 16u), (int)(bz * kBrickZ + u * 16u) + 15);
+            }
+            const unsigned long long e = __ballot(v == 1u);  // some view carves the whole unit
+            culled = ((e & 0xffffull) ? 1u : 0u) | (((e >> 16) & 0xffffull) ? 2u : 0u) |
+                     (((e >> 32) & 0xffffull) ? 4u : 0u) | ((e >> 48) ? 8u : 0u);
+            misses = culled ? 0u : misses + 1u;
+        }
+        // lane = column * 4 + group of 4 voxels: a square patch of the plane, the UNIT the bulk list speaks of (see Append)
         const uint32_t j = by * kBrickY + (lane >> 2);
-        brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, bz * kBrickZ + wave * 16u + (lane & 3u) * 4u, lb, lane);
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t k0 = bz * kBrickZ + u * 16u + (lane & 3u) * 4u;
+            if ((culled >> u) & 1u) {
+                if (j < g.ny && k0 < g.nz)
+                    *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
+                continue;
+            }
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, nullptr, false, u);
+        }
     }
 }
 
@@ -2792,6 +2837,7 @@ struct sc_engine {
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *packed_labels = nullptr;  // sc_values_packed: the labels at 2 or 1 bits each
+    int64_t unit_cull = 1;     // the dense stage asks the views packed ahead about every live brick's units (0: not)
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
     uint32_t *bulk = nullptr;  // units (a wavefront's share of a live brick) finished as a whole (counts in ctl->count[3])
     uint32_t bulkcap = 0;      // ... per sub-list
@@ -3170,7 +3216,7 @@ int enqueue_pack(sc_engine *e, int V, const float *K, const float *R, const floa
     uint32_t flip = pack_flip(dtype);
     bool fast = pack16_eligible(raw_dev, W, dtype, row_stride, view_stride);
     uint32_t *cmask = nullptr;
-    if (fast && e->bulk_min > 0) {  // the cell level behind the bulk units' verdicts: one word per tile
+    if (fast && (e->bulk_min > 0 || e->unit_cull)) {  // the cell level behind the units' verdicts: one word per tile
         void *cv = nullptr;
         rc = arena_alloc(e, occ_bytes * 4 * (size_t)V, &cv);
         if (rc) return rc;
@@ -3406,7 +3452,7 @@ int deferred_job(sc_engine *e, PackJob *out) {
     rc = arena_alloc(e, occ_bytes * (size_t)db.V, &occ_v);
     if (rc) return rc;
     uint32_t *cmask = nullptr;
-    if (e->bulk_min > 0) {
+    if (e->bulk_min > 0 || e->unit_cull) {
         void *cv = nullptr;
         rc = arena_alloc(e, occ_bytes * 4 * (size_t)db.V, &cv);
         if (rc) return rc;
@@ -3687,6 +3733,13 @@ int flush(sc_engine *e, size_t count = 0) {
                 }
                 const int dead_stale = e->dead_clean ? 0 : 1;  // the flags kernel rewrites them all
                 e->dead_clean = true;
+                // unit verdicts (cell level) by the views packed ahead, inside the dense stage
+                int nverd = 0;
+                if (compact && e->unit_cull) {
+                    nverd = std::min(packed_ahead, 16);
+                    for (int q = 0; q < nverd; ++q)
+                        if (e->pending[(size_t)q].cmask == nullptr) nverd = 0;
+                }
                 LaunchTimer ltf{e, SC_KERNEL_FLAGS};
                 rc = ltf.begin();
                 if (rc) return rc;
@@ -3721,11 +3774,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows, parity);
+                                       dense_store_strips, ride, (int)e->pack_rows, parity, nverd);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows, parity);
+                                       dense_store_strips, ride, (int)e->pack_rows, parity, nverd);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -4201,6 +4254,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_ITEM_BIAS:
             if (value < 0 || value > 64) return fail(SC_ERR_INVALID, "item_bias must be in [0, 64]");
             e->item_bias = value;
+            return SC_OK;
+        case SC_OPT_UNIT_CULL:
+            e->unit_cull = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_BULK_ADAPT:
             e->bulk_adapt = value ? 1 : 0;
