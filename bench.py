@@ -267,13 +267,11 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
             eng.flush()
 
         ms = host_timed(eng, torch, step, steps, warmup=2)
-        live, s0, s1n, ovf = eng.fused_counts()
         bytes_step = 4.0 * n_local + float(V) * W * H
         out[kind] = {"ms_per_step": ms, "value": n_local * V / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
                      "mask_foreground": fg,
                      "roofline_frac_hbm": bytes_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "fused_counts": {"live_bricks": live, "alive_after_dense_stage": s0,
-                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}}
+                     "fused_counts": scene_counts(eng)}
     # the reference's own configuration (configs/test_geom_pipe_real.toml:27-36 -> 301 x 301 x 561 voxels,
     # the 60 views of tests/testdata/real_plant): an unaligned grid, a third of it seen by no view
     shape_l, origin_l, vs_l, views_l = scenes.literal_real_plant_scene(60, "plant")
@@ -290,17 +288,23 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
         lit.flush()
 
     ms = host_timed(lit, torch, step_l, steps, warmup=2)
-    live, s0, s1n, ovf = lit.fused_counts()
     nl = lit.num_voxels()
     out["literal_301x301x561_60"] = {
         "ms_per_step": ms, "value": nl * Vl / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
         "roofline_frac_hbm": (4.0 * nl + float(Vl) * Wl * Hl) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "fused_counts": {"live_bricks": live, "alive_after_dense_stage": s0, "alive_after_first_list_stage": s1n,
-                         "list_overflow": ovf},
+        "fused_counts": scene_counts(lit),
         "note": "the reference's literal test configuration; 32 % of the grid is seen by no view"}
     lit.dev_free(ptr)
     lit.close()
     return out
+
+
+def scene_counts(eng):
+    """What the last fused launch left at each stage, incl. the bulk units asked about as a whole and the
+    work items their undecided views became."""
+    c = eng.fused_counts_ex()
+    c.pop("bulk_hold", None)
+    return c
 
 
 def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
