@@ -20,7 +20,10 @@
                                      works on 16x64-voxel bricks with a conservative emptiness
                                      test per brick; 0: linear blocks only                       */
 #define SC_OPT_STAGE2_VIEWS 12    /* views applied to a second survivor list (0 = no such stage)  */
-#define SC_OPT_PACK_ROWS 13       /* tile rows per block of the mask bit packer: 1, 2, 4 (default), 8 */
+#define SC_OPT_PACK_ROWS 13       /* the mask bit packer: 0 (default) the band form -- a block takes one tile row of a
+                                     view, whole picture rows read in a piece (pictures up to 2048 pixels wide, wider
+                                     ones take the panel form) --; 1, 2, 4, 8: the panel form, 128-pixel panels of that
+                                     many tile rows per block                                                      */
 #define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1024): the -1 fill of bricks found empty is done by
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */
@@ -61,8 +64,10 @@
                                      the survivor stages and leaves the bulk list out for 64 batches when that was less
                                      than they cost (a thin plant); 0: always on                                   */
 
-#define SC_OPT_UNIT_CULL 37       /* 1 (default): between the flags kernel and the dense stage the four units of every live
-                                     brick are asked again, one by one and over 8x8-pixel cells, by the views packed
-                                     ahead; a unit some view finds empty is carved whole, not projected; 0: not   */
+#define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
+                                     live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
+                                     ahead; a unit some view finds empty is carved whole, not projected -- unless
+                                     the tile level settled less than half of the bricks (masks without structure:
+                                     nothing for the cells to find); 2: asked whatever the tiles settled; 0: never */
 
 #endif /* SPACECARVE_TUNING_H */

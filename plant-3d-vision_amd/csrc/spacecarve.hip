@@ -109,7 +109,8 @@ struct ListCtl {
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
     uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
     uint32_t pad[26];
-    ListCounter xcd_next[8];     // dense stage: the next run-local entry of the live list for the wavefronts of XCD k
+    ListCounter xcd_next[64];    // dense stage: ticket counters for the live list, 8 per XCD (index xcd * 8 + c: the
+                                 // wavefronts of XCD k whose number ends in c share one; see carve_brick_kernel)
     ListCounter cand;            // .n non-zero: the flags kernel left FULL candidates open (the confirm kernel has work).
                                  // A flag on a line of its own, read before it is written: as a count (an atomic per
                                  // block, 11 ns each on one address) it cost 22 us when every brick is a candidate,
@@ -513,6 +514,85 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(PackJob pj) {
     pack16_block<ROWS>(pj, blockIdx.x);
 }
 
+// The same ingest in BAND form (SC_OPT_PACK_ROWS 0, the default for pictures up to kBandTiles tiles wide): a
+// block takes one tile row of a view -- 32 picture rows, W bytes each, one contiguous run of memory when the rows
+// are not padded -- as a list of 16-pixel tasks in row-major order, 256 at a time, so that a wavefront load reads
+// 1 KB in one piece, and writes the band's tiles (contiguous in the packed arena) from LDS in 16-byte pieces.
+// Measured on one MI355X, 72 masks resident in the Infinity Cache (tools/probes/pack_shape.py): the panel form
+// takes 36 us on 1440 x 1080 pictures (a block's 16 KB lie in 128 pieces 1440 B apart, and 12 % of the panel
+// blocks hang over the picture's edges) and 24 us on the same bytes as 128 x 12150 pictures, where a block's
+// bytes are one run.  Tasks per row are rounded up to an even number: the two halves of a tile row word sit in
+// neighbouring lanes.
+constexpr int kBandTiles = 64;   // widest picture of the band form: 2048 pixels
+#ifndef SC_BAND_PHASE
+#define SC_BAND_PHASE 6
+#endif
+constexpr int kBandPhase = SC_BAND_PHASE;    // 16-byte loads in flight per lane
+
+__device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
+    __shared__ alignas(16) uint32_t band_s[kBandTiles * 32];  // the band's tile words, as they lie in the packed arena
+    __shared__ uint32_t cmb_s[kBandTiles];        // per tile: cells with some foreground | with some background << 16
+    const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
+    const uint32_t flip = pj.flip;
+    const uint32_t tid = threadIdx.x;
+    const int ty = (int)(b % (uint32_t)tiles_y);
+    int slot = (int)(b / (uint32_t)tiles_y);
+    if (slot >= pj.nslots) return;  // block-uniform
+    slot += pj.slot0;
+    const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
+    const uint8_t *raw = pj.raw + view * pj.view_stride + (int64_t)ty * 32 * pj.row_stride;
+    const int cpr = W >> 4;                    // 16-pixel chunks per row (W % 16 == 0)
+    const uint32_t cprp = 2u * (uint32_t)tiles_x;  // ... rounded up to an even number
+    const uint32_t ntasks = 32u * cprp;
+    const int rows_here = min(32, H - ty * 32);
+    if (tid < (uint32_t)tiles_x) cmb_s[tid] = 0u;
+    // task q = tid + 256 i: row q / cprp, chunk q % cprp, stepped without a division
+    uint32_t row = tid / cprp, c = tid - row * cprp;
+    const uint32_t drow = (uint32_t)kBlock / cprp, dc = (uint32_t)kBlock - drow * cprp;
+    bool synced = false;
+    for (uint32_t base = 0; base < ntasks; base += (uint32_t)kBlock * kBandPhase) {
+        uint4 q[kBandPhase];
+        uint32_t rr[kBandPhase], cc[kBandPhase];
+#pragma unroll
+        for (int i = 0; i < kBandPhase; ++i) {
+            rr[i] = row; cc[i] = c;
+            q[i] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
+            if ((int)row < rows_here && (int)c < cpr)
+                q[i] = *reinterpret_cast<const uint4 *>(raw + (int64_t)row * pj.row_stride + (int64_t)c * 16);
+            row += drow; c += dc;
+            if (c >= cprp) { c -= cprp; ++row; }
+        }
+        if (!synced) { __syncthreads(); synced = true; }  // cmb_s is zero for everybody (block-uniform branch)
+#pragma unroll
+        for (int i = 0; i < kBandPhase; ++i) {
+            const uint32_t half = nonzero_nibble(q[i].x ^ flip) | (nonzero_nibble(q[i].y ^ flip) << 4) |
+                                  (nonzero_nibble(q[i].z ^ flip) << 8) | (nonzero_nibble(q[i].w ^ flip) << 12);
+            const uint32_t other = __shfl_xor(half, 1);  // the task next door: same row, the tile's other half
+            if (rr[i] < 32u) {                           // (tasks past the band's end belong to nobody)
+                if ((cc[i] & 1u) == 0u) band_s[(cc[i] >> 1) * 32u + rr[i]] = half | (other << 16);
+                // the task's 16 pixels are two 8-pixel cells of cell row rr >> 3
+                const uint32_t fa = (half & 0xffu) != 0u, fb = (half >> 8) != 0u;
+                const uint32_t ha = (half & 0xffu) != 0xffu, hb = (half >> 8) != 0xffu;  // padding: background
+                const uint32_t bit = (rr[i] >> 3) * 4u + (cc[i] & 1u) * 2u;
+                atomicOr(&cmb_s[cc[i] >> 1], ((fa | (fb << 1)) << bit) | ((ha | (hb << 1)) << (16u + bit)));
+            }
+        }
+    }
+    __syncthreads();
+    // the band's tiles: tiles_x * 32 words in a row in the packed arena
+    uint4 *dst = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * tiles_x * 32);
+    const uint4 *src = reinterpret_cast<const uint4 *>(band_s);
+    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) dst[i] = src[i];
+    if (tid < (uint32_t)tiles_x) {
+        const uint32_t cm = cmb_s[tid];
+        const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + tid;
+        pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+        if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pack_band_kernel(PackJob pj) { pack_band_block(pj, blockIdx.x); }
+
 // ---- brick form of the dense stage -------------------------------------------------------
 // A block takes a BRICK of 16 columns (along y) x 64 voxels (along z) instead of 1024 consecutive
 // voxels (bricks at the far y / z faces may stick out of the grid; any ny, nz with nz <= 4096): wavefront w owns columns 4w..4w+3, lane l the
@@ -892,15 +972,11 @@ __device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db
     }
 }
 
-// ORDERED: the views are views[order[0..nviews)] (a list in LDS: only the views that still have a say
-// about this brick, see the late bricks of carve_resume_kernel), and `seen` says that a view left out of
-// that list saw the whole brick over foreground: a label still 0 at the end becomes 1.
-template <bool FRESH, bool ORDERED = false>
+template <bool FRESH>
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
-                                             uint32_t k0, uint32_t lb, uint32_t lane,
-                                             const uint16_t *order = nullptr, bool seen = false, uint32_t unit = 0) {
+                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0) {
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
     // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
@@ -944,21 +1020,11 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     for (int vi = 0; vi < nviews; vi += 2) {
         if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
         const bool two = vi + 1 < nviews;      // wave-uniform
-        int ia = vi, ib = two ? vi + 1 : vi;
-        if (ORDERED) {
-            ia = __builtin_amdgcn_readfirstlane((int)order[ia]);
-            ib = __builtin_amdgcn_readfirstlane((int)order[ib]);
-        }
-        const ViewDesc da = views[ia];
-        const ViewDesc db = views[ib];
+        const ViewDesc da = views[vi];
+        const ViewDesc db = views[two ? vi + 1 : vi];
         two_views(da, db, two, x, y, z, lab, alive);
     }
 
-    if (ORDERED && seen) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (lab[e] == 0) lab[e] = 1;  // :81 by a view that was not worth projecting for
-    }
     if (vec) {
         bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
         if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
@@ -1322,13 +1388,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              const uint32_t *__restrict__ live,
                                                              ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
-                                                             uint32_t parity, int nverd) {
+                                                             uint32_t parity, int nverd_arg, uint32_t verd_max_live) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
         // panel: persistent riders measured the same or slower.
         const uint32_t b = blockIdx.x - nwalkers - nstore;
-        if (pack_rows == 1) pack16_block<1>(ride, b);
+        if (pack_rows == 0) pack_band_block(ride, b);
+        else if (pack_rows == 1) pack16_block<1>(ride, b);
         else if (pack_rows == 2) pack16_block<2>(ride, b);
         else if (pack_rows == 8) pack16_block<8>(ride, b);
         else pack16_block<4>(ride, b);
@@ -1347,6 +1414,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
     // tickets keep every wavefront busy whatever the bricks hold.)
     const uint32_t nlive = ctl->nlive[parity];
+    // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
+    const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t xcd = blockIdx.x & 7u;
@@ -1358,8 +1427,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     for (;;) {
         uint32_t t = (blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
         if (!first) {
-            if (lane == 0) t = per_xcd + atomicAdd(&ctl->xcd_next[xcd].n, 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
+            // eight counters per XCD, each dealing every eighth run of the XCD's entries to the wavefronts whose
+            // number ends in c: returning atomics on one address take 11 ns each, and with one counter per XCD the
+            // 1 500 tickets of a plant's batch were 16 us of them in a row
+            const uint32_t c = t & 7u;
+            uint32_t n = 0;
+            if (lane == 0) n = atomicAdd(&ctl->xcd_next[xcd * 8u + c].n, 1u);
+            n = __builtin_amdgcn_readfirstlane(n);
+            t = per_xcd + ((n / kXcdRun) * 8u + c) * kXcdRun + (n % kXcdRun);
         }
         first = false;
         t = __builtin_amdgcn_readfirstlane(t);
@@ -1398,7 +1473,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, nullptr, false, u);
+#if defined(SC_TIMING_VARIANT) && SC_TIMING_VARIANT == 3
+            continue;
+#elif defined(SC_TIMING_VARIANT) && SC_TIMING_VARIANT == 2
+            { Append none = ap; none.list = nullptr; brick_voxels<FRESH>(labels, g, views, nviews, init, none, il, j, k0, lb, lane, u); }
+#else
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+#endif
         }
     }
 }
@@ -2825,7 +2906,7 @@ struct sc_engine {
     int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
     int64_t defer_stores = 1024;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
-    int64_t pack_rows = 4;     // tile rows per block of the 16-byte pack kernel (1, 2, 4, 8)
+    int64_t pack_rows = 0;     // 0: the band form of the 16-byte pack kernel; 1, 2, 4, 8: the panel form, tile rows per block
     int64_t view_brick = 1;    // a single-view carve launch goes through the brick kernels too (0: streaming kernel)
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
     bool dead_clean = false;   // `dead` describes the labels (false after a clear: the next flags kernel rewrites it)
@@ -2837,7 +2918,8 @@ struct sc_engine {
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *packed_labels = nullptr;  // sc_values_packed: the labels at 2 or 1 bits each
-    int64_t unit_cull = 1;     // the dense stage asks the views packed ahead about every live brick's units (0: not)
+    int64_t unit_cull = 1;     // the dense stage asks the views packed ahead about every live brick's units (0: not;
+                               // 2: even when the tiles settled less than half of the bricks)
     uint32_t *late = nullptr;  // FULL candidates a later view rejected (count in ctl->nlate)
     uint32_t *bulk = nullptr;  // units (a wavefront's share of a live brick) finished as a whole (counts in ctl->count[3])
     uint32_t bulkcap = 0;      // ... per sub-list
@@ -3164,20 +3246,31 @@ PackJob make_pack_job(const void *raw_dev, int64_t row_stride, int64_t view_stri
     return pj;
 }
 
+// 0: the band form (pictures up to kBandTiles tiles wide, packed arena 16-byte aligned per band); else the panel
+// form with that many tile rows per block
+int pack_form(const sc_engine *e, const PackJob &pj) {
+    // (narrow pictures make bands of a few hundred tasks, less than a block's worth: 128-pixel pictures took 61 us
+    // in bands against 24 in panels)
+    if (e->pack_rows == 0 && pj.tiles_x >= 16 && pj.tiles_x <= kBandTiles) return 0;
+    return e->pack_rows == 0 ? 4 : (int)e->pack_rows;
+}
+
 int64_t pack16_blocks(const sc_engine *e, const PackJob &pj) {
-    const int rows = (int)e->pack_rows;
+    const int rows = pack_form(e, pj);
+    if (rows == 0) return (int64_t)pj.nslots * pj.tiles_y;
     return (int64_t)pj.nslots * ((pj.tiles_y + rows - 1) / rows) * ((pj.tiles_x + 3) / 4);
 }
 
 // slots [pj.slot0, pj.slot0 + pj.nslots) as a launch of their own
 int launch_pack16(sc_engine *e, const PackJob &pj) {
     if (pj.nslots <= 0) return SC_OK;
-    const int rows = (int)e->pack_rows;
+    const int rows = pack_form(e, pj);
     int64_t blocks = pack16_blocks(e, pj);
     if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
 #define LAUNCH_PACK16(ROWS) \
     hipLaunchKernelGGL(pack16_kernel<ROWS>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, pj)
-    if (rows == 1) LAUNCH_PACK16(1);
+    if (rows == 0) hipLaunchKernelGGL(pack_band_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, pj);
+    else if (rows == 1) LAUNCH_PACK16(1);
     else if (rows == 2) LAUNCH_PACK16(2);
     else if (rows == 8) LAUNCH_PACK16(8);
     else LAUNCH_PACK16(4);
@@ -3735,6 +3828,7 @@ int flush(sc_engine *e, size_t count = 0) {
                 e->dead_clean = true;
                 // unit verdicts (cell level) by the views packed ahead, inside the dense stage
                 int nverd = 0;
+                const uint32_t verd_max_live = e->unit_cull == 2 ? 0xffffffffu : (uint32_t)(nbricks / 2);
                 if (compact && e->unit_cull) {
                     nverd = std::min(packed_ahead, 16);
                     for (int q = 0; q < nverd; ++q)
@@ -3774,11 +3868,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows, parity, nverd);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, (int)e->pack_rows, parity, nverd);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -4202,8 +4296,8 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             e->defer_stores = value;
             return SC_OK;
         case SC_OPT_PACK_ROWS:
-            if (value != 1 && value != 2 && value != 4 && value != 8)
-                return fail(SC_ERR_INVALID, "pack_rows must be 1, 2, 4 or 8");
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+                return fail(SC_ERR_INVALID, "pack_rows must be 0, 1, 2, 4 or 8");
             e->pack_rows = value;
             return SC_OK;
         case SC_OPT_VIEW_BRICK:
@@ -4256,7 +4350,8 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             e->item_bias = value;
             return SC_OK;
         case SC_OPT_UNIT_CULL:
-            e->unit_cull = value ? 1 : 0;
+            if (value < 0 || value > 2) return fail(SC_ERR_INVALID, "unit_cull must be 0, 1 or 2");
+            e->unit_cull = value;
             return SC_OK;
         case SC_OPT_BULK_ADAPT:
             e->bulk_adapt = value ? 1 : 0;

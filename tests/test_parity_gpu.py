@@ -174,6 +174,11 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_BULK_MIN": 1},                                               # every unit with a voxel alive is
     {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0},
     {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8},
+    {"SC_OPT_PACK_ROWS": 4},                                              # the panel form of the pack kernel
+    {"SC_OPT_PACK_ROWS": 8, "SC_OPT_PACK_RIDE": 0},
+    {"SC_OPT_UNIT_CULL": 0},                                              # no unit verdicts in the dense stage
+    {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1},                        # ... asked whatever the tiles settled
+    {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
                                         ("dense", (14, 48, 192)),    # a bulky object: whole-brick masks at work
@@ -1053,6 +1058,10 @@ def test_brick_verdicts_on_adversarial_cameras(gpu_device, kw, kind):
         assert (want != 0).mean() > 0.03  # part of the grid really is in the picture
     got, _ = _device_batch_carve(shape, origin, vs, views)
     assert np.array_equal(got, want), (kw, kind, "device batch", histogram3(got), histogram3(want))
+    # the verdicts below the brick asked of every unit, whatever the heuristics would decide
+    got, _ = _device_batch_carve(shape, origin, vs, views, opts=((nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
+                                                                   (nat.SC_OPT_BULK_ADAPT, 0)))
+    assert np.array_equal(got, want), (kw, kind, "device batch, unit verdicts forced", histogram3(got), histogram3(want))
     got = hip_carve(shape, origin, vs, views)
     assert np.array_equal(got, want), (kw, kind, "host masks")
     table = img_as_float32(np.arange(256, dtype=np.uint8))
