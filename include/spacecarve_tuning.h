@@ -24,7 +24,7 @@
                                      view, whole picture rows read in a piece (pictures up to 2048 pixels wide, wider
                                      ones take the panel form) --; 1, 2, 4, 8: the panel form, 128-pixel panels of that
                                      many tile rows per block                                                      */
-#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1024): the -1 fill of bricks found empty is done by
+#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1280): the -1 fill of bricks found empty is done by
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */

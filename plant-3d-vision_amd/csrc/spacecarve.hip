@@ -524,10 +524,7 @@ __global__ __launch_bounds__(kBlock) void pack16_kernel(PackJob pj) {
 // bytes are one run.  Tasks per row are rounded up to an even number: the two halves of a tile row word sit in
 // neighbouring lanes.
 constexpr int kBandTiles = 64;   // widest picture of the band form: 2048 pixels
-#ifndef SC_BAND_PHASE
-#define SC_BAND_PHASE 6
-#endif
-constexpr int kBandPhase = SC_BAND_PHASE;    // 16-byte loads in flight per lane
+constexpr int kBandPhase = 6;    // 16-byte loads in flight per lane (3, 4, 6, 12: the same within a microsecond)
 
 __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
     __shared__ alignas(16) uint32_t band_s[kBandTiles * 32];  // the band's tile words, as they lie in the packed arena
@@ -1379,6 +1376,9 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
 // (neighbouring bricks, which project onto the same mask lines) stay on one XCD.  Blocks behind
 // the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
 // stage fills the others, see carve_list_kernel).
+#ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront did, and when
+__device__ uint32_t g_dense_trace[8192 * 8];
+#endif
 template <bool FRESH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
@@ -1424,7 +1424,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     const uint32_t per_xcd = (nwalkers >> 3) * (kBlock / 64);
     bool first = true;
     uint32_t misses = 0, turn = 0;
+#ifdef SC_TRACE_DENSE
+    const uint64_t tr0 = wall_clock64();
+    uint32_t tr_bricks = 0, tr_units = 0, tr_verd = 0, tr_unit = 0, tr_tick = 0;
+#endif
     for (;;) {
+#ifdef SC_TRACE_DENSE
+        const uint64_t tra = wall_clock64();
+#endif
         uint32_t t = (blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
         if (!first) {
             // eight counters per XCD, each dealing every eighth run of the XCD's entries to the wavefronts whose
@@ -1446,6 +1453,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         const uint32_t rem = lb - il * per_plane;
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
         uint32_t culled = 0;
+#ifdef SC_TRACE_DENSE
+        const uint64_t trb = wall_clock64();
+        tr_tick += (uint32_t)(trb - tra);
+        ++tr_bricks;
+#endif
         // (a wavefront whose last 8 bricks had no unit to cull -- masks without structure -- asks only about every
         // eighth brick from then on: the verdicts cost a tenth of the projections they cannot spare there)
         const bool ask = nverd > 0 && (misses < 8u || (turn & 7u) == 0u);
@@ -1464,6 +1476,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                      (((e >> 32) & 0xffffull) ? 4u : 0u) | ((e >> 48) ? 8u : 0u);
             misses = culled ? 0u : misses + 1u;
         }
+#ifdef SC_TRACE_DENSE
+        const uint64_t trc = wall_clock64();
+        tr_verd += (uint32_t)(trc - trb);
+#endif
         // lane = column * 4 + group of 4 voxels: a square patch of the plane, the UNIT the bulk list speaks of (see Append)
         const uint32_t j = by * kBrickY + (lane >> 2);
         for (uint32_t u = 0; u < 4u; ++u) {
@@ -1473,16 +1489,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-#if defined(SC_TIMING_VARIANT) && SC_TIMING_VARIANT == 3
-            continue;
-#elif defined(SC_TIMING_VARIANT) && SC_TIMING_VARIANT == 2
-            { Append none = ap; none.list = nullptr; brick_voxels<FRESH>(labels, g, views, nviews, init, none, il, j, k0, lb, lane, u); }
-#else
             brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+#ifdef SC_TRACE_DENSE
+            ++tr_units;
 #endif
         }
+#ifdef SC_TRACE_DENSE
+        tr_unit += (uint32_t)(wall_clock64() - trc);
+#endif
     }
+#ifdef SC_TRACE_DENSE
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+        if (w < 8192u) {
+            uint32_t *o = g_dense_trace + w * 8u;
+            o[0] = (uint32_t)tr0; o[1] = (uint32_t)wall_clock64(); o[2] = tr_bricks; o[3] = tr_units;
+            o[4] = tr_verd; o[5] = tr_unit; o[6] = tr_tick; o[7] = 0;
+        }
+    }
+#endif
 }
+#ifdef SC_TRACE_DENSE
+}  // namespace
+extern "C" int sc_debug_dense_trace(uint32_t *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_trace), sizeof(uint32_t) * 8192 * 8);
+}
+namespace {
+#endif
 
 // The dense kernel of a launch WITHOUT survivor stages (fewer than 6 views; a single view in the
 // reference's cadence, cl.py:223-226): walkers on the live list as above, and persistent FILLERS on
@@ -2905,7 +2938,8 @@ struct sc_engine {
     int64_t stage1_store_share = 4;  // sixteenths of the deferred strips filled beside the FIRST list stage
     int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
-    int64_t defer_stores = 1024;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them)
+    int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them);
+                                  // 5 per CU beside 2 store blocks: 1024 -> 1280 is worth 4-5 % on bulky scenes, nothing on a plant; 1536 loses
     int64_t pack_rows = 0;     // 0: the band form of the 16-byte pack kernel; 1, 2, 4, 8: the panel form, tile rows per block
     int64_t view_brick = 1;    // a single-view carve launch goes through the brick kernels too (0: streaming kernel)
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
