@@ -480,8 +480,8 @@ def e2e_host(a, shape, origin, vs, views, device, reps):
     return {"ms": best * 1e3, "ms_all": [x * 1e3 for x in ts], "value": n * V / best / 1e6, "unit": "Mvoxel*views/s",
             "reps": reps, "labels_histogram": hist,
             "note": f"{V} uint8 masks in host memory -> Backprojection.process_view x {V} -> get_values(): int32 "
-                    f"[{shape[0]}][{shape[1]}][{shape[2]}] in host memory; PCIe both ways (labels cross as int8 and are "
-                    f"widened on host threads); best of {reps}"}
+                    f"[{shape[0]}][{shape[1]}][{shape[2]}] in host memory; PCIe both ways (labels cross at 2 bits "
+                    f"each, in pieces, and are widened by host threads inside the library as they land); best of {reps}"}
 
 
 def main():

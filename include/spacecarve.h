@@ -231,6 +231,12 @@ int sc_values_device_ptr(sc_engine *e, void **ptr);
 int64_t sc_packed_bytes(int64_t voxels, int bits);
 int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes);
 int sc_get_values_packed(sc_engine *e, int bits, void *out);
+/* cl.py:229-232 get_values of a carve volume, the fast way round: the labels cross PCIe at 2 bits each, in pieces,
+ * and `threads` host threads (<= 0: 8) widen the pieces that have arrived into out[voxels] (int32, the array the
+ * reference returns) while the next ones are on their way.  staging: host memory of at least
+ * sc_packed_bytes(voxels, 2) bytes the call may scribble on (the caller's, so that its pages can be touched ahead).
+ * SC_ERR_STATE unless default_value is one of -1, 0, 1 (use sc_get_values / sc_get_values_i8 then). */
+int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads);
 int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
                      int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes);
 

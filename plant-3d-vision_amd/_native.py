@@ -70,6 +70,7 @@ _SIGNATURES = {
     "sc_packed_bytes": ("q", ["q", "i"]),
     "sc_values_packed": ("i", ["p", "i", "p", "p"]),
     "sc_get_values_packed": ("i", ["p", "i", "p"]),
+    "sc_get_values_wire2": ("i", ["p", "p", "p", "q", "i"]),
     "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
@@ -550,6 +551,18 @@ class Engine:
         if out.dtype != np.int8 or out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
             raise ValueError("output buffer has the wrong dtype/size/layout")
         self._call("sc_get_values_i8", addr(out))
+        return out
+
+    def get_values_wire2(self, out, staging, threads=None):
+        """Carve labels into the int32 array ``out``: 2 bits each over PCIe in pieces, widened on host threads inside
+        the library as the pieces land (``sc_get_values_wire2``).  ``staging``: a host array of at least a quarter
+        of a byte per voxel the call may scribble on."""
+        if out.dtype != np.int32 or out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("output buffer has the wrong dtype/size/layout")
+        if not staging.flags["C_CONTIGUOUS"]:
+            raise ValueError("the staging buffer must be contiguous")
+        self._call("sc_get_values_wire2", addr(out), addr(staging), int(staging.nbytes),
+                   int(threads if threads is not None else host_workers(16)))
         return out
 
     def values_device_ptr(self):

@@ -37,12 +37,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "spacecarve.h"
@@ -4862,6 +4864,63 @@ int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes) {
     // (the tail of the last 16-byte group is never read by a consumer that knows the voxel count)
     *ptr = e->packed_labels;
     *bytes = nbytes;
+    return SC_OK;
+}
+
+namespace {
+// words [w0, w1) of 2-bit labels (16 per word, label = the pair sign-extended) into int32
+void widen2_range(const uint32_t *src, int32_t *dst, int64_t w0, int64_t w1, int64_t n) {
+    for (int64_t w = w0; w < w1; ++w) {
+        const uint32_t x = src[w];
+        int32_t *o = dst + w * 16;
+        if (w * 16 + 16 <= n) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = (int32_t)(x << (30 - 2 * i)) >> 30;
+        } else {
+            for (int i = 0; w * 16 + i < n; ++i) o[i] = (int32_t)(x << (30 - 2 * i)) >> 30;
+        }
+    }
+}
+}  // namespace
+
+int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads) {
+    if (!e || !out || !staging) return fail(SC_ERR_INVALID, "null argument");
+    void *ptr = nullptr;
+    int64_t bytes = 0;
+    int rc = sc_values_packed(e, 2, &ptr, &bytes);
+    if (rc) return rc;
+    const int64_t n = e->n, words = (n + 15) / 16;
+    if (staging_bytes < words * 4) return fail(SC_ERR_INVALID, "staging buffer too small: %lld bytes needed", (long long)(words * 4));
+    if (threads <= 0) threads = 8;
+    threads = std::min(threads, 64);
+    // pieces of 1 MiB of packed labels (16 MiB of int32): copied in order, widened as they land
+    const int64_t piece = (int64_t)1 << 18;  // words
+    const int64_t npieces = (words + piece - 1) / piece;
+    std::atomic<int64_t> landed{0};
+    std::atomic<int> failed{0};
+    uint32_t *stg = static_cast<uint32_t *>(staging);
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads);
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t]() {
+            for (int64_t k = t; k < npieces; k += threads) {
+                while (landed.load(std::memory_order_acquire) <= k) {
+                    if (failed.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                widen2_range(stg, out, k * piece, std::min(words, (k + 1) * piece), n);
+            }
+        });
+    hipError_t err = hipSuccess;
+    for (int64_t k = 0; k < npieces && err == hipSuccess; ++k) {
+        const int64_t w0 = k * piece, w1 = std::min(words, (k + 1) * piece);
+        err = hipMemcpyAsync(stg + w0, static_cast<const uint32_t *>(ptr) + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+        if (err == hipSuccess) landed.store(k + 1, std::memory_order_release);
+    }
+    if (err != hipSuccess) failed.store(1);
+    for (auto &th : pool) th.join();
+    if (err != hipSuccess) return fail(SC_ERR_DEVICE, "label read-back failed: %s", hipGetErrorString(err));
     return SC_OK;
 }
 

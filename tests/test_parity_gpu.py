@@ -1185,6 +1185,46 @@ def test_int8_read_back_of_carve_labels(gpu_device):
     bp.close()
 
 
+def test_read_back_over_the_two_bit_wire(gpu_device):
+    """sc_get_values_wire2: three-state labels cross PCIe at 2 bits each in pieces and are widened to the int32
+    array of cl.py:229-232 by host threads inside the library -- voxel counts that are not multiples of 16, more
+    pieces than threads and fewer, every default value two bits hold; other default values are refused and the
+    class takes the int8 route for them."""
+    for shape, nviews in (((40, 33, 70), 6), ((3, 5, 7), 3), ((70, 256, 260), 5)):
+        shape, origin, vs, views = scene(shape, nviews, "plant")
+        n = int(np.prod(shape))
+        for dv in (0, 1, -1):
+            want = oracle_c.carve(list(shape), origin, vs, views, dv, nthreads=4)
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=float(dv))
+            out = np.full(n, 99, dtype=np.int32)
+            staging = np.empty((n + 15) // 16 * 4 + 16, dtype=np.uint8)
+            e.get_values_wire2(out, staging, threads=3)  # before any view
+            assert (out == dv).all()
+            for K, R, t, m in views:
+                e.process_view(K, R, t, m, nat.SC_MASK_U8)
+            for threads in (1, 5, 16):
+                out[:] = 99
+                e.get_values_wire2(out, staging, threads=threads)
+                assert np.array_equal(out.reshape(shape), want), (shape, dv, threads)
+            with pytest.raises(ValueError, match="staging"):
+                e.get_values_wire2(out, staging[:8])
+            e.close()
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=7.0)
+    with pytest.raises(nat.SpaceCarveError, match="two bits cannot hold"):
+        e.get_values_wire2(np.empty(n, dtype=np.int32), np.empty(n, dtype=np.uint8))
+    e.close()
+    # the class: 2^24+ voxels and a default value of -1 / 0 / 1 take this route, 7 the int8 one
+    big, origin, vs, views = scene((64, 512, 512), 6, "plant")
+    for dv in (-1, 7):
+        want = oracle_c.carve(list(big), origin, vs, views, dv, nthreads=8)
+        bp = Backprojection(big, origin, vs, default_value=dv)
+        for K, R, t, m in views:
+            bp.process_view(K, R, t, m)
+        got = bp.get_values()
+        assert got.dtype == np.int32 and np.array_equal(got, want), dv
+        bp.close()
+
+
 @pytest.mark.parametrize("default_value", [0, 1, -1, 5])
 @pytest.mark.parametrize("kind", ["plant", "solid", "dense"])
 def test_bricks_no_view_sees_keep_their_labels(gpu_device, kind, default_value):
