@@ -125,7 +125,7 @@ class SpaceCarveError(RuntimeError):
 def build(force=False):
     """Compile ``csrc/spacecarve.hip`` for gfx950 into ``libspacecarve.so`` (in-tree)."""
     csrc = os.path.join(_PKG_DIR, "csrc")
-    deps = [os.path.join(csrc, f) for f in ("spacecarve.hip", "vol2pcd.hip", "label_points.hip", "pngdec.cpp", "Makefile")]
+    deps = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile"]
     deps.append(HEADER_PATH)
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):

@@ -1,0 +1,682 @@
+// Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- the dense stage on live bricks: brick_voxels, fills, unit verdicts, the confirm kernel, carve_brick_kernel, the light and the per-view kernels.
+
+// Two views applied to the four voxels of a lane: both projections first, then the eight gathers of a
+// lane in one flight (the kernels that call this wait on memory, not on arithmetic), then
+// backprojection.c:79-83 for the first view and, for what it left alive, for the second.
+__device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db, bool two, float x, float y,
+                                          const float (&z)[4], int32_t (&lab)[4], uint32_t &alive) {
+    const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
+    const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
+    const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
+    const uint32_t *bitb = static_cast<const uint32_t *>(db.mask);
+    bool oka[4], okb[4];
+    uint32_t wa[4], wb[4];
+    int sha[4], shb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int u, v;
+        const bool live = (alive >> e) & 1u;
+        oka[e] = project(aax, aay, aaz, z[e], da, u, v) & live;
+        sha[e] = u & 31;
+        wa[e] = load_mask_word(bita, oka[e] ? mask_word_index(u, v, da.tiles_x) : 0u);
+        okb[e] = project(bax, bay, baz, z[e], db, u, v) & live & two;
+        shb[e] = u & 31;
+        wb[e] = load_mask_word(bitb, okb[e] ? mask_word_index(u, v, db.tiles_x) : 0u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (oka[e]) {
+            if (((wa[e] >> sha[e]) & 1u) == 0) {  // :79
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {  // :81
+                lab[e] = 1;
+            }
+        }
+        if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
+            if (((wb[e] >> shb[e]) & 1u) == 0) {
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {
+                lab[e] = 1;
+            }
+        }
+    }
+}
+
+template <bool FRESH>
+__device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
+                                             const ViewDesc *__restrict__ views, int nviews,
+                                             int32_t init, Append ap, uint32_t il, uint32_t j,
+                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0) {
+    // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
+    // nothing (they still take part in the wave-wide ballots), a group at the end of a column
+    // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const bool vec = (g.nzp & 3u) == 0;  // grid-uniform (the pitch is a multiple of 64: always)
+    const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nzp + k0;
+    int32_t *p = labels + elem;
+    int32_t lab[4], was[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lab[e] = -1;  // what a lane does not own counts as carved
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = init;
+    } else if (vec) {
+        if (inside) {
+            int4 q = *reinterpret_cast<const int4 *>(p);
+            lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = p[e];
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        was[e] = lab[e];
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
+
+    for (int vi = 0; vi < nviews; vi += 2) {
+        if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
+        const bool two = vi + 1 < nviews;      // wave-uniform
+        const ViewDesc da = views[vi];
+        const ViewDesc db = views[two ? vi + 1 : vi];
+        two_views(da, db, two, x, y, z, lab, alive);
+    }
+
+    if (vec) {
+        bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
+    }
+
+    if (ap.list != nullptr) {
+        ap.sub = (lb * 0x9E3779B1u) >> 24;
+        unsigned long long b[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = __ballot((alive >> e) & 1u);
+            total += (uint32_t)__popcll(b[e]);
+        }
+        bool bulked = false;
+        if (ap.bulk != nullptr && total >= ap.bulk_min) {  // wave-uniform
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&ap.ctl->count[3][ap.sub].n, 1u);
+            pos = __shfl(pos, 0);
+            bulked = pos < ap.bulkcap;  // (a full sub-list: the voxels take the ordinary lists)
+            if (bulked && lane == 0)
+                ap.bulk[(size_t)ap.sub * ap.bulkcap + pos] = lb * 4u + unit;
+        }
+        if (total != 0 && !bulked) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ap.ctl->count[0][ap.sub].n, total);
+            base = __shfl(base, 0);
+            if (base + total > ap.subcap) {
+                if (lane == 0) ap.ctl->overflow = 1u;
+            } else {
+                uint32_t *dst = ap.list + (size_t)ap.sub * ap.subcap + base;
+                unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                uint32_t off = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((alive >> e) & 1u) {
+                        uint32_t rank = off + (uint32_t)__popcll(b[e] & below);
+                        dst[rank] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
+                    }
+                    off += (uint32_t)__popcll(b[e]);
+                }
+            }
+        }
+    }
+}
+
+// The bricks of a strip the flags kernel has settled.  EMPTY (flag 1): live voxels become -1, dead
+// ones are -1 already -- one 16-byte store per lane and brick, nothing else.  FULL (flag 2): every
+// view keeps every voxel, so a label 0 becomes 1 and any other label stays (backprojection.c:81):
+// `kept` is that value for a volume known to hold `init` everywhere (fresh), else the labels are
+// read, patched and written back.
+struct Fill {
+    int32_t kept;   // label of a FULL brick's voxels when the volume is fresh: init == 0 ? 1 : init
+    int32_t fresh;  // the volume holds `init` everywhere (nothing applied since clear)
+    int32_t init;   // ... and this is what an UNTOUCHED brick (flag 6) of a fresh volume gets
+};
+
+__device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
+                                                    const uint8_t *__restrict__ flags, uint32_t strip,
+                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
+    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+    const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
+    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
+    // UNTOUCHED bricks (6) keep their labels: only a fresh volume, whose labels exist as `init` in name
+    // only, has something to write there
+    const unsigned long long untouched = fill.fresh ? __ballot(f == 6u) : 0ull;
+    if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
+    int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nzp;
+    const bool vec = (g.nzp & 3u) == 0;
+    for (uint32_t bz = 0; bz < bricks_z; ++bz) {
+        const bool isfull = (full >> bz) & 1ull, isunt = (untouched >> bz) & 1ull;
+        if (!((culled >> bz) & 1ull) && !isfull && !isunt) continue;
+        const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+        if (k0 >= g.nz) continue;
+        const uint32_t n = min(4u, g.nz - k0);
+        if (!isfull || fill.fresh) {
+            const int32_t val = isunt ? fill.init : (isfull ? fill.kept : -1);
+            if (vec) {
+                // streaming store: the fill is written once and not read again by this batch; kept
+                // out of the caches it does not evict the masks the next batch packs
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i vv = {val, val, val, val};
+                __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(col + k0));
+            } else {
+                for (uint32_t e = 0; e < n; ++e) col[k0 + e] = val;
+            }
+        } else {  // FULL brick of a stored volume: 0 -> 1, the rest as it is
+            for (uint32_t e = 0; e < n; ++e)
+                if (col[k0 + e] == 0) col[k0 + e] = 1;
+        }
+    }
+}
+
+// The UNITS of the bulk list (a wavefront's share of a live brick -- its 16 columns, voxels 16w .. 16w + 15 of
+// each: a square patch of the plane -- with most of its voxels alive after the dense views) are asked about as a whole before anything projects
+// their voxels: every remaining view at once, one view per lane, at the cell level (rect_verdict_cells).
+//   some view sees the unit entirely over background (EMPTY): every voxel is carved, done;
+//   views that see it entirely over foreground (FULL) make a label 0 a 1 (backprojection.c:81) here and now,
+//   and like the views that do not see it at all (OUTSIDE) have nothing more to say;
+//   the UNDECIDED views are the only ones that have to project its voxels: they become work items
+//   (half a unit x up to 16 of those views, see UnitItems) for the final list stage -- or, when that would
+//   be no cheaper than the ordinary survivor lists (few voxels alive, most views undecided), the unit's
+//   voxels are appended to the first list like any other survivor.
+struct UnitJob {
+    const uint32_t *units;    // null: no bulk list.  [kSub][cap] unit ids (brick * 4 + wavefront), counts in ctl->count[3]
+    uint32_t cap;
+    uint4 *items;             // [kSub][icap] work items out, counts in ctl->count[4]
+    uint32_t icap;
+    const ViewDesc *views;    // every view of the batch
+    int32_t nall, ndense;     // ... their number (<= 128), and how many of them the dense stage has applied
+    uint32_t bricks_y, bricks_z;
+    int32_t *labels;
+    uint32_t *list;           // the first survivor list and the room of its sub-lists (counts in ctl->count[0])
+    uint32_t subcap;
+    uint32_t bias;            // items are chosen when their turns * 16 <= bias * the turns the lists would take
+    uint32_t *stats;          // per unit block: {units that got their verdicts, turns those spared the survivor stages}
+};
+
+__device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
+                                              uint32_t sub, uint32_t lane, uint32_t &saved) {
+    const uint32_t lb = unit >> 2, w = unit & 3u;
+    const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / uj.bricks_z, bz = rem - by * uj.bricks_z;
+    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
+    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const uint32_t elem = (il * g.ny + j) * g.nzp + k0;
+    int32_t *p = uj.labels + elem;  // the pitch is a multiple of 64: 16-byte groups
+    int32_t lab[4] = {-1, -1, -1, -1};  // what a lane does not own counts as carved
+    if (inside) {
+        const int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    unsigned long long need[2] = {0ull, 0ull};
+    bool seen = false, empty = false;
+    for (int h = 0; h < 2 && h * 64 < uj.nall; ++h) {
+        const int vi = h * 64 + (int)lane;
+        uint32_t v = 8u;  // no such view, or one the dense stage has applied
+        if (vi < uj.nall && vi >= uj.ndense) {
+            const ViewDesc d = uj.views[vi];  // one descriptor per lane
+            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+        }
+        empty |= __ballot(v == 1u) != 0;
+        seen |= __ballot(v == 2u) != 0;
+        need[h] = __ballot(v == 0u);
+    }
+    unsigned long long b[4];
+    uint32_t nalive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        b[e] = __ballot((alive >> e) & 1u);
+        nalive += (uint32_t)__popcll(b[e]);
+    }
+    // turns of (128 voxels x 2 views) the unit's voxels would take in the survivor lists
+    const uint32_t list_cost = ((nalive + 127u) >> 7) * (((uint32_t)(uj.nall - uj.ndense) + 1u) >> 1);
+    if (empty) {  // some view carves every voxel of the unit
+        if (inside && alive != 0) *reinterpret_cast<int4 *>(p) = make_int4(-1, -1, -1, -1);
+        saved += list_cost;
+        return;
+    }
+    if (seen) {
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) { lab[e] = 1; changed = true; }  // :81 by a view that keeps the whole unit
+        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    }
+    const uint32_t nneed = (uint32_t)__popcll(need[0]) + (uint32_t)__popcll(need[1]);
+    const unsigned long long anyalive = __ballot(alive != 0);
+    if (nneed == 0 || anyalive == 0) {  // wave-uniform: the labels are final
+        saved += list_cost;
+        return;
+    }
+    // the undecided views of each 64-view word in pieces of up to 16; one item per (half with something
+    // alive, word, piece): lane = piece * 4 + word * 2 + half
+    unsigned long long pm[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool bit = (need[h] >> lane) & 1ull;
+        const uint32_t piece = lanes_below(need[h]) >> 4;  // this lane's view is the (16 piece + ..)-th undecided one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pm[h][q] = __ballot(bit && piece == (uint32_t)q);
+    }
+    const uint32_t hq = lane & 1u, wq = (lane >> 1) & 1u, pq = lane >> 2;
+    unsigned long long mymask = 0ull;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (wq == (uint32_t)h && pq == (uint32_t)q) mymask = pm[h][q];
+    const uint32_t halves = ((uint32_t)(anyalive & 0xffffffffull) != 0u ? 1u : 0u) + ((uint32_t)(anyalive >> 32) != 0u ? 1u : 0u);
+    const bool half_alive = ((anyalive >> (32u * hq)) & 0xffffffffull) != 0;
+    const bool mine = lane < 16u && mymask != 0ull && half_alive;
+    const unsigned long long im = __ballot(mine);
+    const uint32_t nitems = (uint32_t)__popcll(im);
+    // turns of (128 voxels x 2 views): the items' against what the unit's voxels would take in the lists
+    const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (item_cost * 16u <= uj.bias * list_cost) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
+        pos = __shfl(pos, 0);
+        if (pos + nitems <= uj.icap) {
+            if (mine)
+                uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
+                    make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
+            saved += list_cost - min(list_cost, item_cost);
+            return;
+        }
+        // (no room: the count stays beyond the capacity, the reader clamps it; the voxels take the list)
+    }
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->count[0][sub].n, nalive);
+    base = __shfl(base, 0);
+    if (base + nalive > uj.subcap) {
+        if (lane == 0) ctl->overflow = 1u;
+        return;
+    }
+    uint32_t *dst = uj.list + (size_t)sub * uj.subcap + base;
+    uint32_t off = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if ((alive >> e) & 1u) dst[off + (uint32_t)__popcll(b[e] & below)] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
+        off += (uint32_t)__popcll(b[e]);
+    }
+}
+
+// FULL candidates (flag 3: every view the flags kernel could see keeps the brick whole, but the masks
+// of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
+// views: same organisation as the flags kernel's own FULL rounds (64 bricks per block, one view per
+// wavefront and round, verdicts joined in LDS).  Kept by all: flag 2, filled like any FULL brick.
+// Otherwise flag 5 and a place on the LATE list: the resume kernel carves such a brick over all the
+// views of the batch, voxel by voxel.  A block without candidates leaves at once.
+// The units of the bulk list get their verdicts, one wavefront per unit (unit_verdicts): a persistent grid of
+// blocks of 8 wavefronts, launched behind the confirm kernel (the masks of every view are packed by then) and
+// ahead of the list stages.  (A kernel of its own: inside the confirm kernel its registers cost that kernel's
+// blocks three wavefronts per SIMD, 40 us on a batch of all-foreground masks.)
+__global__ __launch_bounds__(64 * kFlagWaves) void unit_verdict_kernel(GridDesc g, ListCtl *ctl, UnitJob uj) {
+    const uint32_t nunitblocks = gridDim.x;
+    __shared__ uint32_t upref[kSub + 1];
+    const uint32_t tid = threadIdx.x;
+    {
+        if (tid < kSub) upref[tid + 1] = min(ctl->count[3][tid].n, uj.cap);
+        if (tid == 0) upref[0] = 0;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            uint32_t val = 0, add = 0;
+            if (tid < kSub) {
+                val = upref[tid + 1];
+                add = (tid >= off) ? upref[tid + 1 - off] : 0u;
+            }
+            __syncthreads();
+            if (tid < kSub) upref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
+    const uint32_t total = upref[kSub];
+    const uint32_t uwave = __builtin_amdgcn_readfirstlane(tid >> 6), ulane = tid & 63u;
+    const uint32_t nworkers = nunitblocks * kFlagWaves;
+    uint32_t nunits = 0, saved = 0;
+    for (uint32_t i = blockIdx.x * kFlagWaves + uwave; i < total; i += nworkers) {
+        uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (upref[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t unit = __builtin_amdgcn_readfirstlane(uj.units[(size_t)lo * uj.cap + (i - upref[lo])]);
+        unit_verdicts(uj, g, ctl, unit, lo, ulane, saved);
+        ++nunits;
+    }
+    // what the host's on / off decision reads (see flush): one pair per block, summed by a list kernel (ReportJob)
+    // (atomics on one address from every wavefront of the grid would take longer than the verdicts)
+    __shared__ uint32_t s_stat[2];
+    if (tid < 2) s_stat[tid] = 0u;
+    __syncthreads();
+    if (ulane == 0 && nunits != 0) {
+        atomicAdd(&s_stat[0], nunits);
+        atomicAdd(&s_stat[1], saved);
+    }
+    __syncthreads();
+    if (tid < 2) uj.stats[blockIdx.x * 2u + tid] = s_stat[tid];
+}
+
+__global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
+    GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
+    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
+    if (v0 >= v1 || ctl->cand.n == 0) return;  // no view was packed late, or the flags kernel left no candidate open
+    __shared__ unsigned long long s_full[kFlagWaves], s_seen[kFlagWaves];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    // a persistent grid over the groups of 64 bricks
+    for (uint32_t grp = blockIdx.x; grp * 64u < nbricks; grp += gridDim.x) {
+        const uint32_t lb = grp * 64u + lane;
+        const uint32_t fl = lb < nbricks ? flags[lb] : 0u;
+        const bool isc = fl == 3u || fl == 7u;  // candidates: some view so far saw the brick whole / none sees it
+        unsigned long long any_seen = __ballot(fl == 3u);
+        unsigned long long cand = __ballot(isc);
+        if (cand == 0) continue;  // block-uniform: every wavefront read the same 64 flags
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+        for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
+            const int vi = base + (int)wave;
+            bool keeps = true, sees = false;
+            if (vi < v1 && ((cand >> lane) & 1ull)) {
+                const ViewDesc d = views[vi];
+                const uint32_t v = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), d.tiles_x);
+                keeps = v == 2u || v == 4u;
+                sees = v == 2u;
+            }
+            const unsigned long long mf = __ballot(keeps), ms = __ballot(sees);
+            __syncthreads();  // the previous round's masks have been read by everybody
+            if (lane == 0) { s_full[wave] = mf; s_seen[wave] = ms; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kFlagWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
+        }
+        if (wave != 0) continue;
+        if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
+        const bool failed = isc && !((cand >> lane) & 1ull);
+        const unsigned long long m = __ballot(failed);
+        if (m != 0) {
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&ctl->nlate, (uint32_t)__popcll(m));
+            pos = __shfl(pos, 0);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (failed) late[pos + (uint32_t)__popcll(m & below)] = lb;
+        }
+    }
+}
+
+// The dense kernel proper: a persistent grid walks the live list, one brick per block and turn
+// (wavefront w owns columns 4w..4w+3 of the brick); runs of kXcdRun consecutive entries
+// (neighbouring bricks, which project onto the same mask lines) stay on one XCD.  Blocks behind
+// the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
+// stage fills the others, see carve_list_kernel).
+#ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront did, and when
+__device__ uint32_t g_dense_trace[8192 * 8];
+#endif
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                             const ViewDesc *__restrict__ views,
+                                                             int nviews, int32_t init, Append ap,
+                                                             uint32_t bricks_y, uint32_t bricks_z,
+                                                             const uint8_t *__restrict__ flags,
+                                                             const uint32_t *__restrict__ live,
+                                                             ListCtl *ctl, uint32_t nwalkers,
+                                                             uint32_t nstore, PackJob ride, int pack_rows,
+                                                             uint32_t parity, int nverd_arg, uint32_t verd_max_live) {
+    if (blockIdx.x >= nwalkers + nstore) {
+        // riders: the masks of the views the later stages apply are packed here, beside the walkers
+        // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
+        // panel: persistent riders measured the same or slower.
+        const uint32_t b = blockIdx.x - nwalkers - nstore;
+        if (pack_rows == 0) pack_band_block(ride, b);
+        else if (pack_rows == 1) pack16_block<1>(ride, b);
+        else if (pack_rows == 2) pack16_block<2>(ride, b);
+        else if (pack_rows == 8) pack16_block<8>(ride, b);
+        else pack16_block<4>(ride, b);
+        return;
+    }
+    if (blockIdx.x >= nwalkers) {
+        store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
+                            Fill{init == 0 ? 1 : init, FRESH ? 1 : 0, init});
+        return;
+    }
+    // Walkers are WAVEFRONTS: each takes the next live brick of its XCD's runs (runs of kXcdRun consecutive entries --
+    // neighbouring bricks, which project onto the same mask lines -- stay on one XCD; a ticket counter per XCD), asks
+    // the views packed ahead about the brick's four UNITS (16 columns x 16 voxels) at the cell level, one (unit, view)
+    // pair per lane, carves the units some view finds empty without projecting a voxel -- two thirds of a plant's:
+    // the brick is live because a 32x32 tile under it touches the plant, the unit lies beside it -- and projects the
+    // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
+    // tickets keep every wavefront busy whatever the bricks hold.)
+    const uint32_t nlive = ctl->nlive[parity];
+    // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
+    const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t xcd = blockIdx.x & 7u;
+    // (the first ticket of a wavefront is its own number among the XCD's: a thousand atomics on one address at the
+    // kernel's start would take longer than the first bricks)
+    const uint32_t per_xcd = (nwalkers >> 3) * (kBlock / 64);
+    bool first = true;
+    uint32_t misses = 0, turn = 0;
+#ifdef SC_TRACE_DENSE
+    const uint64_t tr0 = wall_clock64();
+    uint32_t tr_bricks = 0, tr_units = 0, tr_verd = 0, tr_unit = 0, tr_tick = 0;
+#endif
+    for (;;) {
+#ifdef SC_TRACE_DENSE
+        const uint64_t tra = wall_clock64();
+#endif
+        uint32_t t = (blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
+        if (!first) {
+            // eight counters per XCD, each dealing every eighth run of the XCD's entries to the wavefronts whose
+            // number ends in c: returning atomics on one address take 11 ns each, and with one counter per XCD the
+            // 1 500 tickets of a plant's batch were 16 us of them in a row
+            const uint32_t c = t & 7u;
+            uint32_t n = 0;
+            if (lane == 0) n = atomicAdd(&ctl->xcd_next[xcd * 8u + c].n, 1u);
+            n = __builtin_amdgcn_readfirstlane(n);
+            t = per_xcd + ((n / kXcdRun) * 8u + c) * kXcdRun + (n % kXcdRun);
+        }
+        first = false;
+        t = __builtin_amdgcn_readfirstlane(t);
+        const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
+        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
+        if (entry >= nlive) continue;
+        const uint32_t lb = __builtin_amdgcn_readfirstlane(live[entry]);
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        uint32_t culled = 0;
+#ifdef SC_TRACE_DENSE
+        const uint64_t trb = wall_clock64();
+        tr_tick += (uint32_t)(trb - tra);
+        ++tr_bricks;
+#endif
+        // (a wavefront whose last 8 bricks had no unit to cull -- masks without structure -- asks only about every
+        // eighth brick from then on: the verdicts cost a tenth of the projections they cannot spare there)
+        const bool ask = nverd > 0 && (misses < 8u || (turn & 7u) == 0u);
+        ++turn;
+        if (ask) {  // wave-uniform
+            const uint32_t u = lane >> 4, vq = lane & 15u;
+            uint32_t v = 0u;
+            if ((int)vq < nverd) {
+                const ViewDesc d = views[vq];  // one descriptor per lane
+                const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+                v = rect_verdict_cells(d, g, x, (int)(by * kBrickY), (int)(by * kBrickY) + kBrickY - 1,
+                                       (int)(bz * kBrickZ + u * 16u), (int)(bz * kBrickZ + u * 16u) + 15);
+            }
+            const unsigned long long e = __ballot(v == 1u);  // some view carves the whole unit
+            culled = ((e & 0xffffull) ? 1u : 0u) | (((e >> 16) & 0xffffull) ? 2u : 0u) |
+                     (((e >> 32) & 0xffffull) ? 4u : 0u) | ((e >> 48) ? 8u : 0u);
+            misses = culled ? 0u : misses + 1u;
+        }
+#ifdef SC_TRACE_DENSE
+        const uint64_t trc = wall_clock64();
+        tr_verd += (uint32_t)(trc - trb);
+#endif
+        // lane = column * 4 + group of 4 voxels: a square patch of the plane, the UNIT the bulk list speaks of (see Append)
+        const uint32_t j = by * kBrickY + (lane >> 2);
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t k0 = bz * kBrickZ + u * 16u + (lane & 3u) * 4u;
+            if ((culled >> u) & 1u) {
+                if (j < g.ny && k0 < g.nz)
+                    *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
+                continue;
+            }
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+#ifdef SC_TRACE_DENSE
+            ++tr_units;
+#endif
+        }
+#ifdef SC_TRACE_DENSE
+        tr_unit += (uint32_t)(wall_clock64() - trc);
+#endif
+    }
+#ifdef SC_TRACE_DENSE
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+        if (w < 8192u) {
+            uint32_t *o = g_dense_trace + w * 8u;
+            o[0] = (uint32_t)tr0; o[1] = (uint32_t)wall_clock64(); o[2] = tr_bricks; o[3] = tr_units;
+            o[4] = tr_verd; o[5] = tr_unit; o[6] = tr_tick; o[7] = 0;
+        }
+    }
+#endif
+}
+
+// The dense kernel of a launch WITHOUT survivor stages (fewer than 6 views; a single view in the
+// reference's cadence, cl.py:223-226): walkers on the live list as above, and persistent FILLERS on
+// the fill list the flags kernel wrote (settled bricks that are not dead yet) instead of one store
+// block per strip of the grid -- after the first views nearly every brick is dead and a launch costs
+// what its few live and newly settled bricks cost, not a pass over the grid.
+template <bool FRESH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_light_kernel(
+    int32_t *__restrict__ labels, GridDesc g, const ViewDesc *__restrict__ views, int nviews, int32_t init,
+    uint32_t bricks_y, uint32_t bricks_z, const uint32_t *__restrict__ live, const uint32_t *__restrict__ fill_list,
+    const ListCtl *ctl, uint32_t nwalkers, uint32_t parity) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    if (blockIdx.x >= nwalkers) {
+        const uint32_t nfill = ctl->nfill[parity], nfillers = gridDim.x - nwalkers;
+        const bool vec = (g.nzp & 3u) == 0;
+        const int32_t kept = init == 0 ? 1 : init;
+        // 64 entries per load (one per lane), handed out with v_readlane: one round trip per 64 bricks
+        for (uint32_t base = (blockIdx.x - nwalkers) * 64u; base < nfill; base += nfillers * 64u) {
+            const uint32_t mine = (base + lane < nfill) ? fill_list[base + lane] : 0u;
+            const uint32_t n = min(64u, nfill - base);
+            for (uint32_t q = 0; q < n; ++q) {
+                const uint32_t ent = __builtin_amdgcn_readlane(mine, q);
+                const bool isfull = (ent >> 31) != 0, isunt = ((ent >> 30) & 1u) != 0;
+                if (isunt && !FRESH) continue;  // kept and unseen: the labels stay
+                const uint32_t lb = ent & 0x3fffffffu;
+                const uint32_t il = lb / per_plane;
+                const uint32_t rem = lb - il * per_plane;
+                const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+                const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4), k0 = bz * kBrickZ + (lane & 15) * 4;
+                if (j >= g.ny || k0 >= g.nz) continue;
+                int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nzp + k0;
+                const uint32_t nv4 = min(4u, g.nz - k0);
+                if (!isfull || FRESH) {
+                    const int32_t val = isunt ? init : (isfull ? kept : -1);
+                    if (vec) {
+                        typedef int v4i __attribute__((ext_vector_type(4)));
+                        v4i vv = {val, val, val, val};
+                        __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(p));
+                    } else {
+                        for (uint32_t e = 0; e < nv4; ++e) p[e] = val;
+                    }
+                } else {  // kept whole: 0 -> 1, the rest as it is (backprojection.c:81)
+                    for (uint32_t e = 0; e < nv4; ++e)
+                        if (p[e] == 0) p[e] = 1;
+                }
+            }
+        }
+        return;
+    }
+    const uint32_t nlive = ctl->nlive[parity];
+    const Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3, per_xcd = nwalkers >> 3;
+    for (uint32_t t = seq; ; t += per_xcd) {
+        const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
+        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
+        if (entry >= nlive) continue;
+        const uint32_t lb = live[entry];
+        const uint32_t il = lb / per_plane;
+        const uint32_t rem = lb - il * per_plane;
+        const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+        const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
+        brick_voxels<FRESH>(labels, g, views, nviews, init, none, il, j, bz * kBrickZ + (lane & 15) * 4, lb, lane);
+    }
+}
+
+// One view per launch (the reference's schedule, cl.py:223-226): the descriptor travels in
+// the kernel arguments (no copy, no host-side wait), and each lane walks kStreamGroups
+// 16-byte groups with the next group's state load already in flight -- after the first view
+// nearly every wavefront only streams its state through and leaves.
+template <bool FRESH, bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_kernel_1(int32_t *__restrict__ labels, GridDesc g,
+                                                         ViewDesc view, int32_t init) {
+    constexpr int G = (!FRESH && VEC) ? kStreamGroups : 1;
+    uint32_t lb = spread_block(blockIdx.x, gridDim.x);
+    uint64_t grp = (uint64_t)lb * (kBlock * G) + threadIdx.x;
+    Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
+    int4 cur = make_int4(-1, -1, -1, -1);
+    // streaming loads: the state (512 MiB) is far bigger than the Infinity Cache, every view
+    // reads all of it once
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto stream_load = [&](uint64_t gidx) {
+        v4i q = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(labels + gidx * 4));
+        return make_int4(q.x, q.y, q.z, q.w);
+    };
+    if (!FRESH && VEC && grp < g.ngroups) cur = stream_load(grp);  // carve_group takes the stored labels from `cur`
+#pragma unroll 1
+    for (int s = 0; s < G; ++s, grp += kBlock) {
+        int4 nxt = make_int4(-1, -1, -1, -1);
+        if (G > 1 && s + 1 < G && grp + kBlock < g.ngroups)
+            nxt = stream_load(grp + kBlock);
+        if (grp < g.ngroups) carve_group<FRESH, VEC>(labels, g, &view, 1, init, grp, cur, none);
+        cur = nxt;
+    }
+}

@@ -1,0 +1,467 @@
+// Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- the survivor stages (carve_list_kernel) and the resume kernel.
+
+// Work items of the bulk units (see unit_verdicts): (half a unit = 8 columns x 16 voxels, up to 16 of the
+// views that have to project its voxels, as a mask over 64 consecutive views).  The final list stage's
+// wavefronts take them after their own spans; items of one unit may run side by side, which is exact for the
+// same reason as the spans of one chunk: -1 is a plain store, 0 -> 1 a compare-and-swap on 0.
+// What the bulk units' verdicts of this batch were worth, for the host's on / off decision (see flush): the
+// sums over the unit blocks' pairs (UnitJob::stats), written as ONE 8-byte word to page-locked memory by
+// block 0 of the first list kernel behind the verdicts, when it is through with its own work.
+struct ReportJob {
+    unsigned long long *report;  // null: nothing to report.  seq << 48 | min(units, 2^24 - 1) << 24 | min(turns spared / 16, 2^24 - 1)
+    const uint32_t *stats;
+    uint32_t nstats, seq;
+};
+
+struct UnitItems {
+    const uint4 *items;       // null: none.  .x = unit * 2 + half, .y = first view of the mask, .z / .w = the mask
+    uint32_t cap;             // items per sub-list (counts in ctl->count[4])
+    const ViewDesc *views;    // every view of the batch (the items' view numbers index this)
+    uint32_t bricks_y, bricks_z;
+};
+
+// Fused carve, sparse phase: one lane per SURVIVOR.  Reads the survivor sub-lists a previous
+// stage appended and applies views with every lane busy, two views per iteration (two
+// independent projection chains and two gathers in flight per lane).  A persistent grid of
+// wavefronts walks the work items; the counts live in device memory, so the host never waits
+// to learn how many survivors there are.
+//   FINAL == false: an item is a 64-entry chunk and ALL `nviews` views; labels that change
+//     are written (carved -> -1 at once, 0 -> 1 at the end) and what is still alive is appended
+//     to `lout` for the next stage.
+//   FINAL == true : an item is a 64-entry chunk times a GROUP of `vgsize` views, so that there
+//     are many more items than wavefronts (no tail); groups of one chunk may run concurrently
+//     on different wavefronts, which is exact because a carve is a plain store of -1 (final,
+//     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
+// (at most 80 SGPRs: with 82-96 the CU admits 7 such blocks instead of 8, with 98+ only 6 --
+// MI355X_MICROARCH.md, "Residency" -- and the store blocks need the slots the list blocks leave)
+template <bool FINAL, int P>  // P voxels per lane (an item is a chunk of 64 * P entries)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                            const ViewDesc *__restrict__ views,
+                                                            int nviews,
+                                                            const uint32_t *__restrict__ lin,
+                                                            uint32_t *__restrict__ lout,
+                                                            ListCtl *ctl, int sin, int sout,
+                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui,
+                                                            ReportJob rj) {
+    __shared__ uint32_t pref[kSub + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bx = blockIdx.x, gdim = gridDim.x;
+    // A final stage with deferred stores has cs.nstrips STORE blocks behind its persistent list
+    // blocks: this stage is bound by projection arithmetic and the -1 fill of the bricks the flags
+    // kernel found empty by HBM writes, so the two run side by side instead of one after the
+    // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
+    const bool split = cs.flags != nullptr;
+    const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : cs.nstrips - cs.first) : 0u;
+    const uint32_t nbid = gdim - nstore;
+    if (split && bx >= nbid) {
+        // one short block per strip, or (fill_blocks > 0) that many blocks walking the strips: a
+        // wavefront's stores do not hold it up, so few of them keep the write path busy and the
+        // wavefront slots go to the list blocks
+        for (uint32_t strip = cs.first + (bx - nbid); strip < cs.nstrips; strip += nstore)
+            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
+        return;
+    }
+    if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
+    const uint32_t bid = bx;
+    constexpr uint32_t CH = 64u * P;
+    {
+        uint32_t c = (min(ctl->count[sin][tid].n, subcap) + CH - 1u) / CH;  // kSub == kBlock
+        if (tid == 0) pref[0] = 0;
+        pref[tid + 1] = c;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            uint32_t val = pref[tid + 1];
+            uint32_t add = (tid >= off) ? pref[tid + 1 - off] : 0u;
+            __syncthreads();
+            pref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
+    const uint32_t chunks = pref[kSub];
+    const uint32_t lane = tid & 63u;
+    __shared__ uint32_t ipref[FINAL ? kSub + 1 : 1];
+    const bool with_items = FINAL && ui.items != nullptr;  // grid-uniform
+    if (with_items) {
+        const uint32_t c = min(ctl->count[4][tid].n, ui.cap);
+        if (tid == 0) ipref[0] = 0;
+        ipref[tid + 1] = c;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            const uint32_t val = ipref[tid + 1];
+            const uint32_t add = (tid >= off) ? ipref[tid + 1 - off] : 0u;
+            __syncthreads();
+            ipref[tid + 1] = val + add;
+            __syncthreads();
+        }
+    }
+    const uint64_t nworkers = (uint64_t)nbid * (kBlock / 64);
+    // the wavefront index must be a scalar for the compiler, or everything derived from the
+    // item (view range, descriptors) is treated as divergent and fetched with vector loads
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // FINAL: the (chunk, view) pairs, chunk-major, are cut into one SPAN per wavefront -- every
+    // wavefront gets the same number of projections whatever the counts are (with whole
+    // (chunk, view group) items 17 k items over 4096 wavefronts meant 5 items for some and 4 for
+    // others), and a span crosses a chunk boundary once or twice, so the decode of the entries is
+    // paid once or twice per wavefront.  `vgsize` only rounds the span length.
+    // Not FINAL: an item is a chunk and all the views, dealt round-robin.
+    const uint64_t total = FINAL ? (uint64_t)chunks * (uint32_t)nviews : (uint64_t)chunks;
+    uint64_t per = 1;
+    if (FINAL) {
+        per = (total + nworkers - 1) / nworkers;
+        const uint64_t r = (uint64_t)max(vgsize, 1);
+        per = (per + r - 1) / r * r;
+    }
+    const uint64_t wid = (uint64_t)bid * (kBlock / 64) + wave;
+    uint64_t pos = FINAL ? min(total, wid * per) : wid;
+    const uint64_t end = FINAL ? min(total, pos + per) : total;
+    while (pos < end) {
+        uint32_t c;
+        int v0, v1;
+        if (FINAL) {
+            c = (uint32_t)(pos / (uint32_t)nviews);
+            v0 = (int)(pos - (uint64_t)c * (uint32_t)nviews);
+            v1 = (int)min((uint64_t)nviews, (uint64_t)v0 + (end - pos));
+            pos += (uint64_t)(v1 - v0);
+        } else {
+            c = (uint32_t)pos;
+            v0 = 0;
+            v1 = nviews;
+            pos += nworkers;
+        }
+        uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= c (wave-uniform)
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (pref[mid] <= c) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo;
+        const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
+        // P voxels per lane: the descriptor traffic and the scalar bookkeeping of a view are shared,
+        // and a lane has P * U independent projection chains and gathers in flight
+        uint32_t idx[P];
+        bool zero[P], flipped[P], alive[P];
+        float x[P], y[P], z[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t e = (c - pref[s]) * CH + (uint32_t)p * 64u + lane;
+            alive[p] = e < cnt;
+            uint32_t entry = 0;
+            if (alive[p]) entry = lin[(size_t)s * subcap + e];
+            idx[p] = entry & 0x7fffffffu;
+            zero[p] = (entry >> 31) != 0;  // label is still 0
+            flipped[p] = false;
+            const uint32_t col = idx[p] / g.nzp;  // entries index the padded rows
+            const uint32_t k = idx[p] - col * g.nzp;
+            const uint32_t il = col / g.ny;
+            const uint32_t j = col - il * g.ny;
+            x[p] = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+            y[p] = g.oy + (float)(int)j * g.vs;
+            z[p] = g.oz + (float)(int)k * g.vs;
+        }
+        // U views per iteration.  The final stage is bound by arithmetic (U = 2); the stages before
+        // it wait on memory and most of their voxels die within a few views (U = 4).
+        constexpr int U = P >= 4 ? 1 : (FINAL ? 2 : 4);
+        for (int vi = v0; vi < v1; vi += U) {
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) any |= alive[p];
+            if (__ballot(any) == 0) break;
+            bool ok[U][P], fg[U][P];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                // past the end of the range the last view is applied once more: a view applied twice
+                // changes nothing (a carve is final, a kept 0 is already 1), and nothing per lane has
+                // to know whether the slot was real
+                const ViewDesc d = views[vi + q < v1 ? vi + q : vi];
+                // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
+                // tiles_x and the mask pointer one by one where they are first used, three
+                // more scalar-load round trips inside each projection
+                asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    int uu, vv;
+                    // dead lanes project along (their carve below is masked): cheaper than a per-lane test here
+                    ok[q][p] = project(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
+                                       d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv);
+                    uint32_t w = 0;
+                    if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
+                    fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
+                }
+            }
+            // U applications of backprojection.c:79-83; a zero pixel in any of the views wins
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                bool carve = false, keep = false;
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    carve |= ok[q][p] & !fg[q][p];
+                    keep |= ok[q][p] & fg[q][p];
+                }
+                if (carve & alive[p]) {
+                    alive[p] = false;
+                    zero[p] = false;
+                    labels[idx[p]] = -1;
+                } else if (zero[p] & keep) {
+                    zero[p] = false;
+                    if (FINAL) atomicCAS(&labels[idx[p]], 0, 1); else flipped[p] = true;
+                }
+            }
+        }
+        if (!FINAL) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (alive[p] && flipped[p]) labels[idx[p]] = 1;
+                unsigned long long b = __ballot(alive[p]);
+                if (b != 0) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl->count[sout][s].n, (uint32_t)__popcll(b));
+                    base = __shfl(base, 0);
+                    // survivors of sub-list s never outnumber its entries: no overflow here
+                    if (alive[p]) {
+                        unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                        lout[(size_t)s * subcap + base + (uint32_t)__popcll(b & below)] =
+                            idx[p] | (zero[p] ? 0x80000000u : 0u);
+                    }
+                }
+            }
+        }
+    }
+    if (with_items) {
+        // the bulk units' work items, dealt round-robin: two voxels per lane, the views the item names, two
+        // per turn as above
+        const uint32_t itotal = ipref[kSub];
+        const uint32_t per_plane = ui.bricks_y * ui.bricks_z;
+        for (uint32_t i = (uint32_t)wid; i < itotal; i += (uint32_t)nworkers) {
+            uint32_t lo = 0, hi = kSub;  // largest s with ipref[s] <= i (wave-uniform)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ipref[mid] <= i) lo = mid; else hi = mid;
+            }
+            uint4 it = ui.items[(size_t)lo * ui.cap + (i - ipref[lo])];
+            it.x = __builtin_amdgcn_readfirstlane(it.x);
+            it.y = __builtin_amdgcn_readfirstlane(it.y);
+            it.z = __builtin_amdgcn_readfirstlane(it.z);
+            it.w = __builtin_amdgcn_readfirstlane(it.w);
+            const uint32_t unit = it.x >> 1, lb = unit >> 2;
+            const uint32_t il = lb / per_plane, rem = lb - il * per_plane;
+            const uint32_t by = rem / ui.bricks_z, bz = rem - by * ui.bricks_z;
+            // half h of a unit: its columns 8 h .. 8 h + 7; lane = (column & 3) * 16 + voxel, p = column >> 2
+            const uint32_t j0 = by * kBrickY + (it.x & 1u) * 8u + (lane >> 4), k = bz * kBrickZ + (unit & 3u) * 16u + (lane & 15u);
+            const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
+            const float z = g.oz + (float)(int)k * g.vs;
+            uint32_t idx[2];
+            bool alive[2], zero[2];
+            float y[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t j = j0 + 4u * (uint32_t)p;
+                const bool inside = j < g.ny && k < g.nz;
+                idx[p] = (il * g.ny + j) * g.nzp + k;
+                int32_t lab = -1;
+                if (inside) lab = labels[idx[p]];
+                alive[p] = lab != -1;
+                zero[p] = lab == 0;
+                y[p] = g.oy + (float)(int)j * g.vs;
+            }
+            unsigned long long m = ((unsigned long long)it.w << 32) | it.z;
+            const uint32_t vbase = it.y;
+            while (m != 0) {
+                if (__ballot(alive[0] | alive[1]) == 0) break;
+                const uint32_t a = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t b = a;  // a lone view is applied twice: nothing changes the second time
+                if (m != 0) {
+                    b = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                }
+                bool ok[2][2], fg[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const ViewDesc d = ui.views[vbase + (q ? b : a)];
+                    asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        int uu, vv;
+                        ok[q][p] = project(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
+                                           d.R[6] * x + d.R[7] * y[p], z, d, uu, vv);
+                        uint32_t w = 0;
+                        if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
+                        fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const bool carve = (ok[0][p] & !fg[0][p]) | (ok[1][p] & !fg[1][p]);
+                    const bool keep = (ok[0][p] & fg[0][p]) | (ok[1][p] & fg[1][p]);
+                    if (carve & alive[p]) {
+                        alive[p] = false;
+                        zero[p] = false;
+                        labels[idx[p]] = -1;
+                    } else if (zero[p] & keep) {
+                        zero[p] = false;
+                        atomicCAS(&labels[idx[p]], 0, 1);
+                    }
+                }
+            }
+        }
+    }
+    if (rj.report != nullptr && bid == 0) {  // block-uniform
+        __shared__ uint32_t s_sum[2];
+        if (tid < 2) s_sum[tid] = 0u;
+        __syncthreads();
+        uint32_t a = 0, b = 0;
+        for (uint32_t q = tid; q < rj.nstats; q += kBlock) {
+            a += rj.stats[q * 2u];
+            b += rj.stats[q * 2u + 1u];
+        }
+        if (a | b) {
+            atomicAdd(&s_sum[0], a);
+            atomicAdd(&s_sum[1], b);
+        }
+        __syncthreads();
+        if (tid == 0)
+            *rj.report = ((unsigned long long)(rj.seq & 0xffffu) << 48) | ((unsigned long long)min(s_sum[0], 0xffffffu) << 24) |
+                         (unsigned long long)min(s_sum[1] >> 4, 0xffffffu);
+    }
+}
+
+// Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
+// nothing), a persistent grid applies the remaining views densely instead.
+struct LateBricks {           // FULL candidates that turned out not to be (see brick_confirm_kernel)
+    const uint32_t *late;     // null: the batch had no open candidates
+    const ViewDesc *allviews; // every view of the batch
+    const uint8_t *flags;
+    int32_t nall, init, fresh;
+    uint32_t bricks_y, bricks_z;
+};
+
+// A unit of a LATE brick (a FULL candidate some later view did not keep whole after all) through every view of
+// the batch, one wavefront: the views are first asked about the unit as a whole, 64 at a time, one view per
+// lane, at the cell level -- a view that sees it entirely over background carves all of it, views that see it
+// entirely over foreground or not at all have nothing to say about its voxels one by one -- and only the
+// others project them, two per turn.  (A brick inside a solid object lies over foreground in nearly all the
+// views, one at the edge of the pictures outside nearly all.)
+template <bool FRESH>
+__device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const GridDesc &g,
+                                          const ViewDesc *__restrict__ views, int nall, int32_t init, uint32_t unit,
+                                          uint32_t bricks_y, uint32_t bricks_z, uint32_t lane) {
+    const uint32_t lb = unit >> 2, w = unit & 3u;
+    const uint32_t per_plane = bricks_y * bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
+    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
+    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    int32_t *p = labels + ((uint64_t)il * g.ny + j) * g.nzp + k0;  // the pitch is a multiple of 64: 16-byte groups
+    int32_t lab[4] = {-1, -1, -1, -1}, was[4];  // what a lane does not own counts as carved
+    if (FRESH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) lab[e] = init;
+    } else if (inside) {
+        const int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        was[e] = lab[e];
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    }
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    const float y = g.oy + (float)(int)j * g.vs;
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
+    bool seen = false;
+    for (int base = 0; base < nall; base += 64) {
+        if (__ballot(alive != 0) == 0) break;
+        const int vi = base + (int)lane;
+        uint32_t v = 8u;  // no such view
+        if (vi < nall) {
+            const ViewDesc d = views[vi];  // one descriptor per lane
+            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+        }
+        const unsigned long long empty = __ballot(v == 1u), full = __ballot(v == 2u);
+        unsigned long long need = __ballot(v == 0u);
+        if (empty != 0) {  // some view carves every voxel of the unit
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lab[e] = -1;
+            alive = 0;
+            break;
+        }
+        seen |= full != 0;
+        while (need != 0) {
+            if (__ballot(alive != 0) == 0) break;
+            const int a = __builtin_ctzll(need);
+            need &= need - 1;
+            int b = a;
+            const bool two = need != 0;
+            if (two) {
+                b = __builtin_ctzll(need);
+                need &= need - 1;
+            }
+            const ViewDesc da = views[base + a];
+            const ViewDesc db = views[base + b];
+            two_views(da, db, two, x, y, z, lab, alive);
+        }
+    }
+    if (seen) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) lab[e] = 1;  // :81 by a view that kept the whole unit
+    }
+    const bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+    if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                              const ViewDesc *__restrict__ views,
+                                                              int nviews, const ListCtl *ctl,
+                                                              ListCtl *next, LateBricks lb) {
+    // last kernel of a batch: leave the counters of the NEXT batch zeroed (the two blocks
+    // alternate; nobody else touches that one now), so no memset sits on the stream
+    if (next != nullptr) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(next);
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < sizeof(ListCtl) / 4; i += gridDim.x * kBlock) z[i] = 0u;
+    }
+    Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
+    if (lb.late != nullptr) {
+        // bricks some later view does not keep whole after all: every view, one wavefront per unit
+        const uint32_t nlate = ctl->nlate;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const uint32_t nworkers = gridDim.x * (kBlock / 64);
+        for (uint32_t t = blockIdx.x * (kBlock / 64) + wave; t < nlate * 4u; t += nworkers) {
+            const uint32_t unit = lb.late[t >> 2] * 4u + (t & 3u);
+            if (lb.fresh) late_unit<true>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
+            else late_unit<false>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
+        }
+    }
+    if (!ctl->overflow) return;
+    uint64_t nblk = (g.ngroups + kBlock - 1) / kBlock;
+    for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        uint64_t grp = blk * kBlock + threadIdx.x;
+        bool skip = grp >= g.ngroups;
+        if (!skip && lb.late != nullptr) {
+            // bricks every view keeps whole have nothing to gain from this pass, and late bricks are carved
+            // above over ALL views by a block that may not have written them yet: not this pass's voxels
+            Vox4 vx;
+            decode_group(g, grp, vx);
+            const uint32_t col = (uint32_t)(vx.elem / g.nzp), il = col / g.ny, j = col - il * g.ny;
+            const uint32_t fl = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ];
+            skip = fl == 5u || fl == 2u || fl == 6u;
+        }
+        // (a wavefront's lanes leave carve_group's view loop together: skipped lanes still vote)
+        if (grp < g.ngroups && !skip) {
+            int4 pre = make_int4(0, 0, 0, 0);
+            if (VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
+            carve_group<false, VEC>(labels, g, views, nviews, 0, grp, pre, none);
+        }
+    }
+}

@@ -1,0 +1,183 @@
+// Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- 1-byte masks -> bit tiles, tile occupancy and cell maps: the panel and the band form.
+
+// Mask ingest, fast form for 1-byte masks whose rows are 16-byte aligned multiples of 16 px.
+// A block turns 128-pixel x 32-row panels into 32x32 tiles.  Lane l of wavefront w loads 16
+// pixels: row 8w + l/8 of the panel, 16-byte chunk l%8 of that row's 128-byte line -- so every
+// wavefront load instruction reads 8 whole lines, and kPackRows of them are in flight per lane.
+// 16 bytes -> 16 bits in-lane (SWAR non-zero test + one multiply per dword), neighbouring lanes
+// join their halves with one shuffle, and the even lanes store the tile words.
+__device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
+    uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
+    return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
+}
+
+// (Measured: 44-50 us for 72 masks of 1440x1080 whatever ROWS is, and the same for a band form
+// reading whole rows contiguously.  tools/probes/read_probe.hip: a plain read of those 112 MB
+// takes 41 us when they come from HBM -- every step writes 0.5 GB of labels in between, so they
+// do -- and 19 us from the Infinity Cache.  The kernel sits on the cold-read floor.)
+// A batch of 1-byte masks to pack: slots [slot0, slot0 + nslots) of the packed arena, slot s taking
+// the raw view order[s] (the views of a fused carve are packed in the order they will be applied,
+// so that the first few can be packed ahead and the rest beside the dense stage).
+constexpr int kPackOrderMax = 256;
+struct PackJob {
+    const uint8_t *raw;
+    int64_t row_stride, view_stride;
+    int32_t W, H, tiles_x, tiles_y;
+    uint32_t *out;
+    int64_t out_view_words;
+    uint32_t flip;      // 0 plain, 0xffffffff for np.invert on uint8, 0x01010101 for np.invert on bool bytes
+    int32_t use_order;  // 0: slot s takes raw view s
+    uint8_t *occ;
+    uint32_t *cmask;    // per tile: the 4x4 map of its 8x8-pixel cells, [slot][tiles_y][tiles_x] (see ViewDesc)
+    int32_t slot0, nslots;
+    uint16_t order[kPackOrderMax];
+};
+
+template <int ROWS>  // tile rows per block: that many 16-byte loads in flight per lane
+__device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
+    __shared__ uint32_t cm_s[ROWS * 4];  // per tile of the block: cells with some foreground | cells with some background << 16
+    const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
+    const uint32_t flip = pj.flip;
+    const int lane = threadIdx.x & 63;
+    const int txb = (tiles_x + 3) >> 2;            // panels per tile row
+    const int tyb = (tiles_y + ROWS - 1) / ROWS;   // block rows per view
+    int bx = (int)(b % (uint32_t)txb);
+    uint32_t r = b / (uint32_t)txb;
+    int by = (int)(r % (uint32_t)tyb);
+    int slot = (int)(r / (uint32_t)tyb);
+    if (slot >= pj.nslots) return;  // block-uniform
+    slot += pj.slot0;
+    const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
+    const uint8_t *raw = pj.raw + view * pj.view_stride;
+    if (threadIdx.x < ROWS * 4) cm_s[threadIdx.x] = 0;
+    const int wave = (int)(threadIdx.x >> 6);
+    int row = wave * 8 + (lane >> 3);  // row inside the tile
+    int c = lane & 7;                  // 16-pixel chunk inside the panel
+    int u0 = bx * 128 + c * 16;
+    int tx = bx * 4 + (c >> 1);
+    uint4 q[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        int v = (by * ROWS + k) * 32 + row;
+        q[k] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
+        if (v < H && u0 < W)  // W % 16 == 0: a 16-pixel run is inside the row or outside it
+            q[k] = *reinterpret_cast<const uint4 *>(raw + (int64_t)v * pj.row_stride + u0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        int ty = by * ROWS + k;
+        uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
+                        (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
+        uint32_t other = __shfl_xor(half, 1);
+        uint32_t word = half | (other << 16);
+        if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
+            pj.out[(int64_t)slot * pj.out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
+        // 8x8-pixel cells: this wavefront holds rows 8w .. 8w + 7 of the tile (cell row w), lane 8r + c the
+        // pixels 16c .. 16c + 15 of row r -- two cells' worth.  Four ballots; bit c + 8r of each belongs to
+        // lane 8r + c, so lane c < 8 reads off its two cells over the eight rows.
+        const unsigned long long any_a = __ballot((half & 0xffu) != 0u), any_b = __ballot((half >> 8) != 0u);
+        const unsigned long long all_a = __ballot((half & 0xffu) == 0xffu), all_b = __ballot((half >> 8) == 0xffu);
+        if (lane < 8) {
+            constexpr unsigned long long M = 0x0101010101010101ull;
+            const uint32_t fa = ((any_a >> c) & M) != 0 ? 1u : 0u, fb = ((any_b >> c) & M) != 0 ? 1u : 0u;
+            const uint32_t ha = ((all_a >> c) & M) != M ? 1u : 0u, hb = ((all_b >> c) & M) != M ? 1u : 0u;  // padding: background
+            const int bit = wave * 4 + (c & 1) * 2;  // cell (2 (c & 1), w) of tile c >> 1
+            atomicOr(&cm_s[k * 4 + (c >> 1)], ((fa | (fb << 1)) << bit) | ((ha | (hb << 1)) << (16 + bit)));
+        }
+    }
+    __syncthreads();
+    // tile occupancy: bit 0 = some foreground, bit 1 = nothing but foreground; every byte is
+    // written here, nothing for the host to clear
+    if (threadIdx.x < ROWS * 4) {
+        int ty = by * ROWS + (int)(threadIdx.x >> 2), txo = bx * 4 + (int)(threadIdx.x & 3);
+        if (ty < tiles_y && txo < tiles_x) {
+            const uint32_t cm = cm_s[threadIdx.x];
+            const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + txo;
+            pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+            if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+        }
+    }
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(kBlock) void pack16_kernel(PackJob pj) {
+    pack16_block<ROWS>(pj, blockIdx.x);
+}
+
+// The same ingest in BAND form (SC_OPT_PACK_ROWS 0, the default for pictures up to kBandTiles tiles wide): a
+// block takes one tile row of a view -- 32 picture rows, W bytes each, one contiguous run of memory when the rows
+// are not padded -- as a list of 16-pixel tasks in row-major order, 256 at a time, so that a wavefront load reads
+// 1 KB in one piece, and writes the band's tiles (contiguous in the packed arena) from LDS in 16-byte pieces.
+// Measured on one MI355X, 72 masks resident in the Infinity Cache (tools/probes/pack_shape.py): the panel form
+// takes 36 us on 1440 x 1080 pictures (a block's 16 KB lie in 128 pieces 1440 B apart, and 12 % of the panel
+// blocks hang over the picture's edges) and 24 us on the same bytes as 128 x 12150 pictures, where a block's
+// bytes are one run.  Tasks per row are rounded up to an even number: the two halves of a tile row word sit in
+// neighbouring lanes.
+constexpr int kBandTiles = 64;   // widest picture of the band form: 2048 pixels
+constexpr int kBandPhase = 6;    // 16-byte loads in flight per lane (3, 4, 6, 12: the same within a microsecond)
+
+__device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
+    __shared__ alignas(16) uint32_t band_s[kBandTiles * 32];  // the band's tile words, as they lie in the packed arena
+    __shared__ uint32_t cmb_s[kBandTiles];        // per tile: cells with some foreground | with some background << 16
+    const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
+    const uint32_t flip = pj.flip;
+    const uint32_t tid = threadIdx.x;
+    const int ty = (int)(b % (uint32_t)tiles_y);
+    int slot = (int)(b / (uint32_t)tiles_y);
+    if (slot >= pj.nslots) return;  // block-uniform
+    slot += pj.slot0;
+    const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
+    const uint8_t *raw = pj.raw + view * pj.view_stride + (int64_t)ty * 32 * pj.row_stride;
+    const int cpr = W >> 4;                    // 16-pixel chunks per row (W % 16 == 0)
+    const uint32_t cprp = 2u * (uint32_t)tiles_x;  // ... rounded up to an even number
+    const uint32_t ntasks = 32u * cprp;
+    const int rows_here = min(32, H - ty * 32);
+    if (tid < (uint32_t)tiles_x) cmb_s[tid] = 0u;
+    // task q = tid + 256 i: row q / cprp, chunk q % cprp, stepped without a division
+    uint32_t row = tid / cprp, c = tid - row * cprp;
+    const uint32_t drow = (uint32_t)kBlock / cprp, dc = (uint32_t)kBlock - drow * cprp;
+    bool synced = false;
+    for (uint32_t base = 0; base < ntasks; base += (uint32_t)kBlock * kBandPhase) {
+        uint4 q[kBandPhase];
+        uint32_t rr[kBandPhase], cc[kBandPhase];
+#pragma unroll
+        for (int i = 0; i < kBandPhase; ++i) {
+            rr[i] = row; cc[i] = c;
+            q[i] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
+            if ((int)row < rows_here && (int)c < cpr)
+                q[i] = *reinterpret_cast<const uint4 *>(raw + (int64_t)row * pj.row_stride + (int64_t)c * 16);
+            row += drow; c += dc;
+            if (c >= cprp) { c -= cprp; ++row; }
+        }
+        if (!synced) { __syncthreads(); synced = true; }  // cmb_s is zero for everybody (block-uniform branch)
+#pragma unroll
+        for (int i = 0; i < kBandPhase; ++i) {
+            const uint32_t half = nonzero_nibble(q[i].x ^ flip) | (nonzero_nibble(q[i].y ^ flip) << 4) |
+                                  (nonzero_nibble(q[i].z ^ flip) << 8) | (nonzero_nibble(q[i].w ^ flip) << 12);
+            const uint32_t other = __shfl_xor(half, 1);  // the task next door: same row, the tile's other half
+            if (rr[i] < 32u) {                           // (tasks past the band's end belong to nobody)
+                if ((cc[i] & 1u) == 0u) band_s[(cc[i] >> 1) * 32u + rr[i]] = half | (other << 16);
+                // the task's 16 pixels are two 8-pixel cells of cell row rr >> 3
+                const uint32_t fa = (half & 0xffu) != 0u, fb = (half >> 8) != 0u;
+                const uint32_t ha = (half & 0xffu) != 0xffu, hb = (half >> 8) != 0xffu;  // padding: background
+                const uint32_t bit = (rr[i] >> 3) * 4u + (cc[i] & 1u) * 2u;
+                atomicOr(&cmb_s[cc[i] >> 1], ((fa | (fb << 1)) << bit) | ((ha | (hb << 1)) << (16u + bit)));
+            }
+        }
+    }
+    __syncthreads();
+    // the band's tiles: tiles_x * 32 words in a row in the packed arena
+    uint4 *dst = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * tiles_x * 32);
+    const uint4 *src = reinterpret_cast<const uint4 *>(band_s);
+    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) dst[i] = src[i];
+    if (tid < (uint32_t)tiles_x) {
+        const uint32_t cm = cmb_s[tid];
+        const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + tid;
+        pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+        if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pack_band_kernel(PackJob pj) { pack_band_block(pj, blockIdx.x); }

@@ -1,0 +1,139 @@
+// Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- block placement, the exact shared-reciprocal division, project() (backprojection.c:3-34), mask words, unravel_index (common.h:1-12).
+
+// XCD-aware block remap.  Blocks b and b+8 share an XCD (round-robin dispatch); runs of
+// kXcdRun consecutive logical blocks (neighbouring columns, which project onto the same mask
+// lines) stay on one XCD's L2.  Which XCD takes which run of a group of 8 rotates from group
+// to group: a grid plane is a whole number of runs, so a fixed deal would hand the busy stripe
+// of every plane (the columns under the object) to the same few XCDs -- measured 12 % slower
+// on the fused carve and 10 % on the streaming kernel.  Speed only: any placement gives the
+// same result.
+__device__ __forceinline__ uint32_t spread_block(uint32_t bid, uint32_t nblocks) {
+    uint32_t full = nblocks - nblocks % (8u * kXcdRun);
+    if (bid >= full) return bid;
+    uint32_t xcd = bid & 7u, seq = bid >> 3;
+    uint32_t grp = seq / kXcdRun;
+    xcd = (xcd + grp * 3u + (grp >> 3) * 5u) & 7u;  // rotate: no XCD owns a fixed stripe of y
+    return (grp * 8u + xcd) * kXcdRun + (seq % kXcdRun);
+}
+
+// Correctly rounded p/pz for BOTH image coordinates from ONE reciprocal.
+// hipcc expands an IEEE f32 division into  div_scale x2, rcp, 2 fma (Newton step on the
+// reciprocal), mul, 4 fma (two corrections of the quotient), div_fmas, div_fixup.  When the
+// operands are in a range where v_div_scale scales nothing and v_div_fixup fixes nothing
+// (denominator and both numerators normal, within 2^+-40: see the V_DIV_SCALE_F32 rules), that
+// expansion is exactly the plain-FMA sequence below, so running it by hand with the refined
+// reciprocal SHARED between the two numerators gives bit-identical quotients with 13
+// instructions instead of 22 (and one quarter-rate v_rcp_f32 instead of two).  Any lane outside
+// the range sends its whole wavefront through the compiler's division.
+// sc_selftest_division() compares the two bit-for-bit on 2^32 operand pairs.
+__device__ __forceinline__ bool div_fast_range(float px, float py, float pz) {
+    // fmin/fmax drop a NaN operand, so NaNs are excluded by explicit (ordered) comparisons
+    bool ordered = !__builtin_isunordered(px, py);
+    float lo = fminf(fabsf(px), fabsf(py));
+    float hi = fmaxf(fmaxf(fabsf(px), fabsf(py)), pz);
+    return ordered & (pz > 0x1p-40f) & (lo > 0x1p-40f) & (hi < 0x1p40f);  // also false for
+                                                            // zero numerators, pz <= 0, inf
+}
+__device__ __forceinline__ float refined_rcp(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
+// backproject_point (backprojection.c:3-34) with the x/y partial sums hoisted.
+// a{x,y,z} = R[0]*x + R[1]*y etc. (rounded as the reference rounds them).
+//
+// What the instructions cost on gfx950 (tools/probes/valu_probe.hip, cycles of a SIMD per wavefront
+// instruction, independent instructions, 8 wavefronts per SIMD): v_mul_f32 / v_add_f32 / v_sub_f32 /
+// v_and / v_lshrrev / v_add_u32 / v_mov 2.6; every three-operand or VOP3-only form (v_fma_f32, v_cmp_*,
+// v_cvt_*, v_min/max, v_bfi, v_mad_*) 4.3-4.7; v_rcp_f32 8.3.  Where the host has certified the pose
+// (d.safe: every voxel of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30, intrinsics finite and below
+// 2^30) the range test of the fast division is the two comparisons left of it and the picture test is
+// two unsigned comparisons of the truncated coordinates -- uf, vf are finite there, v_cvt_i32_f32
+// truncates toward zero ((-1, 0) -> 0, accepted like the reference's cast) and saturates, so
+// (unsigned)u < W is exactly  uf > -1 && uf < W.
+__device__ __forceinline__ bool project(float ax, float ay, float az, float z,
+                                        const ViewDesc &d, int &u, int &v) {
+    float pz = (az + d.R[8] * z) + d.t[2];  // :11
+    float px = (ax + d.R[2] * z) + d.t[0];  // :17
+    float py = (ay + d.R[5] * z) + d.t[1];  // :18
+    const bool safe = d.safe != 0;          // wave-uniform
+    unsigned long long outside;             // lanes whose operands the fast division does not cover
+    if (safe) {
+        outside = __builtin_amdgcn_ballot_w64(!(fabsf(px) > 0x1p-40f)) | __builtin_amdgcn_ballot_w64(!(fabsf(py) > 0x1p-40f));
+        asm volatile("" : "+s"(outside));  // keeps the two ballots apart: merged, the lane predicate
+    } else {                               // travels through a vector register and back (two more instructions)
+        outside = __builtin_amdgcn_ballot_w64(!div_fast_range(px, py, pz));
+        asm volatile("" : "+s"(outside));
+    }
+    if (outside == 0) {
+        const float r = refined_rcp(pz);
+        // (the packed forms v_pk_mul/fma_f32 were tried for the two chains: no faster in these kernels)
+        const float uf = div_by_rcp(px, pz, r) * d.K[0] + d.K[2];  // :20
+        const float vf = div_by_rcp(py, pz, r) * d.K[1] + d.K[3];  // :21
+        u = (int)uf;
+        v = (int)vf;
+        if (safe) return ((uint32_t)u < (uint32_t)d.W) & ((uint32_t)v < (uint32_t)d.H);
+        return (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);  // pz > 0 here
+    }
+    const float qx = px / pz, qy = py / pz;
+    float uf = qx * d.K[0] + d.K[2];  // :20
+    float vf = qy * d.K[1] + d.K[3];  // :21
+    // :13 rejects pz < 0 (not NaN, not -0); :23-31 reject (int)uf outside [0, W-1].
+    // Truncation toward zero accepts uf in (-1, 0); NaN/inf/huge fail the comparisons,
+    // which is what the cvttss2si INT_MIN result does in the canonical restatement.
+    // (bitwise &: one straight-line predicate, no short-circuit branches)
+    bool ok = !(pz < 0.0f) & (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);
+    u = (int)uf;
+    v = (int)vf;
+    return ok;
+}
+
+__device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
+    // all factors are < 2^24 for in-image pixels: the 24-bit multiply is full rate
+    return (__umul24((uint32_t)(v >> 5), (uint32_t)tiles_x) + (uint32_t)(u >> 5)) * 32u +
+           (uint32_t)(v & 31);
+}
+
+// The mask pointer comes out of a descriptor, so the compiler cannot tell its address space and
+// would emit flat loads; it is always global memory.
+typedef const __attribute__((address_space(1))) uint32_t *gmask_t;
+__device__ __forceinline__ uint32_t load_mask_word(const void *mask, uint32_t word) {
+    return ((gmask_t)(uintptr_t)mask)[word];
+}
+
+struct Vox4 {
+    uint64_t elem;   // offset of the group's first voxel in the slab state
+    uint32_t k0;     // z index of that voxel
+    uint32_t nvalid; // 0..4 voxels of this group that exist (nz tail, row padding)
+    float x, y;
+};
+
+// group index -> column and z run (common.h:6-8: z fastest), voxel centre x, y
+__device__ __forceinline__ void decode_group(const GridDesc &g, uint64_t grp, Vox4 &vx) {
+    uint32_t col, kq;
+    if (g.ngroups <= 0xffffffffull) {
+        uint32_t g32 = (uint32_t)grp;
+        col = g32 / g.gpc;
+        kq = g32 - col * g.gpc;
+    } else {
+        col = (uint32_t)(grp / g.gpc);
+        kq = (uint32_t)(grp - (uint64_t)col * g.gpc);
+    }
+    uint32_t il = col / g.ny;
+    uint32_t j = col - il * g.ny;
+    vx.k0 = kq * 4u;
+    vx.nvalid = vx.k0 < g.nz ? min(4u, g.nz - vx.k0) : 0u;
+    vx.elem = (uint64_t)col * g.nzp + vx.k0;  // == grp * 4: rows are whole groups
+    // backprojection.c:71-72 -- origin + (float)index * voxel_size, GLOBAL x index of the plane
+    vx.x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+    vx.y = g.oy + (float)(int)j * g.vs;
+}

@@ -1,0 +1,76 @@
+// Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- the layouts both sides share: view and grid descriptors, the control block of the survivor lists.
+
+
+struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave-uniform)
+    float K[4];     // fx fy cx cy
+    float R[9];     // row-major
+    float t[3];
+    const void *mask;  // carve: tiled bit words; average: float32 [H][W]
+    int32_t W, H;
+    int32_t tiles_x;
+    int32_t pad;
+    float Wf, Hf;
+    const uint8_t *occ;  // carve: one byte per 32x32 tile: bit 0 some foreground, bit 1 only foreground
+    int32_t safe;        // certify_view(): every voxel centre of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30
+                         // under this pose, and the intrinsics are finite and below 2^30 (see project())
+    int32_t pad2;
+    const uint32_t *cmask;  // carve, 16-byte pack form: per 32x32 tile the 4x4 map of its 8x8-pixel CELLS -- bits 0..15
+                            // "cell holds some foreground", bits 16..31 "cell holds some background" (cell (cx, cy) of
+                            // the tile at bit cy * 4 + cx; padding counts as background); null: no cell level
+    uint64_t reserved;
+};
+static_assert(sizeof(ViewDesc) == 128, "ViewDesc layout");
+
+struct GridDesc {
+    float ox, oy, oz, vs;
+    uint32_t ny, nz;
+    uint32_t i0;        // global x index of the engine's first plane
+    uint32_t gpc;       // 4-voxel groups per row = nzp / 4 (the last ones of a padded row own fewer than 4 voxels, or none)
+    uint64_t ngroups;   // columns owned * gpc
+    uint32_t istride;   // global x step between the engine's planes (1: slab, W: plane-cyclic)
+    uint32_t nzp;       // row pitch of the state in voxels: nz rounded up to a multiple of 64 (a row = one
+                        // (plane, column) run of nz voxels, 256-byte aligned; the padding is never read back)
+};
+
+constexpr int kBlock = 256;
+constexpr int kTile = 32;        // mask tile edge in pixels (32 rows x 32 bits = 128 B)
+constexpr int kSub = 256;        // sharded append counters = sub-lists of a survivor list
+constexpr int kStreamGroups = 2; // 16-byte groups per lane in the per-view streaming kernel
+                                 // (measured with streaming loads: 2 -> 0.0803, 3 -> 0.0811, 4 -> 0.0860 ms)
+constexpr int kXcdRun = 16;      // consecutive logical blocks kept on one XCD
+
+// Survivor lists of the fused carve (see carve_list_kernel).  Zeroed before every fused launch.
+// Every counter sits on a 128-byte line of its own: returning device-scope atomics on one
+// line serialise (~90 per microsecond measured), on different lines they do not.
+struct alignas(128) ListCounter {
+    uint32_t n;
+    uint32_t pad[31];
+};
+struct ListCtl {
+    ListCounter count[5][kSub];  // entries appended per sub-list, one set per list stage; set 3: bulk units, set 4:
+                                 // their work items
+    uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
+    uint32_t nlive[2];           // brick form: bricks no view found empty (entries of the live list); the flags
+                                 // kernel of launch q counts in word q & 1 and zeroes the other one, so launches
+                                 // that keep the same block (fewer than 6 views: no survivor stages) need no memset
+    uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
+    uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
+    uint32_t pad[26];
+    ListCounter xcd_next[64];    // dense stage: ticket counters for the live list, 8 per XCD (index xcd * 8 + c: the
+                                 // wavefronts of XCD k whose number ends in c share one; see carve_brick_kernel)
+    ListCounter cand;            // .n non-zero: the flags kernel left FULL candidates open (the confirm kernel has work).
+                                 // A flag on a line of its own, read before it is written: as a count (an atomic per
+                                 // block, 11 ns each on one address) it cost 22 us when every brick is a candidate,
+                                 // and as a plain store on the line of the live-brick counter it doubled that
+                                 // kernel's time on a bulky object (the atomics on `nlive` waited behind the stores)
+};
+
+// Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).
+struct CullStores {
+    const uint8_t *flags;  // null: nothing deferred
+    uint32_t bricks_y, bricks_z, nstrips, first;  // strips [first, nstrips) are filled there
+    int32_t kept, fresh;   // see Fill
+    uint32_t fill_blocks;  // 0: one store block per strip; n: n persistent store blocks
+    int32_t init;          // see Fill
+};

@@ -1,4 +1,4 @@
-"""CPU check of the bound behind the fused carve's brick verdicts (csrc/spacecarve.hip,
+"""CPU check of the bound behind the fused carve's brick verdicts (csrc/sc_verdicts.h,
 ``brick_verdict``): the image of a brick's four corners, widened by the slack the kernel computes,
 must contain the float32 pixel coordinates the reference arithmetic (backprojection.c:3-34) gives
 EVERY voxel of the brick, and a brick judged in front of the camera must have every voxel in front.
