@@ -641,7 +641,7 @@ def main():
             model = ("fused batch: 4 B/voxel label write (never read) + V*W*H uint8 mask bytes read once; "
                      "the 1-bit tiles and survivor lists are implementation traffic, not counted")
             units = n_local * V
-            kernel = "fused batch (pack16_kernel + brick_flags_kernel + carve_brick_kernel + carve_list_kernel x2)"
+            kernel = "fused batch (pack_band_kernel + brick_flags_kernel + carve_brick_kernel + brick_confirm_kernel + carve_list_kernel x2 + carve_resume_kernel)"
         else:
             avg_ms = st["carve"]["avg_ms"]
             launches = st["carve"]["launches"]

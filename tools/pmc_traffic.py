@@ -40,7 +40,7 @@ def short(name):
                 "carve_brick_kernel<true", "carve_brick_kernel<false", "carve_brick_light_kernel<true",
                 "carve_brick_light_kernel<false", "brick_flags_kernel", "brick_confirm_kernel",
                 "carve_list_kernel<true", "carve_list_kernel<false", "carve_resume_kernel<true",
-                "carve_resume_kernel<false", "average_kernel", "pack16_kernel", "pack_kernel", "fill_kernel"):
+                "carve_resume_kernel<false", "average_kernel", "pack16_kernel", "pack_band_kernel", "pack_kernel", "fill_kernel"):
         if key in name:
             return key + (">" if "<" in key else "")
     return name[:40]
@@ -65,7 +65,7 @@ def main():
         s = short(name)
         f = fetch.get(name, {}).get("mean")
         w = write.get(name, {}).get("mean")
-        wide = s.startswith("carve_kernel_1<false") or s.startswith("carve_kernel<false") or s.startswith("pack16_kernel")
+        wide = s.startswith("carve_kernel_1<false") or s.startswith("carve_kernel<false") or s.startswith("pack16_kernel") or s.startswith("pack_band_kernel")
         ent = {"kernel": name, "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w,
                "launches_fetch_pass": fetch.get(name, {}).get("n"),
                "read_correction": 2.0 if wide else 1.0,
@@ -83,7 +83,7 @@ def main():
         if s.startswith("carve_kernel_1<false") and "hbm_bytes_per_launch" in ent:
             traffic[key] = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": f"profiles/{a.tag}_pmc.json",
                             "kernel": ent["kernel"], "read_correction": ent["read_correction"]}
-    seq = ("pack16_kernel", "brick_flags_kernel", "carve_brick_kernel<true>", "brick_confirm_kernel", "carve_kernel<true>",
+    seq = ("pack16_kernel", "pack_band_kernel", "brick_flags_kernel", "carve_brick_kernel<true>", "brick_confirm_kernel", "carve_kernel<true>",
            "carve_list_kernel<false>", "carve_list_kernel<true>", "carve_resume_kernel<true>")
     parts = {s: per_kernel[s]["hbm_bytes_per_launch"] for s in seq
              if s in per_kernel and "hbm_bytes_per_launch" in per_kernel[s]}
@@ -91,7 +91,7 @@ def main():
         traffic[f"fused_{a.scene}_{a.n}_{a.views}"] = {
             "hbm_bytes_per_launch": sum(parts.values()), "source": f"profiles/{a.tag}_pmc.json",
             "kernel": "fused batch = one launch each of: " + ", ".join(parts), "per_kernel": parts,
-            "read_correction": "pack16_kernel x2 (16 B/lane streaming reads); the others raw -- carve_brick_kernel also "
+            "read_correction": "the pack kernel x2 (16 B/lane streaming reads); the others raw -- carve_brick_kernel also "
                                "carries the packing riders' wide reads of the remaining masks, which FETCH_SIZE "
                                "reports at half their bytes: the sum understates the batch by up to 50 MB"}
     json.dump(traffic, open(traffic_path, "w"), indent=1, sort_keys=True)
