@@ -23,7 +23,7 @@
 #define SC_OPT_PACK_ROWS 13       /* the mask bit packer: 0 (default) the band form -- a block takes one tile row of a
                                      view, whole picture rows read in a piece (pictures up to 2048 pixels wide, wider
                                      ones take the panel form) --; 1, 2, 4, 8: the panel form, 128-pixel panels of that
-                                     many tile rows per block                                                      */
+                                     many tile rows per block; 3: bands for every picture up to 2048 pixels wide     */
 #define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1280): the -1 fill of bricks found empty is done by
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */

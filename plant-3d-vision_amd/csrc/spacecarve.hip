@@ -493,7 +493,8 @@ int pack_form(const sc_engine *e, const PackJob &pj) {
     // (narrow pictures make bands of a few hundred tasks, less than a block's worth: 128-pixel pictures took 61 us
     // in bands against 24 in panels)
     if (e->pack_rows == 0 && pj.tiles_x >= 16 && pj.tiles_x <= kBandTiles) return 0;
-    return e->pack_rows == 0 ? 4 : (int)e->pack_rows;
+    if (e->pack_rows == 3 && pj.tiles_x <= kBandTiles) return 0;  // bands whatever the width (tests)
+    return (e->pack_rows == 0 || e->pack_rows == 3) ? 4 : (int)e->pack_rows;
 }
 
 int64_t pack16_blocks(const sc_engine *e, const PackJob &pj) {
@@ -1537,8 +1538,8 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             e->defer_stores = value;
             return SC_OK;
         case SC_OPT_PACK_ROWS:
-            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-                return fail(SC_ERR_INVALID, "pack_rows must be 0, 1, 2, 4 or 8");
+            if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 8)
+                return fail(SC_ERR_INVALID, "pack_rows must be 0, 1, 2, 3, 4 or 8");
             e->pack_rows = value;
             return SC_OK;
         case SC_OPT_VIEW_BRICK:

@@ -175,6 +175,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0},
     {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8},
     {"SC_OPT_PACK_ROWS": 4},                                              # the panel form of the pack kernel
+    {"SC_OPT_PACK_ROWS": 3, "SC_OPT_PACK_RIDE": 0},                       # bands, every mask packed ahead
     {"SC_OPT_PACK_ROWS": 8, "SC_OPT_PACK_RIDE": 0},
     {"SC_OPT_UNIT_CULL": 0},                                              # no unit verdicts in the dense stage
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1},                        # ... asked whatever the tiles settled
@@ -1183,6 +1184,41 @@ def test_int8_read_back_of_carve_labels(gpu_device):
     bp.clear()
     assert (bp.get_values() == 0).all() and np.array_equal(got, want)  # the array handed out kept its contents
     bp.close()
+
+
+@pytest.mark.parametrize("width,height", [(496, 37), (1008, 75), (2032, 64), (2048, 33), (528, 300), (16, 40), (48, 97)])
+@pytest.mark.parametrize("invert", [False, True])
+def test_masks_packed_in_bands(gpu_device, width, height, invert):
+    """The band form of the pack kernel (a block per tile row of a view, 16-pixel tasks in row-major order): widths
+    with an odd number of 16-pixel chunks per row (the last tile half empty), heights that are not multiples of 32,
+    the narrowest and the widest pictures it takes, plain and inverted masks, packed ahead and by the riders of
+    the dense stage; bands forced for the narrow ones (SC_OPT_PACK_ROWS 3).  Labels against the oracle: a wrong
+    bit, tile byte or cell map shows as a wrong voxel."""
+    shape = (6, 40, 130)
+    _, origin, vs, views = scene(shape, 12, "plant", width=width, height=height, fx=0.9 * width, fy=0.9 * width,
+                                 cx=0.5 * width, cy=0.5 * height)
+    rng = np.random.default_rng(width * 7 + height)
+    views = [(K, R, t, np.where(rng.random(m.shape) < 0.02, 255 - m, m).astype(np.uint8)) for K, R, t, m in views]
+    want = oracle_c.carve(list(shape), origin, vs, [(K, R, t, (255 - m) if invert else m) for K, R, t, m in views], nthreads=4)
+    for ride in (1, 0):
+        e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+        for k, v in ((nat.SC_OPT_PACK_ROWS, 3), (nat.SC_OPT_PACK_RIDE, ride), (nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
+                     (nat.SC_OPT_BULK_ADAPT, 0)):
+            e.set_option(k, v)
+        stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+        ptr = e.dev_alloc(stack.nbytes)
+        e.dev_upload(ptr, stack)
+        K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+        e.process_views_device(K, R, t, ptr, len(views), height, width, nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8)
+        got = e.get_values()
+        assert np.array_equal(got, want), (width, height, invert, ride, histogram3(got), histogram3(want))
+        # host masks: packed one by one as they arrive
+        e.clear()
+        for Kq, Rq, tq, m in views:
+            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8_INV if invert else nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (width, height, invert, "host masks")
+        e.dev_free(ptr)
+        e.close()
 
 
 def test_read_back_over_the_two_bit_wire(gpu_device):

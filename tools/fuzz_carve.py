@@ -17,7 +17,7 @@ KNOBS = {
     "SC_OPT_STAGE2_VIEWS": [0, 2], "SC_OPT_VIEW_GROUP": [1, 5, 16], "SC_OPT_LIST_BLOCKS": [8, 64, 2048],
     "SC_OPT_DEFER_STORES": [0, 8, 1024], "SC_OPT_DEFER_SHARE": [0, 5, 16], "SC_OPT_FULL_BRICKS": [0, 1],
     "SC_OPT_BRICK": [0, 1, 1, 1], "SC_OPT_COMPACT": [0, 1, 1, 1], "SC_OPT_VIEW_ORDER": [0, 1],
-    "SC_OPT_PACK_ROWS": [0, 0, 1, 2, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5],
+    "SC_OPT_PACK_ROWS": [0, 1, 2, 3, 3, 3, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5],
     "SC_OPT_PACK_RIDE": [0, 1], "SC_OPT_BRICK_WALKERS": [8, 1024], "SC_OPT_FILL_BLOCKS": [0, 1, 512],
     "SC_OPT_FINAL_VOXELS": [1, 2, 4], "SC_OPT_STAGE1_VOXELS": [1, 2, 4], "SC_OPT_VIEW_BRICK": [0, 1], "SC_OPT_STAGE1_STORE_SHARE": [0, 4, 16], "SC_OPT_STAGE1_LIST_BLOCKS": [8, 1280],
     "SC_OPT_BULK_MIN": [0, 1, 64, 128, 256], "SC_OPT_BULK_ADAPT": [0, 1], "SC_OPT_ITEM_BIAS": [0, 8, 12, 64],

@@ -13,14 +13,17 @@ from plant3dvision_amd import _native as nat, scenes  # noqa: E402
 
 SWEEP = [
     (),
-    (("SC_OPT_STAGE1_VIEWS", 12),), (("SC_OPT_STAGE1_VIEWS", 14),), (("SC_OPT_STAGE1_VIEWS", 16),), (("SC_OPT_STAGE1_VIEWS", 20),),
-    (("SC_OPT_DEFER_STORES", 1280),), (("SC_OPT_DEFER_STORES", 1536),), (("SC_OPT_DEFER_STORES", 2048),),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1280)), (("SC_OPT_STAGE1_VIEWS", 14), ("SC_OPT_DEFER_STORES", 1280)),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1536)), (("SC_OPT_STAGE1_VIEWS", 16), ("SC_OPT_DEFER_STORES", 1536)),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1280), ("SC_OPT_FILL_BLOCKS", 384)),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1280), ("SC_OPT_STAGE1_LIST_BLOCKS", 1024)),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1280), ("SC_OPT_STAGE1_STORE_SHARE", 3)),
-    (("SC_OPT_STAGE1_VIEWS", 12), ("SC_OPT_DEFER_STORES", 1280), ("SC_OPT_FLAG_VIEWS", 10)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 0), ("SC_OPT_STAGE1_LIST_BLOCKS", 2048)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 0), ("SC_OPT_STAGE1_LIST_BLOCKS", 1792)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 0), ("SC_OPT_STAGE1_LIST_BLOCKS", 1536)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 0), ("SC_OPT_STAGE1_LIST_BLOCKS", 1280)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 2), ("SC_OPT_STAGE1_LIST_BLOCKS", 1792)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 2), ("SC_OPT_STAGE1_LIST_BLOCKS", 1536)),
+    (("SC_OPT_STAGE1_STORE_SHARE", 4), ("SC_OPT_STAGE1_LIST_BLOCKS", 1792), ("SC_OPT_FILL_BLOCKS", 256)),
+    (("SC_OPT_STAGE1_VOXELS", 1), ("SC_OPT_STAGE1_LIST_BLOCKS", 1792), ("SC_OPT_STAGE1_STORE_SHARE", 0)),
+    (("SC_OPT_STAGE1_VOXELS", 1),),
+    (("SC_OPT_FINAL_VOXELS", 1),), (("SC_OPT_FINAL_VOXELS", 4),),
+    (("SC_OPT_DEFER_SHARE", 14),), (("SC_OPT_DEFER_SHARE", 12),),
     (),
 ]
 
