@@ -207,6 +207,9 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
 //   (half a unit x up to 16 of those views, see UnitItems) for the final list stage -- or, when that would
 //   be no cheaper than the ordinary survivor lists (few voxels alive, most views undecided), the unit's
 //   voxels are appended to the first list like any other survivor.
+#ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront of the dense
+__device__ uint32_t g_dense_trace[8192 * 8];  // stage (rows 0..4095) and every wavefront of the unit verdict kernel (4096..) did
+#endif
 struct UnitJob {
     const uint32_t *units;    // null: no bulk list.  [kSub][cap] unit ids (brick * 4 + wavefront), counts in ctl->count[3]
     uint32_t cap;
@@ -375,16 +378,40 @@ __global__ __launch_bounds__(64 * kFlagWaves) void unit_verdict_kernel(GridDesc 
     const uint32_t uwave = __builtin_amdgcn_readfirstlane(tid >> 6), ulane = tid & 63u;
     const uint32_t nworkers = nunitblocks * kFlagWaves;
     uint32_t nunits = 0, saved = 0;
+#ifdef SC_TRACE_DENSE
+    const uint64_t tr0 = wall_clock64();
+    uint32_t tr_fetch = 0, tr_work = 0;
+#endif
     for (uint32_t i = blockIdx.x * kFlagWaves + uwave; i < total; i += nworkers) {
+#ifdef SC_TRACE_DENSE
+        const uint64_t tra = wall_clock64();
+#endif
         uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (upref[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t unit = __builtin_amdgcn_readfirstlane(uj.units[(size_t)lo * uj.cap + (i - upref[lo])]);
+#ifdef SC_TRACE_DENSE
+        const uint64_t trb = wall_clock64();
+        tr_fetch += (uint32_t)(trb - tra);
+#endif
         unit_verdicts(uj, g, ctl, unit, lo, ulane, saved);
+#ifdef SC_TRACE_DENSE
+        tr_work += (uint32_t)(wall_clock64() - trb);
+#endif
         ++nunits;
     }
+#ifdef SC_TRACE_DENSE
+    if (ulane == 0) {
+        const uint32_t w = 4096u + blockIdx.x * kFlagWaves + uwave;
+        if (w < 8192u) {
+            uint32_t *o = g_dense_trace + w * 8u;
+            o[0] = (uint32_t)tr0; o[1] = (uint32_t)wall_clock64(); o[2] = nunits; o[3] = saved;
+            o[4] = tr_fetch; o[5] = tr_work; o[6] = 0; o[7] = 0;
+        }
+    }
+#endif
     // what the host's on / off decision reads (see flush): one pair per block, summed by a list kernel (ReportJob)
     // (atomics on one address from every wavefront of the grid would take longer than the verdicts)
     __shared__ uint32_t s_stat[2];
@@ -452,9 +479,6 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
 // (neighbouring bricks, which project onto the same mask lines) stay on one XCD.  Blocks behind
 // the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
 // stage fills the others, see carve_list_kernel).
-#ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront did, and when
-__device__ uint32_t g_dense_trace[8192 * 8];
-#endif
 template <bool FRESH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,

@@ -34,7 +34,8 @@ def main():
     tr = np.zeros((8192, 8), dtype=np.uint32)
     rc = lib.sc_debug_dense_trace(ctypes.c_void_p(tr.ctypes.data))
     assert rc == 0, rc
-    tr = tr[tr[:, 1] != 0]
+    tr_all = tr
+    tr = tr[:4096][tr[:4096, 1] != 0]
     w = tr[:4096] if len(tr) >= 4096 else tr
     t0 = w[:, 0].astype(np.int64); t1 = w[:, 1].astype(np.int64)
     base = t0.min()
@@ -51,6 +52,17 @@ def main():
     order = np.argsort(t1)[-5:]
     out["last_finishers"] = [{"bricks": int(w[i, 2]), "units": int(w[i, 3]), "start": round((t0[i] - base) * 0.01, 2),
                               "end": round((t1[i] - base) * 0.01, 2)} for i in order]
+    u = tr_all[4096:8192]
+    u = u[u[:, 1] != 0]
+    if len(u):
+        t0 = u[:, 0].astype(np.int64); t1 = u[:, 1].astype(np.int64)
+        b = t0.min()
+        nun = int(u[:, 2].sum())
+        out["unit_verdict_kernel"] = {"wavefronts": int(len(u)), "units": nun,
+                                      "end_us_pct": np.percentile((t1 - b) * 0.01, [0, 50, 90, 100]).round(2).tolist(),
+                                      "units_per_wf_pct": np.percentile(u[:, 2], [0, 50, 100]).tolist(),
+                                      "us_fetching_the_unit_id": round(float(u[:, 4].sum()) * 0.01 / max(1, nun), 3),
+                                      "us_per_unit_after_that": round(float(u[:, 5].sum()) * 0.01 / max(1, nun), 3)}
     print(json.dumps(out))
 
 
