@@ -237,6 +237,9 @@ int sc_get_values_packed(sc_engine *e, int bits, void *out);
  * sc_packed_bytes(voxels, 2) bytes the call may scribble on (the caller's, so that its pages can be touched ahead).
  * SC_ERR_STATE unless default_value is one of -1, 0, 1 (use sc_get_values / sc_get_values_i8 then). */
 int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads);
+/* Host code only (no device, no engine): the widening sc_get_values_wire2's threads do, by itself -- `voxels` labels
+ * at 2 bits each in packed[(voxels + 15) / 16] (the layout above) into out[voxels] on `threads` threads (<= 0: 8). */
+int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int threads);
 int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
                      int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes);
 

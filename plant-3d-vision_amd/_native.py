@@ -71,6 +71,7 @@ _SIGNATURES = {
     "sc_values_packed": ("i", ["p", "i", "p", "p"]),
     "sc_get_values_packed": ("i", ["p", "i", "p"]),
     "sc_get_values_wire2": ("i", ["p", "p", "p", "q", "i"]),
+    "sc_widen_labels2": ("i", ["p", "q", "p", "i"]),
     "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
@@ -350,6 +351,21 @@ def average_labels(engines, K, R, t, mask_ptrs, n_views, H, W):
 def packed_bytes(voxels, bits):
     """Bytes of ``voxels`` labels packed at ``bits`` bits each (whole 16-byte groups)."""
     return int(backend().call("sc_packed_bytes", int(voxels), int(bits)))
+
+
+def widen_labels2(packed, voxels, out=None, threads=None):
+    """``sc_widen_labels2``: ``voxels`` labels at 2 bits each (uint32 words, 16 per word) -> int32, on host threads
+    inside the library (no device needed)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1)
+    if packed.size < (int(voxels) + 15) // 16:
+        raise ValueError("too few packed words")
+    if out is None:
+        out = np.empty(int(voxels), dtype=np.int32)
+    if out.dtype != np.int32 or out.size != int(voxels) or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError("output buffer has the wrong dtype/size/layout")
+    check(backend().call("sc_widen_labels2", addr(packed), int(voxels), addr(out),
+                         int(threads if threads is not None else host_workers(16))), "sc_widen_labels2")
+    return out
 
 
 def unpack_labels(device, stream_ptr, recv_ptr, rank_bytes, world, partition, shape, bits, out_ptr, out_bytes):

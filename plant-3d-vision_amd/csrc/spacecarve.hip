@@ -2089,6 +2089,19 @@ void widen2_range(const uint32_t *src, int32_t *dst, int64_t w0, int64_t w1, int
 }
 }  // namespace
 
+int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int threads) {
+    if (!packed || !out || voxels < 0) return fail(SC_ERR_INVALID, "bad argument");
+    if (threads <= 0) threads = 8;
+    threads = std::min(threads, 64);
+    const int64_t words = (voxels + 15) / 16;
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads);
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([=]() { widen2_range(packed, out, words * t / threads, words * (t + 1) / threads, voxels); });
+    for (auto &th : pool) th.join();
+    return SC_OK;
+}
+
 int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads) {
     if (!e || !out || !staging) return fail(SC_ERR_INVALID, "null argument");
     void *ptr = nullptr;
