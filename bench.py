@@ -263,9 +263,6 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
         K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
         fg = float(np.mean([(m != 0).mean() for _, _, _, m in views]))
         eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
-        # another scene on the same engine: what the engine learnt about the last one (whether the bulk units'
-        # verdicts pay, SC_OPT_BULK_ADAPT) does not carry over -- a Voxels run builds its engine per scan
-        eng.set_option(nat.SC_OPT_BULK_ADAPT, 1)
 
         def step():
             eng.clear()

@@ -73,16 +73,16 @@ extern "C" {
 #define SC_OPT_MAX_PENDING 4      /* deferred views that force a flush (default 256)          */
 #define SC_OPT_RESERVE_EVENTS 31  /* with SC_OPT_TIME_KERNELS: create n HIP events now (0..65536) so that the timed
                                      launches that follow find them in the engine's pool instead of creating them */
-/* The fused carve's tuning knobs (SC_OPT_COMPACT .. SC_OPT_BULK_ADAPT: where work moves between its kernels; results
- * never depend on them) are sc_set_option keys too, declared in spacecarve_tuning.h -- not part of what a caller of
- * the reference's interface needs. */
+/* The fused carve's tuning knobs (SC_OPT_COMPACT .. SC_OPT_UNIT_CULL: where work moves between its kernels; results
+ * never depend on them) are sc_set_option keys too, declared in spacecarve_tuning.h (included at the end of this
+ * header) -- not part of what a caller of the reference's interface needs. */
 
 /* kernel ids for sc_kernel_stats */
 #define SC_KERNEL_CARVE 0
 #define SC_KERNEL_AVERAGE 1
 #define SC_KERNEL_PACK 2
 #define SC_KERNEL_FILL 3
-#define SC_KERNEL_LIST 4 /* survivor-list stages + dense resume of a fused carve */
+#define SC_KERNEL_LIST 4 /* confirm + special kernel + survivor-list stages of a fused carve */
 #define SC_KERNEL_FLAGS 5 /* brick emptiness verdicts ahead of the dense stage (brick form) */
 #define SC_KERNEL_STEP 6  /* a whole fused batch: mask packing + every kernel of its launch     */
 
@@ -260,12 +260,12 @@ int sc_span_end(sc_engine *e, double *ms);
 
 /* Diagnostics of the last fused carve launch (waits for the stream): out[0] bricks no view found
  * empty (brick form, else 0), out[1] voxels alive after the dense stage, out[2] after the first
- * survivor stage, out[3] 1 if a survivor list overflowed (the dense resume kernel took over). */
+ * survivor stage, out[3] 1 if a survivor list overflowed (the special kernel's dense pass took over). */
 int sc_fused_counts(sc_engine *e, int64_t out[4]);
 /* ... the same four, then out[4]: candidate bricks (kept as they are by the views packed ahead) that a later
- * view did not keep -- carved brick by brick by the resume kernel; out[5]: units on the bulk list
- * (SC_OPT_BULK_MIN); out[6]: their work items; out[7]: batches the engine will still run without the bulk
- * list (SC_OPT_BULK_ADAPT). */
+ * view did not keep -- carved unit by unit by the special kernel; out[5]: units on the bulk list
+ * (SC_OPT_BULK_MIN); out[6]: their work items (0 when the batch had fewer units than SC_OPT_BULK_FLOOR: their
+ * voxels took the ordinary lists); out[7]: 0 (round 3: batches the host kept the bulk list off). */
 int sc_fused_counts_ex(sc_engine *e, int64_t out[8]);
 
 /* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on
@@ -400,4 +400,5 @@ int sc_group_get_values(sc_group *g, void *out);
 #ifdef __cplusplus
 }
 #endif
+#include "spacecarve_tuning.h" /* the SC_OPT_* tuning keys: same key space, results never depend on them */
 #endif /* SPACECARVE_H */

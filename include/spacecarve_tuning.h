@@ -60,10 +60,16 @@
                                      unit x up to 16 views each) when those cost at most this share of what its voxels
                                      would cost in the survivor lists; otherwise the voxels take the lists        */
 #define SC_OPT_UNIT_BLOCKS 34     /* blocks of 8 wavefronts giving the units their verdicts (512)                  */
-#define SC_OPT_BULK_ADAPT 35      /* 1 (default): the engine looks at what the units' verdicts of its last batches spared
-                                     the survivor stages and leaves the bulk list out for 64 batches when that was less
-                                     than they cost (a thin plant); 0: always on                                   */
+#define SC_OPT_BULK_FLOOR 35      /* bulk units a batch must have for their verdicts to be asked (2048): with fewer the
+                                     verdict rounds are a latency chain nothing amortises (a thin plant has a few dozen
+                                     bulky units) and the units' voxels join the first survivor list as they are.
+                                     Decided on the device, inside the batch, from the count its own dense stage left:
+                                     the first batch of an engine runs like every later one.  0: always asked        */
+#define SC_OPT_BULK_ADAPT SC_OPT_BULK_FLOOR /* deprecated name of key 35 (rounds 3: 0 = always on, which 0 still means) */
 
+#define SC_OPT_LIST_CAP 38        /* entries per survivor sub-list (0, the default: 5/16 of the voxels over the 256 sub-lists).
+                                     A small value makes the lists overflow on a small grid: how the tests reach the
+                                     overflow paths (the special kernel's dense pass, a bulk unit without room)      */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

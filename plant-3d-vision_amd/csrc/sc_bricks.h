@@ -197,234 +197,15 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
     }
 }
 
-// The UNITS of the bulk list (a wavefront's share of a live brick -- its 16 columns, voxels 16w .. 16w + 15 of
-// each: a square patch of the plane -- with most of its voxels alive after the dense views) are asked about as a whole before anything projects
-// their voxels: every remaining view at once, one view per lane, at the cell level (rect_verdict_cells).
-//   some view sees the unit entirely over background (EMPTY): every voxel is carved, done;
-//   views that see it entirely over foreground (FULL) make a label 0 a 1 (backprojection.c:81) here and now,
-//   and like the views that do not see it at all (OUTSIDE) have nothing more to say;
-//   the UNDECIDED views are the only ones that have to project its voxels: they become work items
-//   (half a unit x up to 16 of those views, see UnitItems) for the final list stage -- or, when that would
-//   be no cheaper than the ordinary survivor lists (few voxels alive, most views undecided), the unit's
-//   voxels are appended to the first list like any other survivor.
 #ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront of the dense
-__device__ uint32_t g_dense_trace[8192 * 8];  // stage (rows 0..4095) and every wavefront of the unit verdict kernel (4096..) did
+__device__ uint32_t g_dense_trace[8192 * 8];  // stage did (rows 0..4095)
 #endif
-struct UnitJob {
-    const uint32_t *units;    // null: no bulk list.  [kSub][cap] unit ids (brick * 4 + wavefront), counts in ctl->count[3]
-    uint32_t cap;
-    uint4 *items;             // [kSub][icap] work items out, counts in ctl->count[4]
-    uint32_t icap;
-    const ViewDesc *views;    // every view of the batch
-    int32_t nall, ndense;     // ... their number (<= 128), and how many of them the dense stage has applied
-    uint32_t bricks_y, bricks_z;
-    int32_t *labels;
-    uint32_t *list;           // the first survivor list and the room of its sub-lists (counts in ctl->count[0])
-    uint32_t subcap;
-    uint32_t bias;            // items are chosen when their turns * 16 <= bias * the turns the lists would take
-    uint32_t *stats;          // per unit block: {units that got their verdicts, turns those spared the survivor stages}
-};
-
-__device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
-                                              uint32_t sub, uint32_t lane, uint32_t &saved) {
-    const uint32_t lb = unit >> 2, w = unit & 3u;
-    const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
-    const uint32_t il = lb / per_plane;
-    const uint32_t rem = lb - il * per_plane;
-    const uint32_t by = rem / uj.bricks_z, bz = rem - by * uj.bricks_z;
-    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
-    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
-    const bool inside = j < g.ny && k0 < g.nz;
-    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
-    const uint32_t elem = (il * g.ny + j) * g.nzp + k0;
-    int32_t *p = uj.labels + elem;  // the pitch is a multiple of 64: 16-byte groups
-    int32_t lab[4] = {-1, -1, -1, -1};  // what a lane does not own counts as carved
-    if (inside) {
-        const int4 q = *reinterpret_cast<const int4 *>(p);
-        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
-    }
-    uint32_t alive = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (lab[e] != -1) alive |= 1u << e;  // :67
-    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
-    unsigned long long need[2] = {0ull, 0ull};
-    bool seen = false, empty = false;
-    for (int h = 0; h < 2 && h * 64 < uj.nall; ++h) {
-        const int vi = h * 64 + (int)lane;
-        uint32_t v = 8u;  // no such view, or one the dense stage has applied
-        if (vi < uj.nall && vi >= uj.ndense) {
-            const ViewDesc d = uj.views[vi];  // one descriptor per lane
-            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
-        }
-        empty |= __ballot(v == 1u) != 0;
-        seen |= __ballot(v == 2u) != 0;
-        need[h] = __ballot(v == 0u);
-    }
-    unsigned long long b[4];
-    uint32_t nalive = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        b[e] = __ballot((alive >> e) & 1u);
-        nalive += (uint32_t)__popcll(b[e]);
-    }
-    // turns of (128 voxels x 2 views) the unit's voxels would take in the survivor lists
-    const uint32_t list_cost = ((nalive + 127u) >> 7) * (((uint32_t)(uj.nall - uj.ndense) + 1u) >> 1);
-    if (empty) {  // some view carves every voxel of the unit
-        if (inside && alive != 0) *reinterpret_cast<int4 *>(p) = make_int4(-1, -1, -1, -1);
-        saved += list_cost;
-        return;
-    }
-    if (seen) {
-        bool changed = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (lab[e] == 0) { lab[e] = 1; changed = true; }  // :81 by a view that keeps the whole unit
-        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
-    }
-    const uint32_t nneed = (uint32_t)__popcll(need[0]) + (uint32_t)__popcll(need[1]);
-    const unsigned long long anyalive = __ballot(alive != 0);
-    if (nneed == 0 || anyalive == 0) {  // wave-uniform: the labels are final
-        saved += list_cost;
-        return;
-    }
-    // the undecided views of each 64-view word in pieces of up to 16; one item per (half with something
-    // alive, word, piece): lane = piece * 4 + word * 2 + half
-    unsigned long long pm[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool bit = (need[h] >> lane) & 1ull;
-        const uint32_t piece = lanes_below(need[h]) >> 4;  // this lane's view is the (16 piece + ..)-th undecided one
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pm[h][q] = __ballot(bit && piece == (uint32_t)q);
-    }
-    const uint32_t hq = lane & 1u, wq = (lane >> 1) & 1u, pq = lane >> 2;
-    unsigned long long mymask = 0ull;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (wq == (uint32_t)h && pq == (uint32_t)q) mymask = pm[h][q];
-    const uint32_t halves = ((uint32_t)(anyalive & 0xffffffffull) != 0u ? 1u : 0u) + ((uint32_t)(anyalive >> 32) != 0u ? 1u : 0u);
-    const bool half_alive = ((anyalive >> (32u * hq)) & 0xffffffffull) != 0;
-    const bool mine = lane < 16u && mymask != 0ull && half_alive;
-    const unsigned long long im = __ballot(mine);
-    const uint32_t nitems = (uint32_t)__popcll(im);
-    // turns of (128 voxels x 2 views): the items' against what the unit's voxels would take in the lists
-    const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (item_cost * 16u <= uj.bias * list_cost) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
-        pos = __shfl(pos, 0);
-        if (pos + nitems <= uj.icap) {
-            if (mine)
-                uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
-                    make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
-            saved += list_cost - min(list_cost, item_cost);
-            return;
-        }
-        // (no room: the count stays beyond the capacity, the reader clamps it; the voxels take the list)
-    }
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->count[0][sub].n, nalive);
-    base = __shfl(base, 0);
-    if (base + nalive > uj.subcap) {
-        if (lane == 0) ctl->overflow = 1u;
-        return;
-    }
-    uint32_t *dst = uj.list + (size_t)sub * uj.subcap + base;
-    uint32_t off = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if ((alive >> e) & 1u) dst[off + (uint32_t)__popcll(b[e] & below)] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
-        off += (uint32_t)__popcll(b[e]);
-    }
-}
-
 // FULL candidates (flag 3: every view the flags kernel could see keeps the brick whole, but the masks
 // of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
 // views: same organisation as the flags kernel's own FULL rounds (64 bricks per block, one view per
 // wavefront and round, verdicts joined in LDS).  Kept by all: flag 2, filled like any FULL brick.
-// Otherwise flag 5 and a place on the LATE list: the resume kernel carves such a brick over all the
-// views of the batch, voxel by voxel.  A block without candidates leaves at once.
-// The units of the bulk list get their verdicts, one wavefront per unit (unit_verdicts): a persistent grid of
-// blocks of 8 wavefronts, launched behind the confirm kernel (the masks of every view are packed by then) and
-// ahead of the list stages.  (A kernel of its own: inside the confirm kernel its registers cost that kernel's
-// blocks three wavefronts per SIMD, 40 us on a batch of all-foreground masks.)
-__global__ __launch_bounds__(64 * kFlagWaves) void unit_verdict_kernel(GridDesc g, ListCtl *ctl, UnitJob uj) {
-    const uint32_t nunitblocks = gridDim.x;
-    __shared__ uint32_t upref[kSub + 1];
-    const uint32_t tid = threadIdx.x;
-    {
-        if (tid < kSub) upref[tid + 1] = min(ctl->count[3][tid].n, uj.cap);
-        if (tid == 0) upref[0] = 0;
-        __syncthreads();
-        for (uint32_t off = 1; off < kSub; off <<= 1) {
-            uint32_t val = 0, add = 0;
-            if (tid < kSub) {
-                val = upref[tid + 1];
-                add = (tid >= off) ? upref[tid + 1 - off] : 0u;
-            }
-            __syncthreads();
-            if (tid < kSub) upref[tid + 1] = val + add;
-            __syncthreads();
-        }
-    }
-    const uint32_t total = upref[kSub];
-    const uint32_t uwave = __builtin_amdgcn_readfirstlane(tid >> 6), ulane = tid & 63u;
-    const uint32_t nworkers = nunitblocks * kFlagWaves;
-    uint32_t nunits = 0, saved = 0;
-#ifdef SC_TRACE_DENSE
-    const uint64_t tr0 = wall_clock64();
-    uint32_t tr_fetch = 0, tr_work = 0;
-#endif
-    for (uint32_t i = blockIdx.x * kFlagWaves + uwave; i < total; i += nworkers) {
-#ifdef SC_TRACE_DENSE
-        const uint64_t tra = wall_clock64();
-#endif
-        uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (upref[mid] <= i) lo = mid; else hi = mid;
-        }
-        const uint32_t unit = __builtin_amdgcn_readfirstlane(uj.units[(size_t)lo * uj.cap + (i - upref[lo])]);
-#ifdef SC_TRACE_DENSE
-        const uint64_t trb = wall_clock64();
-        tr_fetch += (uint32_t)(trb - tra);
-#endif
-        unit_verdicts(uj, g, ctl, unit, lo, ulane, saved);
-#ifdef SC_TRACE_DENSE
-        tr_work += (uint32_t)(wall_clock64() - trb);
-#endif
-        ++nunits;
-    }
-#ifdef SC_TRACE_DENSE
-    if (ulane == 0) {
-        const uint32_t w = 4096u + blockIdx.x * kFlagWaves + uwave;
-        if (w < 8192u) {
-            uint32_t *o = g_dense_trace + w * 8u;
-            o[0] = (uint32_t)tr0; o[1] = (uint32_t)wall_clock64(); o[2] = nunits; o[3] = saved;
-            o[4] = tr_fetch; o[5] = tr_work; o[6] = 0; o[7] = 0;
-        }
-    }
-#endif
-    // what the host's on / off decision reads (see flush): one pair per block, summed by a list kernel (ReportJob)
-    // (atomics on one address from every wavefront of the grid would take longer than the verdicts)
-    __shared__ uint32_t s_stat[2];
-    if (tid < 2) s_stat[tid] = 0u;
-    __syncthreads();
-    if (ulane == 0 && nunits != 0) {
-        atomicAdd(&s_stat[0], nunits);
-        atomicAdd(&s_stat[1], saved);
-    }
-    __syncthreads();
-    if (tid < 2) uj.stats[blockIdx.x * 2u + tid] = s_stat[tid];
-}
-
+// Otherwise flag 5 and a place on the LATE list: the special kernel (carve_special_kernel) carves such a brick
+// over all the views of the batch, unit by unit.  A block without candidates leaves at once.
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {

@@ -1,19 +1,10 @@
 // Part of spacecarve.hip (included there, inside its anonymous namespace, in this order: sc_types, sc_project,
-// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- the survivor stages (carve_list_kernel) and the resume kernel.
+// sc_stream, sc_pack, sc_verdicts, sc_bricks, sc_lists, sc_average, sc_misc) -- the survivor stages (carve_list_kernel), the bulk units' verdicts and the special kernel (bulk units, late bricks, the dense fallback).
 
 // Work items of the bulk units (see unit_verdicts): (half a unit = 8 columns x 16 voxels, up to 16 of the
 // views that have to project its voxels, as a mask over 64 consecutive views).  The final list stage's
 // wavefronts take them after their own spans; items of one unit may run side by side, which is exact for the
 // same reason as the spans of one chunk: -1 is a plain store, 0 -> 1 a compare-and-swap on 0.
-// What the bulk units' verdicts of this batch were worth, for the host's on / off decision (see flush): the
-// sums over the unit blocks' pairs (UnitJob::stats), written as ONE 8-byte word to page-locked memory by
-// block 0 of the first list kernel behind the verdicts, when it is through with its own work.
-struct ReportJob {
-    unsigned long long *report;  // null: nothing to report.  seq << 48 | min(units, 2^24 - 1) << 24 | min(turns spared / 16, 2^24 - 1)
-    const uint32_t *stats;
-    uint32_t nstats, seq;
-};
-
 struct UnitItems {
     const uint4 *items;       // null: none.  .x = unit * 2 + half, .y = first view of the mask, .z / .w = the mask
     uint32_t cap;             // items per sub-list (counts in ctl->count[4])
@@ -42,8 +33,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
                                                             ListCtl *ctl, int sin, int sout,
-                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui,
-                                                            ReportJob rj) {
+                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui) {
     __shared__ uint32_t pref[kSub + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t bx = blockIdx.x, gdim = gridDim.x;
@@ -305,28 +295,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             }
         }
     }
-    if (rj.report != nullptr && bid == 0) {  // block-uniform
-        __shared__ uint32_t s_sum[2];
-        if (tid < 2) s_sum[tid] = 0u;
-        __syncthreads();
-        uint32_t a = 0, b = 0;
-        for (uint32_t q = tid; q < rj.nstats; q += kBlock) {
-            a += rj.stats[q * 2u];
-            b += rj.stats[q * 2u + 1u];
-        }
-        if (a | b) {
-            atomicAdd(&s_sum[0], a);
-            atomicAdd(&s_sum[1], b);
-        }
-        __syncthreads();
-        if (tid == 0)
-            *rj.report = ((unsigned long long)(rj.seq & 0xffffu) << 48) | ((unsigned long long)min(s_sum[0], 0xffffffu) << 24) |
-                         (unsigned long long)min(s_sum[1] >> 4, 0xffffffu);
-    }
 }
 
-// Fused carve, safety net: when a survivor sub-list overflowed (e.g. masks that carve
-// nothing), a persistent grid applies the remaining views densely instead.
 struct LateBricks {           // FULL candidates that turned out not to be (see brick_confirm_kernel)
     const uint32_t *late;     // null: the batch had no open candidates
     const ViewDesc *allviews; // every view of the batch
@@ -420,48 +390,241 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
     if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void carve_resume_kernel(int32_t *__restrict__ labels, GridDesc g,
-                                                              const ViewDesc *__restrict__ views,
-                                                              int nviews, const ListCtl *ctl,
-                                                              ListCtl *next, LateBricks lb) {
-    // last kernel of a batch: leave the counters of the NEXT batch zeroed (the two blocks
-    // alternate; nobody else touches that one now), so no memset sits on the stream
-    if (next != nullptr) {
-        uint32_t *z = reinterpret_cast<uint32_t *>(next);
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < sizeof(ListCtl) / 4; i += gridDim.x * kBlock) z[i] = 0u;
+// The UNITS of the bulk list (a wavefront's share of a live brick -- its 16 columns, voxels 16w .. 16w + 15 of
+// each: a square patch of the plane -- with most of its voxels alive after the dense views) are asked about as a whole before anything projects
+// their voxels: every remaining view at once, one view per lane, at the cell level (rect_verdict_cells).
+//   some view sees the unit entirely over background (EMPTY): every voxel is carved, done;
+//   views that see it entirely over foreground (FULL) make a label 0 a 1 (backprojection.c:81) here and now,
+//   and like the views that do not see it at all (OUTSIDE) have nothing more to say;
+//   the UNDECIDED views are the only ones that have to project its voxels: they become work items
+//   (half a unit x up to 16 of those views, see UnitItems) for the final list stage -- or, when that would
+//   be no cheaper than the ordinary survivor lists (few voxels alive, most views undecided), the unit's
+//   voxels are appended to the first list like any other survivor.
+struct UnitJob {
+    const uint32_t *units;    // null: no bulk list.  [kSub][cap] unit ids (brick * 4 + wavefront), counts in ctl->count[3]
+    uint32_t cap;
+    uint4 *items;             // [kSub][icap] work items out, counts in ctl->count[4]
+    uint32_t icap;
+    const ViewDesc *views;    // every view of the batch
+    int32_t nall, ndense;     // ... their number (<= 128), and how many of them the dense stage has applied
+    uint32_t bricks_y, bricks_z;
+    int32_t *labels;
+    uint32_t *list;           // the first survivor list and the room of its sub-lists (counts in ctl->count[0])
+    uint32_t subcap;
+    uint32_t bias;            // items are chosen when their turns * 16 <= bias * the turns the lists would take
+    uint32_t floor;           // fewer bulk units than this in the whole batch: no verdicts, their voxels join the first
+                              // survivor list as they are (see carve_special_kernel)
+};
+
+__device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
+                                              uint32_t sub, uint32_t lane, bool ask) {
+    const uint32_t lb = unit >> 2, w = unit & 3u;
+    const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
+    const uint32_t il = lb / per_plane;
+    const uint32_t rem = lb - il * per_plane;
+    const uint32_t by = rem / uj.bricks_z, bz = rem - by * uj.bricks_z;
+    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);  // 16 columns x 16 voxels
+    const uint32_t j = (uint32_t)j0 + (lane >> 2), k0 = (uint32_t)kb + (lane & 3u) * 4u;
+    const bool inside = j < g.ny && k0 < g.nz;
+    const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
+    const uint32_t elem = (il * g.ny + j) * g.nzp + k0;
+    int32_t *p = uj.labels + elem;  // the pitch is a multiple of 64: 16-byte groups
+    int32_t lab[4] = {-1, -1, -1, -1};  // what a lane does not own counts as carved
+    if (inside) {
+        const int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
     }
-    Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
-    if (lb.late != nullptr) {
-        // bricks some later view does not keep whole after all: every view, one wavefront per unit
-        const uint32_t nlate = ctl->nlate;
-        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const uint32_t nworkers = gridDim.x * (kBlock / 64);
-        for (uint32_t t = blockIdx.x * (kBlock / 64) + wave; t < nlate * 4u; t += nworkers) {
-            const uint32_t unit = lb.late[t >> 2] * 4u + (t & 3u);
-            if (lb.fresh) late_unit<true>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
-            else late_unit<false>(labels, g, lb.allviews, lb.nall, lb.init, unit, lb.bricks_y, lb.bricks_z, lane);
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (lab[e] != -1) alive |= 1u << e;  // :67
+    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
+    unsigned long long need[2] = {0ull, 0ull};
+    bool seen = false, empty = false;
+    for (int h = 0; ask && h < 2 && h * 64 < uj.nall; ++h) {  // (ask: wave-uniform)
+        const int vi = h * 64 + (int)lane;
+        uint32_t v = 8u;  // no such view, or one the dense stage has applied
+        if (vi < uj.nall && vi >= uj.ndense) {
+            const ViewDesc d = uj.views[vi];  // one descriptor per lane
+            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+        }
+        empty |= __ballot(v == 1u) != 0;
+        seen |= __ballot(v == 2u) != 0;
+        need[h] = __ballot(v == 0u);
+    }
+    unsigned long long b[4];
+    uint32_t nalive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        b[e] = __ballot((alive >> e) & 1u);
+        nalive += (uint32_t)__popcll(b[e]);
+    }
+    // turns of (128 voxels x 2 views) the unit's voxels would take in the survivor lists
+    const uint32_t list_cost = ((nalive + 127u) >> 7) * (((uint32_t)(uj.nall - uj.ndense) + 1u) >> 1);
+    if (empty) {  // some view carves every voxel of the unit
+        if (inside && alive != 0) *reinterpret_cast<int4 *>(p) = make_int4(-1, -1, -1, -1);
+        return;
+    }
+    if (seen) {
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lab[e] == 0) { lab[e] = 1; changed = true; }  // :81 by a view that keeps the whole unit
+        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    }
+    const uint32_t nneed = (uint32_t)__popcll(need[0]) + (uint32_t)__popcll(need[1]);
+    const unsigned long long anyalive = __ballot(alive != 0);
+    if (anyalive == 0 || (ask && nneed == 0)) return;  // wave-uniform: the labels are final
+    // the undecided views of each 64-view word in pieces of up to 16; one item per (half with something
+    // alive, word, piece): lane = piece * 4 + word * 2 + half
+    unsigned long long pm[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool bit = (need[h] >> lane) & 1ull;
+        const uint32_t piece = lanes_below(need[h]) >> 4;  // this lane's view is the (16 piece + ..)-th undecided one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pm[h][q] = __ballot(bit && piece == (uint32_t)q);
+    }
+    const uint32_t hq = lane & 1u, wq = (lane >> 1) & 1u, pq = lane >> 2;
+    unsigned long long mymask = 0ull;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (wq == (uint32_t)h && pq == (uint32_t)q) mymask = pm[h][q];
+    const uint32_t halves = ((uint32_t)(anyalive & 0xffffffffull) != 0u ? 1u : 0u) + ((uint32_t)(anyalive >> 32) != 0u ? 1u : 0u);
+    const bool half_alive = ((anyalive >> (32u * hq)) & 0xffffffffull) != 0;
+    const bool mine = lane < 16u && mymask != 0ull && half_alive;
+    const unsigned long long im = __ballot(mine);
+    const uint32_t nitems = (uint32_t)__popcll(im);
+    // turns of (128 voxels x 2 views): the items' against what the unit's voxels would take in the lists
+    const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (ask && item_cost * 16u <= uj.bias * list_cost) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
+        pos = __shfl(pos, 0);
+        if (pos + nitems <= uj.icap) {
+            if (mine)
+                uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
+                    make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
+            return;
+        }
+        // (no room: the count stays beyond the capacity, the reader clamps it; the voxels take the list)
+    }
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->count[0][sub].n, nalive);
+    base = __shfl(base, 0);
+    if (base + nalive > uj.subcap) {
+        // no room in the sub-list (its count stays beyond the capacity, the readers clamp it): this wavefront takes
+        // the unit through every view of the batch itself.  The overflow flag is the dense stage's alone -- the
+        // blocks of this kernel read it when they start -- and views applied twice change nothing.
+        late_unit<false>(uj.labels, g, uj.views, uj.nall, 0, unit, uj.bricks_y, uj.bricks_z, lane);
+        return;
+    }
+    uint32_t *dst = uj.list + (size_t)sub * uj.subcap + base;
+    uint32_t off = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if ((alive >> e) & 1u) dst[off + (uint32_t)__popcll(b[e] & below)] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
+        off += (uint32_t)__popcll(b[e]);
+    }
+}
+
+// The kernel between the dense stage (and the confirm kernel) and the survivor stages: everything of a batch that is
+// neither a brick verdict nor a survivor list.
+//   * zeroes the counters of the NEXT batch (the two control blocks alternate; nobody else touches that one now),
+//     so no memset sits on the stream;
+//   * the units of the bulk list get their verdicts, one wavefront per unit (unit_verdicts) -- when the batch has
+//     at least `uj.floor` of them: a latency chain of ~7 us per round of wavefronts is not worth a handful of units
+//     (a thin plant has a few dozen), whose voxels then join the first survivor list as they are.  The decision is
+//     taken HERE, from the count the dense stage of this very batch left, so the first batch of a fresh engine
+//     runs exactly like every later one;
+//   * LATE bricks (FULL candidates some later view did not keep whole after all) are carved unit by unit over every
+//     view of the batch (late_unit);
+//   * when a survivor sub-list overflowed in the dense stage (masks that carve little), the views it has not
+//     applied are applied densely here instead; the list kernels behind see the flag and leave.
+struct SpecialJob {
+    UnitJob uj;            // uj.units == nullptr: no bulk list
+    LateBricks lb;         // lb.late == nullptr: the batch had no open candidates
+    ListCtl *next;         // nullptr: nothing to zero
+    const ViewDesc *rest;  // the views the dense stage has not applied (dense fallback)
+    int32_t nrest;
+    const uint8_t *flags;  // brick verdicts (nullptr: a launch without bricks)
+    uint32_t bricks_y, bricks_z;
+};
+
+__global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t *__restrict__ labels, GridDesc g,
+                                                                       ListCtl *ctl, SpecialJob sj) {
+    constexpr uint32_t kThreads = 64 * kFlagWaves;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint32_t nworkers = gridDim.x * kFlagWaves;
+    if (sj.next != nullptr) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(sj.next);
+        for (uint32_t i = blockIdx.x * kThreads + tid; i < sizeof(ListCtl) / 4; i += gridDim.x * kThreads) z[i] = 0u;
+    }
+    const bool overflow = ctl->overflow != 0u;  // written by the dense stage only: the same for every block
+    if (sj.uj.units != nullptr && !overflow) {  // grid-uniform
+        __shared__ uint32_t upref[kSub + 1];
+        if (tid < kSub) upref[tid + 1] = min(ctl->count[3][tid].n, sj.uj.cap);
+        if (tid == 0) upref[0] = 0;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            uint32_t val = 0, add = 0;
+            if (tid < kSub) {
+                val = upref[tid + 1];
+                add = (tid >= off) ? upref[tid + 1 - off] : 0u;
+            }
+            __syncthreads();
+            if (tid < kSub) upref[tid + 1] = val + add;
+            __syncthreads();
+        }
+        const uint32_t total = upref[kSub];
+        const bool ask = total >= sj.uj.floor;  // grid-uniform
+        for (uint32_t i = blockIdx.x * kFlagWaves + wave; i < total; i += nworkers) {
+            uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (upref[mid] <= i) lo = mid; else hi = mid;
+            }
+            const uint32_t unit = __builtin_amdgcn_readfirstlane(sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])]);
+            unit_verdicts(sj.uj, g, ctl, unit, lo, lane, ask);
         }
     }
-    if (!ctl->overflow) return;
-    uint64_t nblk = (g.ngroups + kBlock - 1) / kBlock;
+    if (sj.lb.late != nullptr) {
+        // bricks some later view does not keep whole after all: every view, one wavefront per unit
+        const uint32_t nlate = ctl->nlate;
+        for (uint32_t t = blockIdx.x * kFlagWaves + wave; t < nlate * 4u; t += nworkers) {
+            const uint32_t unit = sj.lb.late[t >> 2] * 4u + (t & 3u);
+            if (sj.lb.fresh) late_unit<true>(labels, g, sj.lb.allviews, sj.lb.nall, sj.lb.init, unit, sj.lb.bricks_y, sj.lb.bricks_z, lane);
+            else late_unit<false>(labels, g, sj.lb.allviews, sj.lb.nall, sj.lb.init, unit, sj.lb.bricks_y, sj.lb.bricks_z, lane);
+        }
+    }
+    if (!overflow) return;
+    // The dense fallback.  Every label it reads has been written: the dense stage stores the voxels of the live
+    // bricks whatever their state; settled bricks (their fill comes with the list kernels' store blocks, which run
+    // whatever the flag says) and late bricks (above, over ALL views, perhaps by a block that has not written
+    // them yet) are not this pass's voxels.
+    const Append none{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
+    const uint64_t nblk = (g.ngroups + kThreads - 1) / kThreads;
     for (uint64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        uint64_t grp = blk * kBlock + threadIdx.x;
+        const uint64_t grp = blk * kThreads + tid;
         bool skip = grp >= g.ngroups;
-        if (!skip && lb.late != nullptr) {
-            // bricks every view keeps whole have nothing to gain from this pass, and late bricks are carved
-            // above over ALL views by a block that may not have written them yet: not this pass's voxels
+        if (!skip && sj.flags != nullptr) {
             Vox4 vx;
             decode_group(g, grp, vx);
             const uint32_t col = (uint32_t)(vx.elem / g.nzp), il = col / g.ny, j = col - il * g.ny;
-            const uint32_t fl = lb.flags[(il * lb.bricks_y + j / kBrickY) * lb.bricks_z + vx.k0 / kBrickZ];
-            skip = fl == 5u || fl == 2u || fl == 6u;
+            const uint32_t fl = sj.flags[(il * sj.bricks_y + j / kBrickY) * sj.bricks_z + vx.k0 / kBrickZ];
+            skip = fl != 0u;  // 1 EMPTY, 2 FULL, 4 dead, 5 late, 6 UNTOUCHED (candidates have their answer by now)
         }
         // (a wavefront's lanes leave carve_group's view loop together: skipped lanes still vote)
-        if (grp < g.ngroups && !skip) {
-            int4 pre = make_int4(0, 0, 0, 0);
-            if (VEC) pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
-            carve_group<false, VEC>(labels, g, views, nviews, 0, grp, pre, none);
+        if (!skip) {
+            const int4 pre = *reinterpret_cast<const int4 *>(labels + grp * 4);
+            carve_group<false, true>(labels, g, sj.rest, sj.nrest, 0, grp, pre, none);
         }
     }
 }

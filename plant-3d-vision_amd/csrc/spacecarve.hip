@@ -170,16 +170,10 @@ struct sc_engine {
     uint32_t itemcap = 0;      // ... per sub-list
     int64_t item_bias = 12;    // sixteenths: items are chosen over the lists when they cost at most this share
     int64_t unit_blocks = 512; // blocks of 8 wavefronts walking the bulk list behind the confirm kernel
-    // Whether the bulk list pays is a property of the scene (a bulky object or a grid wider than the pictures:
-    // yes; a thin plant: the verdicts settle next to nothing and cost ~10 us), so the engine looks at what the
-    // verdicts of its last batches spared the survivor stages and leaves the bulk list out for a while when
-    // that was less than they cost.  Results never depend on it.
-    int64_t bulk_adapt = 1;
-    volatile unsigned long long *report = nullptr;  // page-locked: see ReportJob
-    uint32_t report_seq = 0, report_seen = 0;
-    int bulk_hold = 0;         // batches still to run without the bulk list
-    uint32_t *unit_stats = nullptr;  // [unit blocks][2], see UnitJob
-    size_t unit_stats_cap = 0;
+    // Whether the bulk units' verdicts pay is decided on the device, inside the batch, from the number of units its
+    // own dense stage left (carve_special_kernel): fewer than this and their voxels take the ordinary lists
+    int64_t bulk_floor = 2048;
+    int64_t list_cap = 0, list_cap_built = 0;  // entries per survivor sub-list (0: sized from the grid); tests of the overflow paths
     uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
     uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
     uint32_t last_parity = 0;
@@ -730,13 +724,20 @@ void order_views(std::vector<ViewDesc> &v, std::vector<uint32_t> *perm = nullptr
 constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
 
 int ensure_lists(sc_engine *e) {
-    if (e->lists) return SC_OK;
+    if (e->lists && e->list_cap_built == e->list_cap) return SC_OK;
+    if (e->lists) {  // the capacity knob moved (tests of the overflow paths): rebuilt behind the stream
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->lists);
+        e->lists = nullptr;
+    }
     // room for 5/16 of the voxels: two views of coin-flip masks leave a quarter alive, which the hashed
     // sub-lists must hold with a margin for their unevenness (an overflow sends the batch down the dense
     // resume path, 10 x slower)
     uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4 + (uint64_t)e->n / 16, (uint64_t)kSub * 1024);
     e->subcap = (uint32_t)((total + kSub - 1) / kSub);
+    if (e->list_cap > 0) e->subcap = (uint32_t)e->list_cap;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lists), (size_t)2 * kSub * e->subcap * sizeof(uint32_t)));
+    e->list_cap_built = e->list_cap;
     return SC_OK;
 }
 
@@ -751,11 +752,24 @@ int ensure_ctl(sc_engine *e) {
     size_t flag_bytes = (nbricks + 15) & ~(size_t)15;
     // bulk units: four per brick, hashed over the sub-lists; twice the even share each (a full one sends its
     // units' voxels down the ordinary lists)
-    e->bulkcap = (uint32_t)((nbricks * 4 * 2 + kSub - 1) / kSub + 64);
-    const size_t bulk_words = nbricks ? (size_t)kSub * e->bulkcap : 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base),
-                      2 * sizeof(ListCtl) + flag_bytes + (3 * nbricks + bulk_words) * sizeof(uint32_t) + 16));
-    HIP_TRY(hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream));
+    const uint32_t bulkcap = (uint32_t)((nbricks * 4 * 2 + kSub - 1) / kSub + 64);
+    const size_t bulk_words = nbricks ? (size_t)kSub * bulkcap : 0;
+    // up to 2 halves x 2 words x 4 pieces per unit; room for a third of that on average (a full sub-list
+    // sends the unit's voxels down the ordinary lists)
+    const uint32_t itemcap = bulkcap * 5u;
+    uint4 *items = nullptr;
+    if (bulk_words) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&items), (size_t)kSub * itemcap * sizeof(uint4)));
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&base),
+                              2 * sizeof(ListCtl) + flag_bytes + (3 * nbricks + bulk_words) * sizeof(uint32_t) + 16);
+    if (he == hipSuccess) he = hipMemsetAsync(base, 0, 2 * sizeof(ListCtl), e->stream);
+    if (he != hipSuccess) {  // nothing of this is published before all of it exists
+        if (items) (void)hipFree(items);
+        if (base) (void)hipFree(base);
+        return fail(he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE, "control block allocation failed: %s", hipGetErrorString(he));
+    }
+    e->bulkcap = bulkcap;
+    e->itemcap = itemcap;
+    e->items = items;
     e->ctl2[0] = reinterpret_cast<ListCtl *>(base);
     e->ctl2[1] = e->ctl2[0] + 1;
     e->ctl_clean[0] = e->ctl_clean[1] = true;
@@ -766,12 +780,6 @@ int ensure_ctl(sc_engine *e) {
     e->late = e->live + nbricks;
     e->fill_list = e->late + nbricks;
     e->bulk = bulk_words ? e->fill_list + nbricks : nullptr;
-    if (bulk_words) {
-        // up to 2 halves x 2 words x 4 pieces per unit; room for a third of that on average (a full sub-list
-        // sends the unit's voxels down the ordinary lists)
-        e->itemcap = e->bulkcap * 5u;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->items), (size_t)kSub * e->itemcap * sizeof(uint4)));
-    }
     return SC_OK;
 }
 
@@ -1002,37 +1010,9 @@ int flush(sc_engine *e, size_t count = 0) {
             dense_views = ndense;
         }
         // bulk units: brick form with survivor stages, every view with its cell level
-        bool bulk_on = compact && brick && e->bulk_min > 0 && e->bulk != nullptr;
+        bool bulk_on = compact && brick && e->bulk_min > 0 && e->bulk != nullptr && e->items != nullptr;
         if (nv > 128) bulk_on = false;  // the units' verdict masks cover 128 views
         for (size_t q = 0; q < nv && bulk_on; ++q) bulk_on = e->pending[q].cmask != nullptr;
-        if (bulk_on && e->bulk_adapt) {
-            if (!e->report) {
-                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(const_cast<unsigned long long **>(&e->report)), 64, hipHostMallocDefault));
-                e->report[0] = 0ull;
-            }
-            const unsigned long long rep = e->report[0];
-            const uint32_t seq = (uint32_t)(rep >> 48);
-            if (seq != e->report_seen) {  // a batch has reported since the last look
-                e->report_seen = seq;
-                const uint64_t units = (rep >> 24) & 0xffffffu, spared = (rep & 0xffffffu) << 4;
-                // Measured on one MI355X: the verdicts take max(10 us, 3.3 ns per unit) and a turn spared is worth
-                // 0.28 ns of the survivor stages (2.3 us per turn over 8192 wavefronts)
-                // (no unit at all: the verdict kernel's launch and the dense stage's bookkeeping bought nothing)
-                if (spared < std::max<uint64_t>(36000, units * 12)) e->bulk_hold = 64;
-            }
-            if (e->bulk_hold > 0) {
-                --e->bulk_hold;
-                bulk_on = false;
-            }
-        }
-        if (bulk_on && (size_t)e->unit_blocks > e->unit_stats_cap) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            if (e->unit_stats) (void)hipFree(e->unit_stats);
-            e->unit_stats = nullptr;
-            e->unit_stats_cap = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->unit_stats), (size_t)e->unit_blocks * 2 * sizeof(uint32_t)));
-            e->unit_stats_cap = (size_t)e->unit_blocks;
-        }
         if (bulk_on) {
             ap.bulk = e->bulk;
             ap.bulkcap = e->bulkcap;
@@ -1146,12 +1126,24 @@ int flush(sc_engine *e, size_t count = 0) {
                 hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kFlagWaves), 0, e->stream, g, vd,
                                    packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
             }
-            if (bulk_on) {
-                // ... and the units of the bulk list their verdicts
-                const UnitJob uj{e->bulk, e->bulkcap, e->items, e->itemcap, vd, (int32_t)nv, ndense, bys, bzs, st,
-                                 e->lists, e->subcap, (uint32_t)e->item_bias, e->unit_stats};
-                hipLaunchKernelGGL(unit_verdict_kernel, dim3((uint32_t)e->unit_blocks), dim3(64 * kFlagWaves), 0,
-                                   e->stream, g, e->ctl, uj);
+            {
+                // bulk units, late bricks, the dense fallback, the next batch's counters: one launch, always there
+                // (what it finds to do is decided on the device)
+                SpecialJob sj;
+                memset(&sj, 0, sizeof sj);
+                if (bulk_on)
+                    sj.uj = UnitJob{e->bulk, e->bulkcap, e->items, e->itemcap, vd, (int32_t)nv, ndense, bys, bzs, st,
+                                    e->lists, e->subcap, (uint32_t)e->item_bias, (uint32_t)e->bulk_floor};
+                sj.lb = LateBricks{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
+                sj.next = e->ctl2[e->ctl_idx ^ 1];
+                sj.rest = vd + ndense;
+                sj.nrest = (int32_t)nv - ndense;
+                sj.flags = brick ? e->flags : nullptr;
+                sj.bricks_y = bys;
+                sj.bricks_z = bzs;
+                hipLaunchKernelGGL(carve_special_kernel, dim3((uint32_t)e->unit_blocks), dim3(64 * kFlagWaves), 0,
+                                   e->stream, st, g, e->ctl, sj);
+                e->ctl_clean[e->ctl_idx ^ 1] = true;
             }
             // final stage with deferred stores: e->defer_stores persistent list blocks (they leave
             // wavefront slots free) and one short store block per strip behind them
@@ -1182,28 +1174,18 @@ int flush(sc_engine *e, size_t count = 0) {
             uint32_t *nolist = nullptr;
             // the final stage also takes the work items of the bulk units
             const UnitItems noitems{nullptr, 0u, nullptr, 0u, 0u}, ui{bulk_on ? e->items : nullptr, e->itemcap, vd, bys, bzs};
-            // ... and the first list kernel behind the verdicts tells the host what they were worth
-            const ReportJob norep{nullptr, nullptr, 0u, 0u};
-            ReportJob rj = norep;
-            if (bulk_on && e->bulk_adapt)
-                rj = ReportJob{const_cast<unsigned long long *>(e->report), e->unit_stats, (uint32_t)e->unit_blocks, ++e->report_seq};
             if ((size_t)s1 >= nv) {
-                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs, ui, rj);
+                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs, ui);
             } else {
-                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1, noitems, rj);
+                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1, noitems);
                 if (s2 > s1 && (size_t)s2 < nv) {
-                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none, noitems, norep);
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs, ui, norep);
+                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none, noitems);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs, ui);
                 } else {
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs, ui, norep);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs, ui);
                 }
             }
 #undef LAUNCH_LIST
-            // the resume kernel is also what zeroes the next batch's counters
-            e->ctl_clean[e->ctl_idx ^ 1] = true;
-            const LateBricks late{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
-            hipLaunchKernelGGL(carve_resume_kernel<true>, dim3(list_blocks), block, 0, e->stream,
-                               st, g, vd + ndense, (int)nv - ndense, e->ctl, e->ctl2[e->ctl_idx ^ 1], late);
             HIP_TRY(hipGetLastError());
             rc = lt2.end();
             if (rc) return rc;
@@ -1453,8 +1435,6 @@ void sc_destroy(sc_engine *e) {
     if (e->lists) (void)hipFree(e->lists);
     if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
     if (e->items) (void)hipFree(e->items);
-    if (e->report) (void)hipHostFree(const_cast<unsigned long long *>(e->report));
-    if (e->unit_stats) (void)hipFree(e->unit_stats);
     if (e->state) (void)hipFree(e->state);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -1595,9 +1575,13 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value < 0 || value > 2) return fail(SC_ERR_INVALID, "unit_cull must be 0, 1 or 2");
             e->unit_cull = value;
             return SC_OK;
-        case SC_OPT_BULK_ADAPT:
-            e->bulk_adapt = value ? 1 : 0;
-            e->bulk_hold = 0;
+        case SC_OPT_BULK_FLOOR:
+            if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
+            e->bulk_floor = value;
+            return SC_OK;
+        case SC_OPT_LIST_CAP:
+            if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "list_cap must be in [0, 2^31)");
+            e->list_cap = value;
             return SC_OK;
         case SC_OPT_UNIT_BLOCKS:
             if (value < 1 || value > 65536) return fail(SC_ERR_INVALID, "unit_blocks must be in [1, 65536]");
@@ -2266,7 +2250,7 @@ int sc_fused_counts_ex(sc_engine *e, int64_t out[8]) {
             out[5] += std::min<uint32_t>(host.count[3][q].n, e->bulkcap);
             out[6] += std::min<uint32_t>(host.count[4][q].n, e->itemcap);
         }
-    out[7] = e->bulk_hold;
+    out[7] = 0;  // (was: batches the host kept the bulk list off; the decision is the device's now)
     return SC_OK;
 }
 

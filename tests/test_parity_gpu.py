@@ -91,13 +91,70 @@ def test_carve_given_order_equals_perpendicular_first_order(gpu_device):
 
 
 @pytest.mark.parametrize("kind,n,v", [("solid", 40, 12), ("noise", 40, 12), ("solid", (33, 20, 30), 9)])
-def test_survivor_list_overflow_falls_back_to_dense_resume(gpu_device, kind, n, v):
-    """Masks that carve little overflow the survivor sub-lists (capacity N/8): the dense
-    resume kernel must finish the remaining views with the same result."""
+def test_masks_that_carve_little_through_both_schedules(gpu_device, kind, n, v):
     shape, origin, vs, views = scene(n, v, kind)
     want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
     assert np.array_equal(hip_carve(shape, origin, vs, views, compact=1), want)
     assert np.array_equal(hip_carve(shape, origin, vs, views, compact=0), want)
+
+
+def _batch(e, views, host):
+    if host:
+        for K, R, t, m in views:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        return None
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([q[0] for q in views]); R = np.stack([q[1] for q in views]); t = np.stack([q[2] for q in views])
+    e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+    return ptr
+
+
+@pytest.mark.parametrize("kind,shape,v", [("noise", (8, 32, 128), 12), ("plant", (12, 48, 128), 10), ("dense", (9, 32, 192), 12)])
+@pytest.mark.parametrize("host", [False, True])
+@pytest.mark.parametrize("brick", [1, 0])
+def test_survivor_list_overflow_takes_the_dense_pass(gpu_device, kind, shape, v, host, brick):
+    """A survivor sub-list that runs out of room in the dense stage (SC_OPT_LIST_CAP makes that happen on a small
+    grid) raises the overflow flag: the list kernels leave and the special kernel applies the remaining views
+    densely -- same labels, on a fresh volume and on a second batch over the stored one."""
+    sh, origin, vs, views = scene(shape, v, kind)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+    e.set_option(nat.SC_OPT_LIST_CAP, 4)
+    e.set_option(nat.SC_OPT_BRICK, brick)
+    e.set_option(nat.SC_OPT_UNIT_CULL, 2)
+    ptr = _batch(e, views, host)
+    assert np.array_equal(e.get_values(), want), (kind, host, brick, histogram3(want))
+    assert e.fused_counts()[3] == 1, "the lists did not overflow: the test tests nothing"
+    ptr2 = _batch(e, views, host)
+    assert np.array_equal(e.get_values(), want), "second batch over the stored volume"
+    for q in (ptr, ptr2):
+        if q is not None:
+            e.dev_free(q)
+    e.close()
+
+
+@pytest.mark.parametrize("kind,shape", [("dense", (9, 32, 192)), ("plant", (12, 48, 128)), ("solid", (6, 32, 128))])
+@pytest.mark.parametrize("floor", [0, 1 << 30])
+def test_bulk_unit_without_room_in_the_lists_is_carved_on_the_spot(gpu_device, kind, shape, floor):
+    """Every unit with a voxel alive goes on the bulk list (SC_OPT_BULK_MIN 1), so the dense stage appends nothing
+    and cannot overflow; the special kernel then finds no room for the units' voxels in the sub-lists
+    (SC_OPT_LIST_CAP) and takes each such unit through every view itself -- asked first (floor 0) or not."""
+    sh, origin, vs, views = scene(shape, 11, kind)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+    for k, val in ((nat.SC_OPT_LIST_CAP, 2), (nat.SC_OPT_BULK_MIN, 1), (nat.SC_OPT_BULK_FLOOR, floor),
+                   (nat.SC_OPT_ITEM_BIAS, 0), (nat.SC_OPT_UNIT_CULL, 0)):
+        e.set_option(k, val)
+    ptr = _batch(e, views, False)
+    assert np.array_equal(e.get_values(), want), (kind, floor, histogram3(want))
+    c = e.fused_counts_ex()
+    assert c["list_overflow"] == 0, "only the dense stage may raise the flag"
+    if kind != "solid":
+        assert c["bulk_units"] > 0
+    e.dev_free(ptr)
+    e.close()
 
 
 @pytest.mark.parametrize("shape,kw", [
@@ -171,14 +228,18 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_STAGE1_VOXELS": 4, "SC_OPT_VIEW_GROUP": 3},
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
     {"SC_OPT_BULK_MIN": 0},                                               # no unit is finished as a whole
-    {"SC_OPT_BULK_MIN": 1},                                               # every unit with a voxel alive is
-    {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0},
-    {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8},
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},                       # every unit with a voxel alive is, and asked
+    {"SC_OPT_BULK_MIN": 1},                                               # ... too few for the default floor: spilled
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_ITEM_BIAS": 64},  # items whatever they cost
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_ITEM_BIAS": 0},   # never items: asked, then the lists
+    {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0, "SC_OPT_BULK_FLOOR": 0},
+    {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8, "SC_OPT_BULK_FLOOR": 0},
+    {"SC_OPT_BULK_MIN": 40, "SC_OPT_UNIT_BLOCKS": 1, "SC_OPT_BULK_FLOOR": 3},  # one block does all the special kernel has
     {"SC_OPT_PACK_ROWS": 4},                                              # the panel form of the pack kernel
     {"SC_OPT_PACK_ROWS": 3, "SC_OPT_PACK_RIDE": 0},                       # bands, every mask packed ahead
     {"SC_OPT_PACK_ROWS": 8, "SC_OPT_PACK_RIDE": 0},
     {"SC_OPT_UNIT_CULL": 0},                                              # no unit verdicts in the dense stage
-    {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1},                        # ... asked whatever the tiles settled
+    {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},  # ... asked whatever the tiles settled
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
@@ -267,6 +328,7 @@ def test_bulk_units_asked_as_a_whole(gpu_device, shape, default_value, bulk_min,
         want = oracle_c.carve(sh, origin, vs, vv, default_value, nthreads=4)
         e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=default_value)
         e.set_option(nat.SC_OPT_BULK_MIN, bulk_min)
+        e.set_option(nat.SC_OPT_BULK_FLOOR, 0)  # asked however few they are (a test grid has fewer than the default floor)
         e.set_option(nat.SC_OPT_FULL_BRICKS, full)
         stack = np.ascontiguousarray(np.stack(masks))
         ptr = e.dev_alloc(stack.nbytes)
@@ -1061,7 +1123,7 @@ def test_brick_verdicts_on_adversarial_cameras(gpu_device, kw, kind):
     assert np.array_equal(got, want), (kw, kind, "device batch", histogram3(got), histogram3(want))
     # the verdicts below the brick asked of every unit, whatever the heuristics would decide
     got, _ = _device_batch_carve(shape, origin, vs, views, opts=((nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
-                                                                   (nat.SC_OPT_BULK_ADAPT, 0)))
+                                                                   (nat.SC_OPT_BULK_FLOOR, 0)))
     assert np.array_equal(got, want), (kw, kind, "device batch, unit verdicts forced", histogram3(got), histogram3(want))
     got = hip_carve(shape, origin, vs, views)
     assert np.array_equal(got, want), (kw, kind, "host masks")
@@ -1203,7 +1265,7 @@ def test_masks_packed_in_bands(gpu_device, width, height, invert):
     for ride in (1, 0):
         e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
         for k, v in ((nat.SC_OPT_PACK_ROWS, 3), (nat.SC_OPT_PACK_RIDE, ride), (nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
-                     (nat.SC_OPT_BULK_ADAPT, 0)):
+                     (nat.SC_OPT_BULK_FLOOR, 0)):
             e.set_option(k, v)
         stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
         ptr = e.dev_alloc(stack.nbytes)
