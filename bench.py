@@ -81,6 +81,14 @@ def parse():
     ap.add_argument("--e2e-reps", type=int, default=3, help="host masks -> host labels repetitions (0 = skip)")
     ap.add_argument("--strong-steps", type=int, default=20, help="N > 1: steps of the 512^3 grid split over the ranks")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--traffic-passes", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1, fused path: measure roofline.traffic in this invocation -- two short child runs of this "
+                         "script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), started "
+                         "before this process touches the GPU; auto = when rocprofv3 is on PATH and this process is "
+                         "not itself being profiled; off / failure: the committed file is cited instead")
+    ap.add_argument("--cold-reps", type=int, default=2, help="fresh engines timed for cold_first_batch (0 = skip)")
+    ap.add_argument("--scene-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "sc_bench_scene"),
+                    help="prefix of the .npy cache of the synthetic masks (the child passes reuse the parent's)")
     ap.add_argument("--skip-other-path", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option KEY=VALUE (sc_set_option)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -228,6 +236,136 @@ def cpu_baseline(shape, origin, vs, views, budget_s):
                       f"{avail} visible",
             "value_1thread": p1 * plane * V / t1 / 1e6,
             "sample_1thread": f"{p1} central X-planes x {V} views in {t1:.2f} s, 1 thread"}
+
+
+def cached_scene(a, scenes, shape):
+    """The synthetic scene of the run; its masks (the costly part: 72 splatted silhouettes) are kept as one .npy under
+    --scene-cache so that the traffic child passes do not rebuild them."""
+    key = "%s_%dx%dx%d_%d_%s.npy" % (a.scene_cache, shape[0], shape[1], shape[2], a.views, a.scene)
+    if os.path.exists(key):
+        try:
+            stack = np.load(key)
+            gshape, origin, vs, poses, _, _ = scenes.scene_poses(tuple(shape), a.views, a.scene)
+            if stack.shape == (a.views, scenes.HEIGHT, scenes.WIDTH) and stack.dtype == np.uint8:
+                return gshape, origin, vs, [(K, R, t, stack[q]) for q, (K, R, t) in enumerate(poses)]
+        except Exception:
+            pass
+    gshape, origin, vs, views = scenes.make_scene(tuple(shape), a.views, a.scene)
+    try:
+        tmp = key + ".%d.tmp.npy" % os.getpid()
+        np.save(tmp, np.stack([m for _, _, _, m in views]))
+        os.replace(tmp, key)
+    except Exception:
+        pass
+    return gshape, origin, vs, views
+
+
+def traffic_passes(a):
+    """roofline.traffic measured by THIS invocation: two short child runs of this script under rocprofv3, one per PMC
+    counter (separate passes, kernel trace only beside them -- /opt/skills/guides/MI355X_MICROARCH.md, HBM), started
+    before this process initialises the GPU.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE counts the
+    wide (16 B per lane) streaming reads of the pack kernel at half their bytes on gfx950 (x2 there; the riders'
+    reads inside carve_brick_kernel stay raw: the sum understates a batch by <= 50 MB).  Returns a dict or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = {"per_kernel": {}, "source": "this run: child passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` of "
+                                       "bench.py --steps 3 --warmup 1 (same box, same process tree)"}
+    work = tempfile.mkdtemp(prefix="sc_traffic_", dir=os.environ.get("TMPDIR", "/tmp"))
+    sums = {}
+    batches = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                   "--cpu-seconds", "0", "--extra-steps", "0", "--e2e-reps", "0", "--skip-other-path", "--cold-reps", "0",
+                   "--traffic-passes", "off", "--n", str(a.n), "--views", str(a.views), "--scene", a.scene,
+                   "--scene-cache", a.scene_cache]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run(cmd, cwd=env["TMPDIR"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name", counter) != counter:
+                        continue
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                    per.setdefault(name, []).append(float(row["Counter_Value"]))
+            nb = len(per.get("carve_list_kernel<true, 2>", []) or per.get("carve_special_kernel", []))
+            if nb == 0:
+                return None
+            batches[counter] = nb
+            for name, vals in per.items():
+                if name.startswith("fill_kernel") or name.startswith("__amd") or "selftest" in name:
+                    continue
+                corr = 2.0 if (counter == "FETCH_SIZE" and name.startswith("pack")) else 1.0
+                b = sum(vals) * 1024.0 * corr / nb
+                sums[counter] = sums.get(counter, 0.0) + b
+                out["per_kernel"].setdefault(name, {})[counter + "_bytes_per_batch"] = b
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    if "FETCH_SIZE" not in sums or "WRITE_SIZE" not in sums:
+        return None
+    out["hbm_bytes_per_launch"] = sums["FETCH_SIZE"] + sums["WRITE_SIZE"]
+    out["read_bytes"] = sums["FETCH_SIZE"]
+    out["write_bytes"] = sums["WRITE_SIZE"]
+    out["batches_per_pass"] = batches
+    return out
+
+
+def cold_first_batch(a, nat, shape, origin, vs, call, device, reps):
+    """What a Voxels run pays (tasks/cl.py:162-165 of the reference: ONE batch on a fresh engine): sc_create -> the
+    72 resident masks enqueued -> flush -> synchronize, the engine's one-off allocations (label volume, survivor
+    lists, control block, packed-mask arena) and every kernel of the batch included; host clock.  The same engine's
+    second batch beside it (clear + batch + synchronize, host clock): what is left when nothing is allocated."""
+    K, R, t, masks_dev, V, H, W = call
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        eng = nat.Engine(list(shape), origin, vs, nat.SC_MODE_CARVE, device=device)
+        t1 = time.perf_counter()
+        eng.process_views_device(K, R, t, masks_dev, V, H, W, nat.SC_MASK_U8)
+        eng.flush()
+        t2 = time.perf_counter()
+        eng.synchronize()
+        t3 = time.perf_counter()
+        eng.clear()
+        eng.process_views_device(K, R, t, masks_dev, V, H, W, nat.SC_MASK_U8)
+        eng.flush()
+        eng.synchronize()
+        t4 = time.perf_counter()
+        # device time of a first batch by itself: a third batch with an event pair around every kernel
+        eng.set_option(nat.SC_OPT_TIME_KERNELS, 1)
+        eng.clear()
+        eng.process_views_device(K, R, t, masks_dev, V, H, W, nat.SC_MASK_U8)
+        eng.flush()
+        eng.synchronize()
+        ksum = 0.0
+        for kid in (nat.SC_KERNEL_PACK, nat.SC_KERNEL_FLAGS, nat.SC_KERNEL_CARVE, nat.SC_KERNEL_LIST):
+            _, ms = eng.kernel_stats(kid)
+            ksum += ms
+        eng.close()
+        runs.append({"total_ms": (t3 - t0) * 1e3, "create_ms": (t1 - t0) * 1e3, "enqueue_ms": (t2 - t1) * 1e3,
+                     "wait_ms": (t3 - t2) * 1e3, "second_batch_ms": (t4 - t3) * 1e3, "kernels_ms": ksum})
+    best = min(runs, key=lambda r: r["total_ms"])
+    return {"cold_first_batch_ms": best["total_ms"], "breakdown": best, "all_total_ms": [r["total_ms"] for r in runs],
+            "note": "fresh sc_create -> 72 resident masks enqueued -> flush -> synchronize, host clock, best of %d; "
+                    "create_ms = the 512 MiB label volume and a stream; enqueue_ms = the engine's one-off allocations "
+                    "(survivor lists, control block, packed-mask arena) interleaved with its launches; wait_ms = what "
+                    "was left of the device work when the host was through; second_batch_ms = clear + the same batch "
+                    "+ synchronize on that engine; kernels_ms = HIP events around every kernel of a batch (the bulk "
+                    "decision is taken on the device inside each batch: a first batch runs the kernels of every "
+                    "later one)" % reps}
 
 
 def host_timed(engine, torch, fn, steps, warmup=1, runs=3):
@@ -483,11 +621,12 @@ def e2e_host(a, shape, origin, vs, views, device, reps):
     bp.close()
     n = int(np.prod(shape))
     best = min(ts)
-    return {"ms": best * 1e3, "ms_all": [x * 1e3 for x in ts], "value": n * V / best / 1e6, "unit": "Mvoxel*views/s",
-            "reps": reps, "labels_histogram": hist,
+    med = float(np.median(ts))
+    return {"ms": med * 1e3, "ms_best": best * 1e3, "ms_all": [x * 1e3 for x in ts], "value": n * V / med / 1e6,
+            "unit": "Mvoxel*views/s", "reps": reps, "labels_histogram": hist, "ms_is": "median of ms_all",
             "note": f"{V} uint8 masks in host memory -> Backprojection.process_view x {V} -> get_values(): int32 "
                     f"[{shape[0]}][{shape[1]}][{shape[2]}] in host memory; PCIe both ways (labels cross at 2 bits "
-                    f"each, in pieces, and are widened by host threads inside the library as they land); best of {reps}"}
+                    f"each, in pieces, and are widened by host threads inside the library as they land); median of {reps}"}
 
 
 def main():
@@ -500,6 +639,17 @@ def main():
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         a.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # roofline.traffic measured in this invocation: child passes under rocprofv3, BEFORE this process touches the GPU
+    # (a GPU-initialised process must not start other programs on these boxes)
+    live_traffic = None
+    profiled = any(k in os.environ for k in ("ROCPROFILER_TOOL_LIBRARIES", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
+        "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and rank == 0 and a.path == "fused" and not a.rccl_rehearsal and \
+            (a.traffic_passes == "on" or (a.traffic_passes == "auto" and not profiled)):
+        sys.path.insert(0, ROOT)
+        from plant3dvision_amd import scenes as _scenes
+        cached_scene(a, _scenes, global_shape(a.n, 1))  # built once, the children load it
+        live_traffic = traffic_passes(a)
     # ONE JSON line on stdout: RCCL prints a version banner to stdout when its communicator comes up, so
     # everything but that line (libraries included, file descriptor 1) goes to stderr from here on
     sys.stdout.flush()
@@ -525,7 +675,7 @@ def main():
     from plant3dvision_amd.sharded import ShardedBackprojection
 
     shape = global_shape(a.n, world)
-    gshape, origin, vs, views = scenes.make_scene(tuple(shape), a.views, a.scene)
+    gshape, origin, vs, views = cached_scene(a, scenes, shape) if world == 1 else scenes.make_scene(tuple(shape), a.views, a.scene)
     V = len(views)
     H, W = views[0][3].shape
     sb = ShardedBackprojection(gshape, origin, vs, rank=rank, world_size=world, device=local_rank)
@@ -548,6 +698,34 @@ def main():
     other = "stream" if a.path == "fused" else "fused"
     if a.path == "stream":
         eng.set_option(nat.SC_OPT_VIEW_BRICK, 0)  # the streaming kernel, not the brick form of a one-view launch
+    # The other schedules run FIRST: a rocprofv3 trace of a long run (profiles/r04_clock_ramp.txt) shows every
+    # kernel of the batch ~6 % slower during the first ~15 ms of device activity after an idle spell (scene
+    # building on the host) than in the sustained state; the headline's W warm-up + K timed steps follow these
+    # legs' device work, so `value` is the sustained rate whatever K is.  (--skip-other-path: no such lead-in.)
+    t_legs0 = time.perf_counter()
+    res_other = per_view = None
+    eng.set_option(nat.SC_OPT_VIEW_BRICK, 0)  # "stream" is the streaming kernel: every view reads the whole state
+    if not a.skip_other_path:
+        osteps = max(4, a.steps // 4) if other == "stream" else a.steps
+        run_steps(eng, nat, *call, 1, vpl[other])
+        eng.synchronize()
+        dto, statso = timed(eng, nat, torch, dist, call, osteps, vpl[other], world)
+        res_other = (dto, statso, osteps)
+        # the same cadence (one launch per view) in its brick form: dead bricks are skipped
+        eng.set_option(nat.SC_OPT_VIEW_BRICK, 1)
+        psteps = max(2, a.steps // 4)
+        run_steps(eng, nat, *call, 1, 1)
+        eng.synchronize()
+        dtp, _ = timed(eng, nat, torch, dist, call, psteps, 1, world)
+        _, pvk = timed(eng, nat, torch, dist, call, 2, 1, world, time_kernels=1)  # events around every kernel
+        per_view = {"value": n_total * V * psteps / dtp / 1e6, "unit": "Mvoxel*views/s", "steps": psteps,
+                    "ms_per_step": dtp / psteps * 1e3, "launches_per_step": 2 * V,
+                    "device_ms_per_step": sum(pvk[k]["total_ms"] for k in ("carve", "flags", "pack", "fill")) / 2,
+                    "note": "one launch (+ its verdict kernel) per view, the reference's cadence cl.py:223-226, brick "
+                            "verdicts and dead-brick skipping (SC_OPT_VIEW_BRICK 1, the default)"}
+    eng.set_option(nat.SC_OPT_VIEW_BRICK, 0 if a.path == "stream" else 1)
+    t_device_before = time.perf_counter() - t_legs0
+
     # warmup (untimed), in the timing mode of the timed steps: the first batches with event pairs create
     # their HIP events (tens of microseconds each), which is warm-up work, not a step's
     eng.set_option(nat.SC_OPT_TIME_KERNELS, 2)
@@ -568,28 +746,6 @@ def main():
         live, s0, s1n, ovf = eng.fused_counts()
         breakdown["fused_counts"] = {"live_bricks": live, "alive_after_dense_stage": s0,
                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}
-    res_other = per_view = None
-    eng.set_option(nat.SC_OPT_VIEW_BRICK, 0)  # "stream" is the streaming kernel: every view reads the whole state
-    if not a.skip_other_path:
-        osteps = max(2, a.steps // 4) if other == "stream" else a.steps
-        run_steps(eng, nat, *call, 1, vpl[other])
-        eng.synchronize()
-        dto, statso = timed(eng, nat, torch, dist, call, osteps, vpl[other], world)
-        res_other = (dto, statso, osteps)
-        # the same cadence (one launch per view) in its brick form: dead bricks are skipped
-        eng.set_option(nat.SC_OPT_VIEW_BRICK, 1)
-        psteps = max(2, a.steps // 4)
-        run_steps(eng, nat, *call, 1, 1)
-        eng.synchronize()
-        dtp, _ = timed(eng, nat, torch, dist, call, psteps, 1, world)
-        _, pvk = timed(eng, nat, torch, dist, call, 2, 1, world, time_kernels=1)  # events around every kernel
-        per_view = {"value": n_total * V * psteps / dtp / 1e6, "unit": "Mvoxel*views/s", "steps": psteps,
-                    "ms_per_step": dtp / psteps * 1e3, "launches_per_step": 2 * V,
-                    "device_ms_per_step": sum(pvk[k]["total_ms"] for k in ("carve", "flags", "pack", "fill")) / 2,
-                    "note": "one launch (+ its verdict kernel) per view, the reference's cadence cl.py:223-226, brick "
-                            "verdicts and dead-brick skipping (SC_OPT_VIEW_BRICK 1, the default)"}
-    eng.set_option(nat.SC_OPT_VIEW_BRICK, 1)
-
     # N > 1: carve + assembly, always (t_device + collective)
     asm = None
     if collective and a.assembly_steps > 0:
@@ -607,6 +763,10 @@ def main():
         extras = extra_scenes(a, nat, torch, eng, gshape, masks_dev, a.extra_steps)
         eng.dev_upload(masks_dev, stack)
         avg = average_forms(a, nat, torch, gshape, origin, vs, views, local_rank, max(2, a.extra_steps // 2))
+
+    cold = None
+    if world == 1 and not a.rccl_rehearsal and a.cold_reps > 0 and a.path == "fused":
+        cold = cold_first_batch(a, nat, gshape, origin, vs, call, local_rank, a.cold_reps)
 
     # another assembly on request, once
     gather = None
@@ -632,7 +792,7 @@ def main():
     b_alg_per_vv = (4.0 * n_local * V + 4.0 * n_local + V * W * H) / (n_local * V)
     mask_bits_bytes = ((W + 31) // 32) * ((H + 31) // 32) * 128
 
-    def roof(path, st, traffic):
+    def roof(path, st, traffic, traffic_src=None):
         if path == "fused":
             # One "launch" of the fused schedule is the whole batch: pack16 -> brick_flags ->
             # carve_brick -> carve_list<false> -> carve_list<true> (-> resume).  The timed steps are
@@ -658,8 +818,8 @@ def main():
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-             "traffic_source": (os.path.relpath(a.traffic_json, ROOT) + " (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                "passes, tools/profile_gpu.sh; not measured in this run)") if traffic is not None else None,
+             "traffic_source": (traffic_src or (os.path.relpath(a.traffic_json, ROOT) + " (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                "passes, tools/profile_gpu.sh; not measured in this run)")) if traffic is not None else None,
              "kernel": kernel,
              "avg_launch_ms": avg_ms, "launches": launches,
              "algorithmic_bytes_per_launch": bytes_launch, "bytes_model": model,
@@ -702,10 +862,22 @@ def main():
                                       f"{a.n}^3 grid over the ranks",
                        "path": a.path, "views_per_launch": V if a.path == "fused" else 1,
                        "arithmetic": "float32 projection (no contraction, correctly rounded divide) into int32 labels"},
-            "roofline": roof(a.path, stats, traffic_for(a.path)),
+            "roofline": (roof(a.path, stats, live_traffic["hbm_bytes_per_launch"], live_traffic["source"])
+                         if live_traffic is not None and world == 1 and list(sb.slab_shape) == [a.n, a.n, a.n]
+                         else roof(a.path, stats, traffic_for(a.path))),
             "kernels": {k: stats[k] for k in ("carve", "step") if stats[k]["launches"]},
             "kernels_breakdown_pass": breakdown,
         }
+        if live_traffic is not None:
+            out["roofline"]["traffic_read_bytes"] = live_traffic["read_bytes"]
+            out["roofline"]["traffic_write_bytes"] = live_traffic["write_bytes"]
+            out["roofline"]["traffic_per_kernel"] = live_traffic["per_kernel"]
+        out["lead_in"] = {"seconds_of_other_legs_before_warmup": t_device_before,
+                          "note": "stream + per_view legs run before the headline's warm-up (sustained device state); "
+                                  "0 with --skip-other-path"}
+        if cold is not None:
+            out["cold_first_batch_ms"] = cold["cold_first_batch_ms"]
+            out["cold_first_batch"] = cold
         if res_other is not None:
             dto, statso, osteps = res_other
             out[other] = {"value": n_total * V * osteps / dto / 1e6, "unit": "Mvoxel*views/s",

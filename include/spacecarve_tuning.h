@@ -60,9 +60,11 @@
                                      unit x up to 16 views each) when those cost at most this share of what its voxels
                                      would cost in the survivor lists; otherwise the voxels take the lists        */
 #define SC_OPT_UNIT_BLOCKS 34     /* blocks of 8 wavefronts giving the units their verdicts (512)                  */
-#define SC_OPT_BULK_FLOOR 35      /* bulk units a batch must have for their verdicts to be asked (2048): with fewer the
-                                     verdict rounds are a latency chain nothing amortises (a thin plant has a few dozen
-                                     bulky units) and the units' voxels join the first survivor list as they are.
+#define SC_OPT_BULK_FLOOR 35      /* bulk units a batch must have for their verdicts to be asked (8192 = two rounds of the
+                                     special kernel's wavefronts): with fewer the verdict rounds are a latency chain
+                                     nothing amortises (the bench's thin plant has 3 268 such units and their verdicts
+                                     settle next to nothing; a bulky object 18 000 - 56 000) and the first survivor
+                                     stage takes the units' voxels as they are.
                                      Decided on the device, inside the batch, from the count its own dense stage left:
                                      the first batch of an engine runs like every later one.  0: always asked        */
 #define SC_OPT_BULK_ADAPT SC_OPT_BULK_FLOOR /* deprecated name of key 35 (rounds 3: 0 = always on, which 0 still means) */

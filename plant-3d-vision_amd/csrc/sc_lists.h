@@ -12,6 +12,16 @@ struct UnitItems {
     uint32_t bricks_y, bricks_z;
 };
 
+// Bulk units of a batch that has too few of them for their verdicts to be asked (fewer than `floor`, see
+// carve_special_kernel): the FIRST survivor stage takes them as they are -- a unit's 256 voxels as chunks of its
+// own, the labels read where a list chunk reads its entries -- and appends what is left alive to its output list
+// like any other survivor.  Nobody copies them anywhere in between.
+struct UnitSpill {
+    const uint32_t *units;  // null: no bulk list.  [kSub][cap] unit ids, counts in ctl->count[3]
+    uint32_t cap, floor;
+    uint32_t bricks_y, bricks_z;
+};
+
 // Fused carve, sparse phase: one lane per SURVIVOR.  Reads the survivor sub-lists a previous
 // stage appended and applies views with every lane busy, two views per iteration (two
 // independent projection chains and two gathers in flight per lane).  A persistent grid of
@@ -33,7 +43,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                             const uint32_t *__restrict__ lin,
                                                             uint32_t *__restrict__ lout,
                                                             ListCtl *ctl, int sin, int sout,
-                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui) {
+                                                            uint32_t subcap, int vgsize, CullStores cs, UnitItems ui,
+                                                            UnitSpill us, int nrest) {  // nrest: views from `views` to the batch's last
     __shared__ uint32_t pref[kSub + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t bx = blockIdx.x, gdim = gridDim.x;
@@ -70,8 +81,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     const uint32_t chunks = pref[kSub];
     const uint32_t lane = tid & 63u;
-    __shared__ uint32_t ipref[FINAL ? kSub + 1 : 1];
+    __shared__ uint32_t ipref[kSub + 1];  // FINAL: the work items' prefix; else: the spilled bulk units'
     const bool with_items = FINAL && ui.items != nullptr;  // grid-uniform
+    uint32_t uchunks = 0;  // chunks made of spilled bulk units, behind the list's own
+    constexpr uint32_t kUnitParts = 256u / (64u * P);  // chunks per unit
+    if (!FINAL && us.units != nullptr) {  // grid-uniform
+        const uint32_t c = min(ctl->count[3][tid].n, us.cap);
+        if (tid == 0) ipref[0] = 0;
+        ipref[tid + 1] = c;
+        __syncthreads();
+        for (uint32_t off = 1; off < kSub; off <<= 1) {
+            const uint32_t val = ipref[tid + 1];
+            const uint32_t add = (tid >= off) ? ipref[tid + 1 - off] : 0u;
+            __syncthreads();
+            ipref[tid + 1] = val + add;
+            __syncthreads();
+        }
+        if (ipref[kSub] < us.floor) uchunks = ipref[kSub] * kUnitParts;  // (else the special kernel has dealt with them)
+    }
     if (with_items) {
         const uint32_t c = min(ctl->count[4][tid].n, ui.cap);
         if (tid == 0) ipref[0] = 0;
@@ -95,7 +122,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     // others), and a span crosses a chunk boundary once or twice, so the decode of the entries is
     // paid once or twice per wavefront.  `vgsize` only rounds the span length.
     // Not FINAL: an item is a chunk and all the views, dealt round-robin.
-    const uint64_t total = FINAL ? (uint64_t)chunks * (uint32_t)nviews : (uint64_t)chunks;
+    const uint64_t total = FINAL ? (uint64_t)chunks * (uint32_t)nviews : (uint64_t)chunks + uchunks;
     uint64_t per = 1;
     if (FINAL) {
         per = (total + nworkers - 1) / nworkers;
@@ -119,10 +146,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             v1 = nviews;
             pos += nworkers;
         }
-        uint32_t lo = 0, hi = kSub;  // largest s with pref[s] <= c (wave-uniform)
+        const bool from_unit = !FINAL && c >= chunks;  // wave-uniform: a chunk of a spilled bulk unit
+        const uint32_t *pf = from_unit ? ipref : pref;
+        const uint32_t key = from_unit ? (c - chunks) / kUnitParts : c;
+        uint32_t lo = 0, hi = kSub;  // largest s with pf[s] <= key (wave-uniform)
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
-            if (pref[mid] <= c) lo = mid; else hi = mid;
+            if (pf[mid] <= key) lo = mid; else hi = mid;
         }
         const uint32_t s = lo;
         const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
@@ -131,14 +161,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         uint32_t idx[P];
         bool zero[P], flipped[P], alive[P];
         float x[P], y[P], z[P];
+        uint32_t unit = 0, upart = 0;
+        if (from_unit) {
+            unit = __builtin_amdgcn_readfirstlane(us.units[(size_t)s * us.cap + (key - ipref[s])]);
+            upart = (c - chunks) % kUnitParts;
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const uint32_t e = (c - pref[s]) * CH + (uint32_t)p * 64u + lane;
-            alive[p] = e < cnt;
-            uint32_t entry = 0;
-            if (alive[p]) entry = lin[(size_t)s * subcap + e];
-            idx[p] = entry & 0x7fffffffu;
-            zero[p] = (entry >> 31) != 0;  // label is still 0
+            if (from_unit) {
+                // voxel v of the unit (16 columns x 16 voxels of brick unit >> 2, its z quarter unit & 3): column v >> 4
+                const uint32_t v = upart * CH + (uint32_t)p * 64u + lane;
+                const uint32_t lb = unit >> 2, per_plane = us.bricks_y * us.bricks_z;
+                const uint32_t il = lb / per_plane, rem = lb - il * per_plane;
+                const uint32_t by = rem / us.bricks_z, bz = rem - by * us.bricks_z;
+                const uint32_t j = by * kBrickY + (v >> 4), k = bz * kBrickZ + (unit & 3u) * 16u + (v & 15u);
+                const bool inside = j < g.ny && k < g.nz;
+                idx[p] = inside ? (il * g.ny + j) * g.nzp + k : 0u;
+                int32_t lab = -1;
+                if (inside) lab = labels[idx[p]];
+                alive[p] = lab != -1;   // backprojection.c:67
+                zero[p] = lab == 0;
+            } else {
+                const uint32_t e = (c - pref[s]) * CH + (uint32_t)p * 64u + lane;
+                alive[p] = e < cnt;
+                uint32_t entry = 0;
+                if (alive[p]) entry = lin[(size_t)s * subcap + e];
+                idx[p] = entry & 0x7fffffffu;
+                zero[p] = (entry >> 31) != 0;  // label is still 0
+            }
             flipped[p] = false;
             const uint32_t col = idx[p] / g.nzp;  // entries index the padded rows
             const uint32_t k = idx[p] - col * g.nzp;
@@ -151,6 +201,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         // U views per iteration.  The final stage is bound by arithmetic (U = 2); the stages before
         // it wait on memory and most of their voxels die within a few views (U = 4).
         constexpr int U = P >= 4 ? 1 : (FINAL ? 2 : 4);
+        for (;;) {  // (once; a second time over the views behind this stage's for a chunk whose survivors find no room)
         for (int vi = v0; vi < v1; vi += U) {
             bool any = false;
 #pragma unroll
@@ -197,23 +248,43 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 }
             }
         }
-        if (!FINAL) {
+        if (FINAL) break;
+        bool noroom = false;
+        if (v1 < nrest) {  // views behind this stage: what is still alive goes on the output list
+            unsigned long long b[P];
+            uint32_t tot = 0;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                if (alive[p] && flipped[p]) labels[idx[p]] = 1;
-                unsigned long long b = __ballot(alive[p]);
-                if (b != 0) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&ctl->count[sout][s].n, (uint32_t)__popcll(b));
-                    base = __shfl(base, 0);
-                    // survivors of sub-list s never outnumber its entries: no overflow here
-                    if (alive[p]) {
-                        unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                        lout[(size_t)s * subcap + base + (uint32_t)__popcll(b & below)] =
-                            idx[p] | (zero[p] ? 0x80000000u : 0u);
+                b[p] = __ballot(alive[p]);
+                tot += (uint32_t)__popcll(b[p]);
+            }
+            if (tot != 0) {  // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctl->count[sout][s].n, tot);
+                base = __shfl(base, 0);
+                // The survivors of sub-list s do not outnumber its entries, but spilled bulk units append here too:
+                // without room (the count stays beyond the capacity, the readers clamp it) this wavefront takes its
+                // chunk through the remaining views itself -- these voxels are on no list, nobody else touches them
+                noroom = base + tot > subcap;
+                if (!noroom) {
+                    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        if (alive[p])
+                            lout[(size_t)s * subcap + base + (uint32_t)__popcll(b[p] & below)] = idx[p] | (zero[p] ? 0x80000000u : 0u);
+                        base += (uint32_t)__popcll(b[p]);
                     }
                 }
             }
+        }
+        if (!noroom) break;
+        v0 = v1;
+        v1 = nrest;
+        }
+        if (!FINAL) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (alive[p] && flipped[p]) labels[idx[p]] = 1;
         }
     }
     if (with_items) {
@@ -412,12 +483,12 @@ struct UnitJob {
     uint32_t *list;           // the first survivor list and the room of its sub-lists (counts in ctl->count[0])
     uint32_t subcap;
     uint32_t bias;            // items are chosen when their turns * 16 <= bias * the turns the lists would take
-    uint32_t floor;           // fewer bulk units than this in the whole batch: no verdicts, their voxels join the first
-                              // survivor list as they are (see carve_special_kernel)
+    uint32_t floor;           // fewer bulk units than this in the whole batch: no verdicts, the first survivor stage
+                              // takes their voxels as they are (see carve_special_kernel, UnitSpill)
 };
 
 __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
-                                              uint32_t sub, uint32_t lane, bool ask) {
+                                              uint32_t sub, uint32_t lane) {
     const uint32_t lb = unit >> 2, w = unit & 3u;
     const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
     const uint32_t il = lb / per_plane;
@@ -444,7 +515,7 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
     unsigned long long need[2] = {0ull, 0ull};
     bool seen = false, empty = false;
-    for (int h = 0; ask && h < 2 && h * 64 < uj.nall; ++h) {  // (ask: wave-uniform)
+    for (int h = 0; h < 2 && h * 64 < uj.nall; ++h) {
         const int vi = h * 64 + (int)lane;
         uint32_t v = 8u;  // no such view, or one the dense stage has applied
         if (vi < uj.nall && vi >= uj.ndense) {
@@ -477,7 +548,7 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     }
     const uint32_t nneed = (uint32_t)__popcll(need[0]) + (uint32_t)__popcll(need[1]);
     const unsigned long long anyalive = __ballot(alive != 0);
-    if (anyalive == 0 || (ask && nneed == 0)) return;  // wave-uniform: the labels are final
+    if (anyalive == 0 || nneed == 0) return;  // wave-uniform: the labels are final
     // the undecided views of each 64-view word in pieces of up to 16; one item per (half with something
     // alive, word, piece): lane = piece * 4 + word * 2 + half
     unsigned long long pm[2][4];
@@ -503,7 +574,7 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     // turns of (128 voxels x 2 views): the items' against what the unit's voxels would take in the lists
     const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (ask && item_cost * 16u <= uj.bias * list_cost) {
+    if (item_cost * 16u <= uj.bias * list_cost) {
         uint32_t pos = 0;
         if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
         pos = __shfl(pos, 0);
@@ -540,9 +611,9 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
 //     so no memset sits on the stream;
 //   * the units of the bulk list get their verdicts, one wavefront per unit (unit_verdicts) -- when the batch has
 //     at least `uj.floor` of them: a latency chain of ~7 us per round of wavefronts is not worth a handful of units
-//     (a thin plant has a few dozen), whose voxels then join the first survivor list as they are.  The decision is
-//     taken HERE, from the count the dense stage of this very batch left, so the first batch of a fresh engine
-//     runs exactly like every later one;
+//     (the bench's thin plant has 3 268, a bulky object 18 000 - 56 000), which the first survivor stage then takes as they are (UnitSpill).  The
+//     decision is taken on the DEVICE, here and there alike, from the count the dense stage of this very batch
+//     left, so the first batch of a fresh engine runs exactly like every later one;
 //   * LATE bricks (FULL candidates some later view did not keep whole after all) are carved unit by unit over every
 //     view of the batch (late_unit);
 //   * when a survivor sub-list overflowed in the dense stage (masks that carve little), the views it has not
@@ -570,29 +641,40 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
     const bool overflow = ctl->overflow != 0u;  // written by the dense stage only: the same for every block
     if (sj.uj.units != nullptr && !overflow) {  // grid-uniform
         __shared__ uint32_t upref[kSub + 1];
-        if (tid < kSub) upref[tid + 1] = min(ctl->count[3][tid].n, sj.uj.cap);
-        if (tid == 0) upref[0] = 0;
+        __shared__ uint32_t s_total;
+        const uint32_t mine = tid < kSub ? min(ctl->count[3][tid].n, sj.uj.cap) : 0u;
+        if (tid == 0) s_total = 0u;
         __syncthreads();
-        for (uint32_t off = 1; off < kSub; off <<= 1) {
-            uint32_t val = 0, add = 0;
-            if (tid < kSub) {
-                val = upref[tid + 1];
-                add = (tid >= off) ? upref[tid + 1 - off] : 0u;
-            }
+        uint32_t wsum = mine;
+        for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+        if (lane == 0 && wsum != 0u) atomicAdd(&s_total, wsum);
+        __syncthreads();
+        const uint32_t total = s_total;
+        // Fewer units than the floor: nobody asks, the first survivor stage takes their voxels as they are
+        // (UnitSpill -- it applies the same rule to the same counts).  Grid-uniform.
+        if (total >= sj.uj.floor && total != 0u) {
+            if (tid < kSub) upref[tid + 1] = mine;
+            if (tid == 0) upref[0] = 0;
             __syncthreads();
-            if (tid < kSub) upref[tid + 1] = val + add;
-            __syncthreads();
-        }
-        const uint32_t total = upref[kSub];
-        const bool ask = total >= sj.uj.floor;  // grid-uniform
-        for (uint32_t i = blockIdx.x * kFlagWaves + wave; i < total; i += nworkers) {
-            uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (upref[mid] <= i) lo = mid; else hi = mid;
+            for (uint32_t off = 1; off < kSub; off <<= 1) {
+                uint32_t val = 0, add = 0;
+                if (tid < kSub) {
+                    val = upref[tid + 1];
+                    add = (tid >= off) ? upref[tid + 1 - off] : 0u;
+                }
+                __syncthreads();
+                if (tid < kSub) upref[tid + 1] = val + add;
+                __syncthreads();
             }
-            const uint32_t unit = __builtin_amdgcn_readfirstlane(sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])]);
-            unit_verdicts(sj.uj, g, ctl, unit, lo, lane, ask);
+            for (uint32_t i = blockIdx.x * kFlagWaves + wave; i < total; i += nworkers) {
+                uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (upref[mid] <= i) lo = mid; else hi = mid;
+                }
+                const uint32_t unit = __builtin_amdgcn_readfirstlane(sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])]);
+                unit_verdicts(sj.uj, g, ctl, unit, lo, lane);
+            }
         }
     }
     if (sj.lb.late != nullptr) {

@@ -172,7 +172,7 @@ struct sc_engine {
     int64_t unit_blocks = 512; // blocks of 8 wavefronts walking the bulk list behind the confirm kernel
     // Whether the bulk units' verdicts pay is decided on the device, inside the batch, from the number of units its
     // own dense stage left (carve_special_kernel): fewer than this and their voxels take the ordinary lists
-    int64_t bulk_floor = 2048;
+    int64_t bulk_floor = 8192;
     int64_t list_cap = 0, list_cap_built = 0;  // entries per survivor sub-list (0: sized from the grid); tests of the overflow paths
     uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
     uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
@@ -1126,6 +1126,9 @@ int flush(sc_engine *e, size_t count = 0) {
                 hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kFlagWaves), 0, e->stream, g, vd,
                                    packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
             }
+            // Too few bulk units for their verdicts are taken by the first survivor stage as they are (UnitSpill); a
+            // batch with a single (final) list stage has no such stage: its units are always asked
+            const uint32_t unit_floor = (size_t)ndense + (size_t)nstage1 >= nv ? 0u : (uint32_t)e->bulk_floor;
             {
                 // bulk units, late bricks, the dense fallback, the next batch's counters: one launch, always there
                 // (what it finds to do is decided on the device)
@@ -1133,7 +1136,7 @@ int flush(sc_engine *e, size_t count = 0) {
                 memset(&sj, 0, sizeof sj);
                 if (bulk_on)
                     sj.uj = UnitJob{e->bulk, e->bulkcap, e->items, e->itemcap, vd, (int32_t)nv, ndense, bys, bzs, st,
-                                    e->lists, e->subcap, (uint32_t)e->item_bias, (uint32_t)e->bulk_floor};
+                                    e->lists, e->subcap, (uint32_t)e->item_bias, unit_floor};
                 sj.lb = LateBricks{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
                 sj.next = e->ctl2[e->ctl_idx ^ 1];
                 sj.rest = vd + ndense;
@@ -1174,15 +1177,17 @@ int flush(sc_engine *e, size_t count = 0) {
             uint32_t *nolist = nullptr;
             // the final stage also takes the work items of the bulk units
             const UnitItems noitems{nullptr, 0u, nullptr, 0u, 0u}, ui{bulk_on ? e->items : nullptr, e->itemcap, vd, bys, bzs};
+            // ... the first one the bulk units of a batch that has too few for their verdicts (decided on the device)
+            const UnitSpill nospill{nullptr, 0u, 0u, 0u, 0u}, us{bulk_on ? e->bulk : nullptr, e->bulkcap, unit_floor, bys, bzs};
             if ((size_t)s1 >= nv) {
-                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs, ui);
+                LAUNCH_LIST(true, fgrid, st, g, vd + ndense, s1 - ndense, l0, nolist, e->ctl, 0, 0, e->subcap, vg, cs, ui, nospill, s1 - ndense);
             } else {
-                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1, noitems);
+                LAUNCH_LIST(false, grid1, st, g, vd + ndense, s1 - ndense, l0, l1, e->ctl, 0, 1, e->subcap, vg, cs1, noitems, us, (int)nv - ndense);
                 if (s2 > s1 && (size_t)s2 < nv) {
-                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none, noitems);
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs, ui);
+                    LAUNCH_LIST(false, dim3(list_blocks), st, g, vd + s1, s2 - s1, l1, l0, e->ctl, 1, 2, e->subcap, vg, none, noitems, nospill, (int)nv - s1);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s2, (int)nv - s2, l0, nolist, e->ctl, 2, 2, e->subcap, vg, cs, ui, nospill, (int)nv - s2);
                 } else {
-                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs, ui);
+                    LAUNCH_LIST(true, fgrid, st, g, vd + s1, (int)nv - s1, l1, nolist, e->ctl, 1, 1, e->subcap, vg, cs, ui, nospill, (int)nv - s1);
                 }
             }
 #undef LAUNCH_LIST

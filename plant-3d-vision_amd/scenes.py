@@ -194,6 +194,18 @@ def literal_real_plant_scene(n_views=60, kind="plant", width=WIDTH, height=HEIGH
     return shape, origin, vs, [(K, R, t, m) for (K, R, t), m in zip(poses, masks)]
 
 
+def scene_poses(n, n_views, kind="plant", voxel_size=VOXEL_SIZE, center=CENTER, radius_factor=2.0, tilt_deg=0.0,
+                fx=FX, fy=FY, cx=CX, cy=CY):
+    """Grid and camera ring of ``make_scene`` without the masks: (shape, origin, voxel_size, poses, radius, extent)."""
+    shape, origin = grid_for(n, voxel_size, center)
+    extent = max(shape) * voxel_size
+    if kind == "dense" and radius_factor == 2.0:
+        radius_factor = 1.2  # close cameras: the object fills ~30 % of every picture
+    radius = radius_factor * extent
+    poses = ring_cameras(n_views, center, radius, tilt_deg=tilt_deg, fx=fx, fy=fy, cx=cx, cy=cy)
+    return shape, origin, float(voxel_size), poses, radius, extent
+
+
 def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=VOXEL_SIZE,
                center=CENTER, radius_factor=2.0, tilt_deg=0.0, fx=FX, fy=FY, cx=CX, cy=CY,
                seed=None):
@@ -202,12 +214,8 @@ def make_scene(n, n_views, kind="plant", width=WIDTH, height=HEIGHT, voxel_size=
     Camera ring radius = radius_factor * max(n) * voxel_size at the height of the centre
     (every voxel then projects inside every 1440x1080 image: worst-case work).
     """
-    shape, origin = grid_for(n, voxel_size, center)
-    extent = max(shape) * voxel_size
-    if kind == "dense" and radius_factor == 2.0:
-        radius_factor = 1.2  # close cameras: the object fills ~30 % of every picture
-    radius = radius_factor * extent
-    poses = ring_cameras(n_views, center, radius, tilt_deg=tilt_deg, fx=fx, fy=fy, cx=cx, cy=cy)
+    shape, origin, voxel_size, poses, radius, extent = scene_poses(n, n_views, kind, voxel_size, center, radius_factor,
+                                                                   tilt_deg, fx, fy, cx, cy)
     masks = []
     if kind == "plant":
         # lattice spacing ~1.5 px at the nearest depth -- but never finer than extent / 800 (the

@@ -135,6 +135,25 @@ def test_survivor_list_overflow_takes_the_dense_pass(gpu_device, kind, shape, v,
     e.close()
 
 
+@pytest.mark.parametrize("nviews", [6, 7, 10, 11, 13])
+@pytest.mark.parametrize("kind,shape", [("dense", (9, 32, 192)), ("plant", (12, 48, 128))])
+def test_bulk_units_whatever_the_number_of_list_stages(gpu_device, nviews, kind, shape):
+    """Bulk units below the floor are taken by the FIRST survivor stage as they are; a batch short enough to have
+    only the final stage (<= 10 views) has no such stage and must have its units asked instead."""
+    sh, origin, vs, views = scene(shape, nviews, kind)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    for floor in (None, 0):
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+        e.set_option(nat.SC_OPT_BULK_MIN, 1)
+        if floor is not None:
+            e.set_option(nat.SC_OPT_BULK_FLOOR, floor)
+        ptr = _batch(e, views, False)
+        assert np.array_equal(e.get_values(), want), (nviews, kind, floor, histogram3(want))
+        assert e.fused_counts_ex()["bulk_units"] > 0
+        e.dev_free(ptr)
+        e.close()
+
+
 @pytest.mark.parametrize("kind,shape", [("dense", (9, 32, 192)), ("plant", (12, 48, 128)), ("solid", (6, 32, 128))])
 @pytest.mark.parametrize("floor", [0, 1 << 30])
 def test_bulk_unit_without_room_in_the_lists_is_carved_on_the_spot(gpu_device, kind, shape, floor):
@@ -266,7 +285,9 @@ def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape
     live, s0, s1, overflow = e.fused_counts()
     nbricks = sh[0] * ((sh[1] + 15) // 16) * ((sh[2] + 63) // 64)
     assert 0 <= live <= nbricks
-    assert overflow or s1 <= s0
+    # (bulk units too few to be asked are taken by the first survivor stage as they are: their survivors are on its
+    # output list without ever having been on its input list)
+    assert overflow or s1 <= s0 + 256 * e.fused_counts_ex()["bulk_units"]
     e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
     assert np.array_equal(e.get_values(), want), ("device masks, stored state", opts)
     e.clear()
