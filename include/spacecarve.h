@@ -232,14 +232,20 @@ int64_t sc_packed_bytes(int64_t voxels, int bits);
 int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes);
 int sc_get_values_packed(sc_engine *e, int bits, void *out);
 /* cl.py:229-232 get_values of a carve volume, the fast way round: the labels cross PCIe at 2 bits each, in pieces,
- * and `threads` host threads (<= 0: 8) widen the pieces that have arrived into out[voxels] (int32, the array the
- * reference returns) while the next ones are on their way.  staging: host memory of at least
+ * and the library's host pool (SC_OPT_HOST_THREADS; `threads` is ignored since round 4) widens the pieces that
+ * have arrived into out[voxels] (int32, the array the reference returns) while the next ones are on their way --
+ * streaming stores where out is 32-byte aligned.  staging: host memory of at least
  * sc_packed_bytes(voxels, 2) bytes the call may scribble on (the caller's, so that its pages can be touched ahead).
  * SC_ERR_STATE unless default_value is one of -1, 0, 1 (use sc_get_values / sc_get_values_i8 then). */
 int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads);
-/* Host code only (no device, no engine): the widening sc_get_values_wire2's threads do, by itself -- `voxels` labels
- * at 2 bits each in packed[(voxels + 15) / 16] (the layout above) into out[voxels] on `threads` threads (<= 0: 8). */
+/* Host code only (no device, no engine): the widening sc_get_values_wire2 does, by itself -- `voxels` labels at
+ * 2 bits each in packed[(voxels + 15) / 16] (the layout above) into out[voxels] on the host pool (`threads` ignored). */
 int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int threads);
+/* Host code only: the bit form in which sc_process_view sends a carve mask over PCIe (cl.py:215 + backprojection.c:79:
+ * a pixel counts when it is != 0; SC_MASK_U8_INV / SC_MASK_BOOL_INV: after np.invert, cl.py:300-301) -- row-major,
+ * out[H][(W + 31) / 32] words, pixel u of a row at bit u & 31 of word u >> 5, bits beyond W zero.  mask_dtype: the
+ * carve dtypes (SC_MASK_U8, SC_MASK_I32, SC_MASK_U8_INV, SC_MASK_BOOL_INV); row_stride_bytes 0 = tight rows. */
+int sc_hostpack_bits(const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes, uint32_t *out);
 int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
                      int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes);
 

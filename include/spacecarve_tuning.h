@@ -72,6 +72,12 @@
 #define SC_OPT_LIST_CAP 38        /* entries per survivor sub-list (0, the default: 5/16 of the voxels over the 256 sub-lists).
                                      A small value makes the lists overflow on a small grid: how the tests reach the
                                      overflow paths (the special kernel's dense pass, a bulk unit without room)      */
+#define SC_OPT_HOST_PACK 39       /* 1 (default): a carve mask handed over in HOST memory (sc_process_view) is reduced to
+                                     1 bit per pixel on host threads and crosses PCIe as bits (14 MB for 72 masks of
+                                     1440 x 1080 instead of 112 MB), one copy per flush; 0: the bytes go through the
+                                     page-locked ring and are packed on the device (round 1-3 path)                 */
+#define SC_OPT_HOST_THREADS 40    /* threads of the library's host pool (mask bits, label widening): 0 = default,
+                                     min(8, hardware threads / 2).  Process-wide; before the pool's first use        */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

@@ -41,7 +41,7 @@ SC_OPT_PACK_RIDE, SC_OPT_BRICK_WALKERS, SC_OPT_FILL_BLOCKS, SC_OPT_FINAL_VOXELS 
 SC_OPT_VIEW_BRICK, SC_OPT_AVG_TILE_F32, SC_OPT_STAGE1_VOXELS, SC_OPT_RESERVE_EVENTS = 26, 29, 30, 31
 SC_OPT_BULK_MIN, SC_OPT_ITEM_BIAS, SC_OPT_UNIT_BLOCKS, SC_OPT_BULK_FLOOR = 32, 33, 34, 35
 SC_OPT_BULK_ADAPT = SC_OPT_BULK_FLOOR  # deprecated name of key 35 (0 still means: the units are always asked)
-SC_OPT_UNIT_CULL, SC_OPT_LIST_CAP = 37, 38
+SC_OPT_UNIT_CULL, SC_OPT_LIST_CAP, SC_OPT_HOST_PACK, SC_OPT_HOST_THREADS = 37, 38, 39, 40
 
 # name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
 _SIGNATURES = {
@@ -73,6 +73,7 @@ _SIGNATURES = {
     "sc_get_values_packed": ("i", ["p", "i", "p"]),
     "sc_get_values_wire2": ("i", ["p", "p", "p", "q", "i"]),
     "sc_widen_labels2": ("i", ["p", "q", "p", "i"]),
+    "sc_hostpack_bits": ("i", ["p", "i", "i", "i", "q", "p"]),
     "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
@@ -406,6 +407,27 @@ def pose_records(entries):
         if shape is not None:
             i[q, 22:25] = [int(x) for x in shape]
     return rec
+
+
+def hostpack_bits(mask, dtype_code=None):
+    """``sc_hostpack_bits``: the bit form in which a carve mask handed to ``process_view`` crosses PCIe -- uint32
+    ``[H][(W + 31) // 32]``, pixel ``u`` of a row at bit ``u & 31`` of word ``u >> 5`` (host code, no device needed)."""
+    mask = np.asarray(mask)
+    if mask.ndim != 2:
+        raise ValueError("mask must be 2-D")
+    if dtype_code is None:
+        dtype_code = SC_MASK_I32 if mask.dtype == np.int32 else SC_MASK_U8
+    want = np.int32 if dtype_code == SC_MASK_I32 else np.uint8
+    if mask.dtype == np.bool_ and want is np.uint8:
+        mask = mask.view(np.uint8)
+    if mask.dtype != want or mask.strides[1] != mask.itemsize:
+        mask = np.ascontiguousarray(mask, dtype=want)
+    H, W = mask.shape
+    out = np.empty((H, (W + 31) // 32), dtype=np.uint32)
+    # (rows may be padded -- a view of a wider array: the row stride goes along)
+    check(backend().call("sc_hostpack_bits", int(mask.ctypes.data), H, W, int(dtype_code), int(mask.strides[0]), addr(out)),
+          "sc_hostpack_bits")
+    return out
 
 
 def png_decode_gray8(raw):

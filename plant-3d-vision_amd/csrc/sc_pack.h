@@ -181,3 +181,56 @@ __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
 }
 
 __global__ __launch_bounds__(kBlock) void pack_band_kernel(PackJob pj) { pack_band_block(pj, blockIdx.x); }
+
+// Masks that arrive from the HOST cross PCIe as bits already (hostpack.h: `pixel != 0` after the optional invert, on
+// host threads, row-major, one word per 32 pixels, 0 beyond the picture).  What is left for the device is a pass over
+// those bits: the words into the 32x32-tile order the carve kernels gather from, and per tile its occupancy byte and
+// the 4x4 map of its 8x8-pixel cells (see ViewDesc) -- the same three products the byte packers above make.
+// One record per view, in a table that travels with the bits; a wavefront takes two tiles (lane = tile half * 32 + row).
+struct BitsRec {
+    uint64_t src_off;  // of the view's bit rows in the arena
+    uint32_t *tiles;
+    uint8_t *occ;
+    uint32_t *cmask;   // may be null
+    int32_t W, H, tiles_x, tiles_y;
+    uint64_t pad;
+};
+static_assert(sizeof(BitsRec) == 56, "BitsRec layout");
+
+__global__ __launch_bounds__(kBlock) void bits_tiles_kernel(const char *__restrict__ arena, uint64_t table_off) {
+    const BitsRec rec = reinterpret_cast<const BitsRec *>(arena + table_off)[blockIdx.y];  // block-uniform: scalar loads
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pair = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ntiles = (uint32_t)rec.tiles_x * (uint32_t)rec.tiles_y;
+    if (pair * 2u >= ntiles) return;  // wave-uniform
+    const uint32_t t = pair * 2u + (lane >> 5), r = lane & 31u;
+    const bool have = t < ntiles;
+    const uint32_t ty = t / (uint32_t)rec.tiles_x, tx = t - ty * (uint32_t)rec.tiles_x;
+    const uint32_t v = ty * 32u + r;
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>(arena + rec.src_off);
+    uint32_t word = 0u;
+    if (have && v < (uint32_t)rec.H) word = bits[(size_t)v * (uint32_t)rec.tiles_x + tx];
+    if (have) rec.tiles[(size_t)t * 32u + r] = word;
+    // cells: row of cells r >> 3, column of cells = the byte of the word
+    unsigned long long anyf[4], anyb[4];
+#pragma unroll
+    for (int cx = 0; cx < 4; ++cx) {
+        const uint32_t byte = (word >> (8 * cx)) & 0xffu;
+        anyf[cx] = __ballot(byte != 0u);
+        anyb[cx] = __ballot(byte != 0xffu);  // padding is background: a tile over the picture's edge is never FULL
+    }
+    if (r == 0u && have) {
+        const uint32_t sh = lane;  // 0 or 32: this tile's 32 rows in the ballots
+        uint32_t cm = 0u;
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 4; ++cx) {
+                const uint32_t f = (uint32_t)((anyf[cx] >> (sh + 8u * cy)) & 0xffull), b = (uint32_t)((anyb[cx] >> (sh + 8u * cy)) & 0xffull);
+                cm |= (f ? 1u : 0u) << (cy * 4 + cx);
+                cm |= (b ? 1u : 0u) << (16 + cy * 4 + cx);
+            }
+        rec.occ[t] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+        if (rec.cmask != nullptr) rec.cmask[t] = cm;
+    }
+}

@@ -47,6 +47,7 @@
 #include <thread>
 #include <vector>
 
+#include "hostpack.h"
 #include "spacecarve.h"
 #include "spacecarve_tuning.h"
 
@@ -190,6 +191,18 @@ struct sc_engine {
     uint32_t *lists = nullptr;  // 2 x (kSub * subcap) entries
     ListCtl *ctl = nullptr;
     uint32_t subcap = 0;
+
+    // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
+    // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
+    int64_t host_pack = 1;
+    struct HostBits {
+        char *pin = nullptr, *dev = nullptr;
+        size_t cap = 0, used = 0;
+        hipEvent_t ev = nullptr;  // the last copy out of `pin` has completed
+        bool armed = false;
+    } hb[2];
+    int hb_cur = 0;
+    std::vector<BitsRec> hp_pending;  // host-packed views not uploaded yet (all of them are among `pending`)
 
     // host-mask staging ring
     void *pin[kSlots] = {nullptr, nullptr, nullptr, nullptr};
@@ -830,6 +843,120 @@ int materialize_deferred(sc_engine *e) {
     return lt.end();
 }
 
+// Room for `bytes` more in the current host arena (page-locked memory + its device mirror).  An arena whose last copy
+// may still be in flight is waited for before it is written again; one that is too small grows (what it holds is
+// carried over: nothing of it has been uploaded yet).
+int hostbits_reserve(sc_engine *e, size_t bytes, char **out) {
+    auto &a = e->hb[e->hb_cur];
+    if (a.used == 0 && a.armed) {
+        HIP_TRY(hipEventSynchronize(a.ev));
+        a.armed = false;
+    }
+    if (a.used + bytes > a.cap) {
+        const size_t cap = std::max<size_t>({a.used + bytes, a.cap * 2, (size_t)16 << 20});
+        char *pin = nullptr, *dev = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pin), cap, hipHostMallocDefault));
+        hipError_t he = hipMalloc(reinterpret_cast<void **>(&dev), cap);
+        if (he != hipSuccess) {
+            (void)hipHostFree(pin);
+            return fail(he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE, "host-mask arena: %s", hipGetErrorString(he));
+        }
+        if (a.used) memcpy(pin, a.pin, a.used);
+        if (a.pin) {
+            // the old blocks may be the source / target of a copy still on the stream (a.used > 0 means: not of this
+            // batch's, but an earlier flush's): wait before they go
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            (void)hipHostFree(a.pin);
+            (void)hipFree(a.dev);
+        }
+        a.pin = pin;
+        a.dev = dev;
+        a.cap = cap;
+        a.armed = false;
+    }
+    if (!a.ev) HIP_TRY(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+    *out = a.pin + a.used;
+    a.used += bytes;
+    return SC_OK;
+}
+
+// A carve mask in HOST memory: its bits (pixel != 0 after the optional invert) are made here, on host threads, and
+// only they cross PCIe -- 1/8 of the bytes (1/32 of an int32 mask's); tiles, occupancy bytes and cell maps are a
+// device pass over the bits at the next flush (bits_tiles_kernel).  Appends one pending view.
+int enqueue_hostbits(sc_engine *e, const float *K, const float *R, const float *t, const void *mask, int H, int W,
+                     int dtype, int64_t row_stride) {
+    const int wpr = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    const size_t bits_bytes = ((size_t)H * wpr * 4 + 255) & ~(size_t)255;
+    char *dst = nullptr;
+    int rc = hostbits_reserve(e, bits_bytes, &dst);
+    if (rc) return rc;
+    const uint64_t src_off = (uint64_t)(dst - e->hb[e->hb_cur].pin);
+    const int elem = dtype == SC_MASK_I32 ? 4 : 1;
+    const uint8_t flip = dtype == SC_MASK_U8_INV ? 255 : dtype == SC_MASK_BOOL_INV ? 1 : 0;
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+    // bands of rows over the pool: a 1440 x 1080 mask is 1.5 MB to read, ~17 bands of 64 rows
+    const bool par = (size_t)H * W >= ((size_t)1 << 18);  // small pictures are not worth a hand-over
+    const int band = 64, nparts = par ? (H + band - 1) / band : 1;
+    schost::parallel_for(nparts, [&](int part) {
+        const int r0 = par ? part * band : 0, r1 = par ? std::min(H, r0 + band) : H;
+        schost::pack_rows(mask, row_stride, W, r0, r1, out, wpr, elem, flip);
+    });
+    const size_t ntiles = (size_t)wpr * tiles_y;
+    void *tiles = nullptr, *occ = nullptr, *cm = nullptr;
+    rc = arena_alloc(e, ntiles * 128, &tiles);
+    if (rc) return rc;
+    rc = arena_alloc(e, ntiles, &occ);
+    if (rc) return rc;
+    rc = arena_alloc(e, ntiles * 4, &cm);
+    if (rc) return rc;
+    BitsRec br;
+    memset(&br, 0, sizeof br);
+    br.src_off = src_off;
+    br.tiles = static_cast<uint32_t *>(tiles);
+    br.occ = static_cast<uint8_t *>(occ);
+    br.cmask = static_cast<uint32_t *>(cm);
+    br.W = W; br.H = H; br.tiles_x = wpr; br.tiles_y = tiles_y;
+    e->hp_pending.push_back(br);
+    ViewDesc d;
+    fill_desc(e, d, K, R, t, tiles, H, W, static_cast<const uint8_t *>(occ));
+    d.cmask = static_cast<const uint32_t *>(cm);
+    e->pending.push_back(d);
+    return SC_OK;
+}
+
+// The host-packed views' bits to the device, and their tiles made: one copy, one kernel, ahead of whatever the flush
+// launches.
+int upload_hostbits(sc_engine *e) {
+    if (e->hp_pending.empty()) return SC_OK;
+    const size_t nrec = e->hp_pending.size();
+    if (nrec > 65535) return fail(SC_ERR_INVALID, "too many host masks in one batch");
+    char *table = nullptr;
+    int rc = hostbits_reserve(e, nrec * sizeof(BitsRec), &table);  // (may move the arena: offsets stay)
+    if (rc) return rc;
+    auto &a = e->hb[e->hb_cur];
+    memcpy(table, e->hp_pending.data(), nrec * sizeof(BitsRec));
+    const uint64_t table_off = (uint64_t)(table - a.pin);
+    uint32_t maxtiles = 0;
+    for (const auto &r : e->hp_pending) maxtiles = std::max(maxtiles, (uint32_t)r.tiles_x * (uint32_t)r.tiles_y);
+    rc = step_begin(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(a.dev, a.pin, a.used, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(a.ev, e->stream));
+    a.armed = true;
+    LaunchTimer lt{e, SC_KERNEL_PACK};
+    rc = lt.begin();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bits_tiles_kernel, dim3((maxtiles + 7u) / 8u, (uint32_t)nrec), dim3(kBlock), 0, e->stream,
+                       static_cast<const char *>(a.dev), table_off);
+    HIP_TRY(hipGetLastError());
+    rc = lt.end();
+    if (rc) return rc;
+    e->hp_pending.clear();
+    a.used = 0;          // (the next batch's bits take the other arena; this one is free once its event has fired)
+    e->hb_cur ^= 1;
+    return SC_OK;
+}
+
 // What a fused carve of `nv` views will look like (see flush): decided before anything is launched,
 // because a deferred batch is packed according to it.
 struct FusedPlan {
@@ -866,6 +993,10 @@ FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
 // Launch the first `count` pending views (count == 0: all of them).
 int flush(sc_engine *e, size_t count = 0) {
     if (e->pending.empty()) return SC_OK;
+    {
+        int rch = upload_hostbits(e);
+        if (rch) return rch;
+    }
     size_t nv = count ? std::min(count, e->pending.size()) : e->pending.size();
     // A device batch whose packing was deferred is packed here, in the order its views will be
     // applied: the views the flags kernel, the dense stage and the first survivor stage need go
@@ -1428,6 +1559,11 @@ void sc_destroy(sc_engine *e) {
         if (e->raw[s]) (void)hipFree(e->raw[s]);
         if (e->slot_ev[s]) (void)hipEventDestroy(e->slot_ev[s]);
     }
+    for (auto &a : e->hb) {
+        if (a.pin) (void)hipHostFree(a.pin);
+        if (a.dev) (void)hipFree(a.dev);
+        if (a.ev) (void)hipEventDestroy(a.ev);
+    }
     if (e->views_dev) (void)hipFree(e->views_dev);
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->narrow) (void)hipFree(e->narrow);
@@ -1450,6 +1586,8 @@ int sc_clear(sc_engine *e) {
     int rc = use_device(e);
     if (rc) return rc;
     e->pending.clear();
+    e->hp_pending.clear();
+    e->hb[e->hb_cur].used = 0;  // (nothing of it was uploaded)
     e->deferred.on = false;
     e->dead_clean = false;  // the labels go back to default_value: no brick is known to be all -1
     arena_reset(e);
@@ -1584,6 +1722,14 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
             e->bulk_floor = value;
             return SC_OK;
+        case SC_OPT_HOST_PACK:
+            if (!e->hp_pending.empty()) return fail(SC_ERR_STATE, "host-packed views are pending: flush first");
+            e->host_pack = value ? 1 : 0;
+            return SC_OK;
+        case SC_OPT_HOST_THREADS:
+            if (value < 0 || value > 256) return fail(SC_ERR_INVALID, "host_threads must be in [0, 256]");
+            schost::pool_set_threads((int)value);  // process-wide; takes effect before the pool's first use
+            return SC_OK;
         case SC_OPT_LIST_CAP:
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "list_cap must be in [0, 2^31)");
             e->list_cap = value;
@@ -1673,6 +1819,12 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
     size_t row = (size_t)W * es;
     if (row_stride_bytes == 0) row_stride_bytes = (int64_t)row;
     if (row_stride_bytes < (int64_t)row) return fail(SC_ERR_INVALID, "row stride smaller than a row");
+    if (e->mode == SC_MODE_CARVE && e->host_pack) {
+        // the caller's buffer is consumed here (its bits are in the arena when this returns)
+        rc = enqueue_hostbits(e, K, R, t, mask, H, W, mask_dtype, row_stride_bytes);
+        if (rc) return rc;
+        return after_enqueue(e);
+    }
     size_t bytes = row * (size_t)H;
     rc = ensure_slots(e, bytes);
     if (rc) return rc;
@@ -2062,72 +2214,72 @@ int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes) {
     return SC_OK;
 }
 
-namespace {
-// words [w0, w1) of 2-bit labels (16 per word, label = the pair sign-extended) into int32
-void widen2_range(const uint32_t *src, int32_t *dst, int64_t w0, int64_t w1, int64_t n) {
-    for (int64_t w = w0; w < w1; ++w) {
-        const uint32_t x = src[w];
-        int32_t *o = dst + w * 16;
-        if (w * 16 + 16 <= n) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = (int32_t)(x << (30 - 2 * i)) >> 30;
-        } else {
-            for (int i = 0; w * 16 + i < n; ++i) o[i] = (int32_t)(x << (30 - 2 * i)) >> 30;
-        }
-    }
+int sc_hostpack_bits(const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes, uint32_t *out) {
+    if (!mask || !out || H <= 0 || W <= 0) return fail(SC_ERR_INVALID, "bad argument");
+    if (mask_dtype != SC_MASK_U8 && mask_dtype != SC_MASK_I32 && mask_dtype != SC_MASK_U8_INV && mask_dtype != SC_MASK_BOOL_INV)
+        return fail(SC_ERR_INVALID, "mask dtype %d has no bit form", mask_dtype);
+    const int elem = mask_dtype == SC_MASK_I32 ? 4 : 1;
+    if (row_stride_bytes == 0) row_stride_bytes = (int64_t)W * elem;
+    if (row_stride_bytes < (int64_t)W * elem) return fail(SC_ERR_INVALID, "row stride smaller than a row");
+    const uint8_t flip = mask_dtype == SC_MASK_U8_INV ? 255 : mask_dtype == SC_MASK_BOOL_INV ? 1 : 0;
+    const int wpr = (W + 31) / 32, band = 64, nparts = (H + band - 1) / band;
+    schost::parallel_for(nparts, [&](int part) {
+        schost::pack_rows(mask, row_stride_bytes, W, part * band, std::min(H, part * band + band), out, wpr, elem, flip);
+    });
+    return SC_OK;
 }
-}  // namespace
 
 int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int threads) {
     if (!packed || !out || voxels < 0) return fail(SC_ERR_INVALID, "bad argument");
-    if (threads <= 0) threads = 8;
-    threads = std::min(threads, 64);
-    const int64_t words = (voxels + 15) / 16;
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)threads);
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([=]() { widen2_range(packed, out, words * t / threads, words * (t + 1) / threads, voxels); });
-    for (auto &th : pool) th.join();
+    (void)threads;  // the library's host pool does it (SC_OPT_HOST_THREADS)
+    const int64_t words = (voxels + 15) / 16, piece = (int64_t)1 << 16;
+    const int nparts = (int)std::min<int64_t>((words + piece - 1) / piece, 1 << 20);
+    schost::parallel_for(nparts, [&](int part) {
+        schost::widen2(packed, out, part * piece, std::min(words, (part + 1) * piece), voxels);
+    });
     return SC_OK;
 }
 
 int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads) {
     if (!e || !out || !staging) return fail(SC_ERR_INVALID, "null argument");
+    (void)threads;
     void *ptr = nullptr;
     int64_t bytes = 0;
     int rc = sc_values_packed(e, 2, &ptr, &bytes);
     if (rc) return rc;
     const int64_t n = e->n, words = (n + 15) / 16;
     if (staging_bytes < words * 4) return fail(SC_ERR_INVALID, "staging buffer too small: %lld bytes needed", (long long)(words * 4));
-    if (threads <= 0) threads = 8;
-    threads = std::min(threads, 64);
-    // pieces of 1 MiB of packed labels (16 MiB of int32): copied in order, widened as they land
+    // Pieces of 1 MiB of packed labels (16 MiB of int32): every copy is put on the stream at once, an event behind
+    // each; this thread waits for the events in turn and hands each landed piece to the host pool, whose workers
+    // widen it while the next ones are on their way.  Nobody spins.
     const int64_t piece = (int64_t)1 << 18;  // words
     const int64_t npieces = (words + piece - 1) / piece;
-    std::atomic<int64_t> landed{0};
-    std::atomic<int> failed{0};
     uint32_t *stg = static_cast<uint32_t *>(staging);
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)threads);
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([&, t]() {
-            for (int64_t k = t; k < npieces; k += threads) {
-                while (landed.load(std::memory_order_acquire) <= k) {
-                    if (failed.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                widen2_range(stg, out, k * piece, std::min(words, (k + 1) * piece), n);
-            }
-        });
+    std::vector<hipEvent_t> evs((size_t)npieces, nullptr);
     hipError_t err = hipSuccess;
+    int64_t queued = 0;
     for (int64_t k = 0; k < npieces && err == hipSuccess; ++k) {
         const int64_t w0 = k * piece, w1 = std::min(words, (k + 1) * piece);
+        if (get_event(e, &evs[(size_t)k]) != SC_OK) { err = hipErrorOutOfMemory; break; }
+        ++queued;
         err = hipMemcpyAsync(stg + w0, static_cast<const uint32_t *>(ptr) + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, e->stream);
-        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-        if (err == hipSuccess) landed.store(k + 1, std::memory_order_release);
+        if (err == hipSuccess) err = hipEventRecord(evs[(size_t)k], e->stream);
     }
-    if (err != hipSuccess) failed.store(1);
-    for (auto &th : pool) th.join();
+    {
+        schost::TaskGroup tg;
+        for (int64_t k = 0; k < queued && err == hipSuccess; ++k) {
+            err = hipEventSynchronize(evs[(size_t)k]);
+            if (err != hipSuccess) break;
+            const int64_t w0 = k * piece, w1 = std::min(words, (k + 1) * piece);
+            // two halves per piece: a finer grain for the pool at the transfer's end
+            const int64_t mid = w0 + (w1 - w0) / 2;
+            tg.submit([=]() { schost::widen2(stg, out, w0, mid, n); });
+            tg.submit([=]() { schost::widen2(stg, out, mid, w1, n); });
+        }
+        tg.wait();
+    }
+    (void)hipStreamSynchronize(e->stream);  // (every copy has landed or failed before the events go back)
+    for (int64_t k = 0; k < queued; ++k) e->event_pool.push_back(evs[(size_t)k]);
     if (err != hipSuccess) return fail(SC_ERR_DEVICE, "label read-back failed: %s", hipGetErrorString(err));
     return SC_OK;
 }

@@ -453,6 +453,60 @@ def test_mask_dtypes_bool_int32_grey(gpu_device):
     assert np.array_equal(hip_carve(shape, origin, vs, as_f64), oracle_c.carve(shape, origin, vs, as_f64))
 
 
+@pytest.mark.parametrize("host_pack", [1, 0])
+@pytest.mark.parametrize("w,h", [(33, 17), (100, 70), (160, 96), (1440, 1080)])
+def test_host_masks_cross_pcie_as_bits(gpu_device, host_pack, w, h):
+    """a carve mask handed over in host memory is reduced to 1 bit per pixel on host threads
+    (SC_OPT_HOST_PACK 1, the default) and the device makes tiles, occupancy bytes and cell maps from the bits; 0 is
+    the byte path of rounds 1-3.  Grey levels, bool, int32 (negative values too), inverted uint8 / bool, widths
+    that are not multiples of 32 or 16, one launch per view, per 5 views, per batch -- all against the oracle."""
+    n = 20 if w < 1000 else 28
+    shape, origin, vs, views = scene(n, 7, "plant", width=w, height=h, fx=0.8 * w, fy=0.8 * w, cx=w / 2.0, cy=h / 2.0)
+    rng = np.random.default_rng(w * 31 + h)
+    grey = [np.where(m != 0, rng.integers(1, 256, m.shape), 0).astype(np.uint8) for _, _, _, m in views]
+    forms = [("grey", grey, nat.SC_MASK_U8, lambda m: m),
+             ("bool", [m != 0 for m in grey], nat.SC_MASK_U8, lambda m: m),
+             ("i32", [(m.astype(np.int64) * int(rng.choice([-70000, 1, 3]))).astype(np.int32) for m in grey], nat.SC_MASK_I32, lambda m: m),
+             ("u8 inverted", [np.where(m != 0, 255, rng.integers(0, 255, m.shape)).astype(np.uint8) for m in grey],
+              nat.SC_MASK_U8_INV, np.invert),
+             ("bool inverted", [m == 0 for m in grey], nat.SC_MASK_BOOL_INV, np.invert)]
+    for tag, masks, code, conv in forms:
+        want = oracle_c.carve(shape, origin, vs, [(K, R, t, conv(m)) for (K, R, t, _), m in zip(views, masks)], nthreads=4)
+        for vpl in (0, 1, 5):
+            e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+            e.set_option(nat.SC_OPT_HOST_PACK, host_pack)
+            e.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, vpl)
+            for (K, R, t, _), m in zip(views, masks):
+                e.process_view(K, R, t, m.view(np.uint8) if m.dtype == np.bool_ else m, code)
+            assert np.array_equal(e.get_values(), want), (tag, vpl, host_pack, histogram3(want))
+            # a second batch over the stored volume, after a clear in between batches of the arena's other half
+            for (K, R, t, _), m in zip(views, masks):
+                e.process_view(K, R, t, m.view(np.uint8) if m.dtype == np.bool_ else m, code)
+            assert np.array_equal(e.get_values(), want), (tag, vpl, host_pack, "second batch")
+            e.clear()
+            for (K, R, t, _), m in zip(views[:3], masks[:3]):
+                e.process_view(K, R, t, m.view(np.uint8) if m.dtype == np.bool_ else m, code)
+            e.clear()  # pending host bits dropped
+            for (K, R, t, _), m in zip(views, masks):
+                e.process_view(K, R, t, m.view(np.uint8) if m.dtype == np.bool_ else m, code)
+            assert np.array_equal(e.get_values(), want), (tag, vpl, host_pack, "after clears")
+            e.close()
+
+
+def test_host_mask_arena_grows_with_the_batch(gpu_device):
+    """90 masks of 1440 x 1080 are 17.5 MB of bits: more than the arena's first 16 MB, in one batch."""
+    shape, origin, vs, views = scene(16, 6, "plant")
+    many = [views[q % len(views)] for q in range(90)]
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=4)  # a view applied again changes nothing
+    e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    for _ in range(2):
+        e.clear()
+        for K, R, t, m in many:
+            e.process_view(K, R, t, m, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want)
+    e.close()
+
+
 @pytest.mark.parametrize("w,h", [(160, 96), (33, 17), (1440, 1080)])
 def test_invert_folded_into_device_packing(gpu_device, w, h):
     """``process_fileset(invert=True)``: uint8 / bool masks are inverted by the pack kernels

@@ -29,3 +29,51 @@ def test_widening_refuses_short_input():
         nat.widen_labels2(np.zeros(1, dtype=np.uint32), 17)
     with pytest.raises(ValueError):
         nat.widen_labels2(np.zeros(2, dtype=np.uint32), 17, out=np.zeros(16, dtype=np.int32))
+
+
+def _bits_reference(fg):
+    """fg: bool [H][W] -> uint32 [H][ceil(W / 32)], pixel u at bit u & 31 of word u >> 5."""
+    H, W = fg.shape
+    wpr = (W + 31) // 32
+    pad = np.zeros((H, wpr * 32), dtype=np.uint64)
+    pad[:, :W] = fg
+    return (pad.reshape(H, wpr, 32) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 31), (5, 32), (7, 33), (64, 100), (130, 257), (1080, 1440), (33, 1024 + 17)])
+def test_host_bit_packing_is_the_carve_test_on_every_pixel(shape):
+    """The host half of mask ingest: what crosses PCIe for a carve mask is `pixel != 0` (backprojection.c:79 on the
+    int32 cast of cl.py:215), after np.invert where the fileset loop asks for it (cl.py:300-301) -- for grey levels,
+    bool bytes, int32 masks with negative values, padded rows, widths that are not multiples of 32."""
+    from plant3dvision_amd import _native as nat
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    grey = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    grey[rng.random((H, W)) < 0.5] = 0
+    assert np.array_equal(nat.hostpack_bits(grey, nat.SC_MASK_U8), _bits_reference(grey != 0))
+    assert np.array_equal(nat.hostpack_bits(grey, nat.SC_MASK_U8_INV), _bits_reference(np.invert(grey) != 0))
+    b = rng.random((H, W)) < 0.3
+    assert np.array_equal(nat.hostpack_bits(b, nat.SC_MASK_U8), _bits_reference(b))
+    assert np.array_equal(nat.hostpack_bits(b, nat.SC_MASK_BOOL_INV), _bits_reference(np.invert(b)))
+    i32 = rng.integers(-3, 4, (H, W)).astype(np.int32) * rng.integers(0, 2, (H, W)).astype(np.int32) * 70000
+    assert np.array_equal(nat.hostpack_bits(i32, nat.SC_MASK_I32), _bits_reference(i32 != 0))
+    wide = np.zeros((H, W + 13), dtype=np.uint8)  # a view with padded rows
+    wide[:, :W] = grey
+    wide[:, W:] = 255
+    assert np.array_equal(nat.hostpack_bits(wide[:, :W], nat.SC_MASK_U8), _bits_reference(grey != 0))
+
+
+def test_widening_at_every_alignment_and_tail():
+    from plant3dvision_amd import _native as nat
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 16, 17, 1000, (1 << 20) + 5):
+        lab = rng.integers(-1, 2, n).astype(np.int32)
+        words = np.zeros((n + 15) // 16, dtype=np.uint32)
+        for i in range(16):
+            part = (lab[i::16] & 3).astype(np.uint32)
+            words[:part.size] |= part << np.uint32(2 * i)
+        buf = np.empty(n + 8, dtype=np.int32)
+        for off in (0, 1, 3):  # 32-byte aligned (streaming stores) or not
+            out = buf[off:off + n]
+            nat.widen_labels2(words, n, out=out)
+            assert np.array_equal(out, lab), (n, off)
