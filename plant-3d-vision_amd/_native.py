@@ -592,16 +592,13 @@ class Engine:
         self._call("sc_get_values_i8", addr(out))
         return out
 
-    def get_values_wire2(self, out, staging, threads=None):
-        """Carve labels into the int32 array ``out``: 2 bits each over PCIe in pieces, widened on host threads inside
-        the library as the pieces land (``sc_get_values_wire2``).  ``staging``: a host array of at least a quarter
-        of a byte per voxel the call may scribble on."""
+    def get_values_wire2(self, out, staging=None, threads=None):
+        """Carve labels into the int32 array ``out``: 2 bits each over PCIe in pieces (into a page-locked buffer the
+        engine keeps), widened by the library's host pool as the pieces land (``sc_get_values_wire2``).  ``staging``
+        and ``threads`` are ignored (round 3 arguments)."""
         if out.dtype != np.int32 or out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
             raise ValueError("output buffer has the wrong dtype/size/layout")
-        if not staging.flags["C_CONTIGUOUS"]:
-            raise ValueError("the staging buffer must be contiguous")
-        self._call("sc_get_values_wire2", addr(out), addr(staging), int(staging.nbytes),
-                   int(threads if threads is not None else host_workers(16)))
+        self._call("sc_get_values_wire2", addr(out), 0, 0, 0)
         return out
 
     def values_device_ptr(self):

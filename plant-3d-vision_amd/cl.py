@@ -308,11 +308,16 @@ class Backprojection(object):
         return (self.dtype == np.int32 and int(np.prod([int(s) for s in self.shape])) >= (1 << 24)
                 and -128 <= int(self.default_value) <= 127 and hasattr(self._engine, "get_values_i8"))
 
+    def _wire2_ok(self):
+        """Three-state labels: the 2-bit wire (``sc_get_values_wire2``), which needs no staging array of ours."""
+        return (self._narrow_ok() and float(self.default_value) in (-1.0, 0.0, 1.0)
+                and hasattr(self._engine, "get_values_wire2"))
+
     def _start_prefault(self):
         # the buffers the next read-back lands in, touched on host threads while the device works: the
         # volume-sized array, and the int8 staging buffer where labels travel as bytes
         shape = tuple(int(s) for s in self.shape)
-        if self._narrow_ok() and not isinstance(self._narrow_h, np.ndarray):
+        if self._narrow_ok() and not self._wire2_ok() and not isinstance(self._narrow_h, np.ndarray):
             self._narrow_h = nat.TouchedEmpty(shape, np.int8, threads=2)
         self._prefault = nat.TouchedEmpty(shape, self.dtype)
 
@@ -339,17 +344,16 @@ class Backprojection(object):
         volumes, default values that do not fit a byte and averaging volumes are copied as they are."""
         if self._values_h is None:
             self._values_h = self._take_buffer()
-        if self._narrow_ok():
+        if self._wire2_ok():
+            # three-state labels: 2 bits each over PCIe, widened inside the library as the pieces land
+            self._engine.get_values_wire2(self._values_h.reshape(-1))
+        elif self._narrow_ok():
             if isinstance(self._narrow_h, nat.TouchedEmpty):
                 self._narrow_h = self._narrow_h.result()
             if self._narrow_h is None or self._narrow_h.size != self._values_h.size:
                 self._narrow_h = np.empty(self._values_h.shape, dtype=np.int8)
-            if float(self.default_value) in (-1.0, 0.0, 1.0) and hasattr(self._engine, "get_values_wire2"):
-                # three-state labels: 2 bits each over PCIe, widened inside the library as the pieces land
-                self._engine.get_values_wire2(self._values_h.reshape(-1), self._narrow_h.reshape(-1))
-            else:
-                self._engine.get_values_i8(self._narrow_h)
-                nat.widen_i8(self._values_h, self._narrow_h)
+            self._engine.get_values_i8(self._narrow_h)
+            nat.widen_i8(self._values_h, self._narrow_h)
         else:
             self._engine.get_values(self._values_h)
         return self._values_h.reshape(self.shape)

@@ -1310,16 +1310,17 @@ def test_int8_read_back_of_carve_labels(gpu_device):
     with pytest.raises(nat.SpaceCarveError):
         e.get_values_i8()
     e.close()
-    # the class: a volume of 2^24+ voxels goes through the int8 path and comes back int32
+    # the class: a volume of 2^24+ voxels whose default value two bits cannot hold goes through the int8 path and
+    # comes back int32 (-1 / 0 / 1 take the 2-bit wire: test_read_back_over_the_two_bit_wire)
     big, origin, vs, views = scene((64, 512, 512), 8, "plant")
-    want = oracle_c.carve(list(big), origin, vs, views, nthreads=8)
-    bp = Backprojection(big, origin, vs)
+    want = oracle_c.carve(list(big), origin, vs, views, 7, nthreads=8)
+    bp = Backprojection(big, origin, vs, default_value=7)
     for K, R, t, m in views:
         bp.process_view(K, R, t, m)
     got = bp.get_values()
     assert got.dtype == np.int32 and np.array_equal(got, want) and isinstance(bp._narrow_h, np.ndarray)
     bp.clear()
-    assert (bp.get_values() == 0).all() and np.array_equal(got, want)  # the array handed out kept its contents
+    assert (bp.get_values() == 7).all() and np.array_equal(got, want)  # the array handed out kept its contents
     bp.close()
 
 
@@ -1379,8 +1380,12 @@ def test_read_back_over_the_two_bit_wire(gpu_device):
                 out[:] = 99
                 e.get_values_wire2(out, staging, threads=threads)
                 assert np.array_equal(out.reshape(shape), want), (shape, dv, threads)
-            with pytest.raises(ValueError, match="staging"):
-                e.get_values_wire2(out, staging[:8])
+            e.get_values_wire2(out)  # the round-3 staging argument is optional now (the engine keeps a page-locked one)
+            assert np.array_equal(out.reshape(shape), want), (shape, dv, "no staging argument")
+            # a destination that is not 32-byte aligned
+            odd = np.full(n + 3, 99, dtype=np.int32)[3:]
+            e.get_values_wire2(odd)
+            assert np.array_equal(odd.reshape(shape), want), (shape, dv, "unaligned destination")
             e.close()
     e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, default_value=7.0)
     with pytest.raises(nat.SpaceCarveError, match="two bits cannot hold"):
