@@ -189,6 +189,10 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
  */
 int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, const float *R, const float *t,
                       const void *const *masks_dev, int H, int W);
+/* How many sc_average_labels calls of this process took the shared-launch form (the others went label by label:
+ * more than 4 labels left over, masks or widths that are not 16-byte multiples, engines that differ): tests assert
+ * the form they mean to exercise. */
+int64_t sc_average_labels_fused_count(void);
 
 /* Launch everything still deferred (asynchronous on the engine's stream). */
 int sc_flush(sc_engine *e);

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views_device": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i"]),
     "sc_average_labels": ("i", ["p", "i", "i", "p", "p", "p", "p", "i", "i"]),
+    "sc_average_labels_fused_count": ("q", []),
     "sc_flush": ("i", ["p"]),
     "sc_synchronize": ("i", ["p"]),
     "sc_get_values": ("i", ["p", "p"]),

@@ -72,6 +72,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 
 thread_local std::string g_err;
+std::atomic<int64_t> g_avg_labels_fused{0};  // sc_average_labels calls that took the shared-launch form
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -2016,21 +2017,25 @@ int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, c
     // streams take up again behind it
     hipStream_t main = e0->stream;
     std::vector<hipStream_t> own((size_t)L);
-    for (int l = 0; l < L; ++l) {
-        own[(size_t)l] = engines[l]->stream;
-        if (l > 0 && own[(size_t)l] != main) {
-            hipEvent_t ev;
-            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            hipError_t he = hipEventRecord(ev, own[(size_t)l]);
-            if (he == hipSuccess) he = hipStreamWaitEvent(main, ev, 0);
-            (void)hipEventDestroy(ev);
-            if (he != hipSuccess) return fail(SC_ERR_DEVICE, "stream ordering failed: %s", hipGetErrorString(he));
-        }
-        engines[l]->stream = main;
+    for (int l = 0; l < L; ++l) own[(size_t)l] = engines[l]->stream;
+    // the ordering first, for every engine; the `stream` fields are switched only once all of it has succeeded, and
+    // whatever way this function is left they go back to the engines' own (an engine must never keep another's)
+    for (int l = 1; l < L; ++l) {
+        if (own[(size_t)l] == main) continue;
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t he = hipEventRecord(ev, own[(size_t)l]);
+        if (he == hipSuccess) he = hipStreamWaitEvent(main, ev, 0);
+        (void)hipEventDestroy(ev);
+        if (he != hipSuccess) return fail(SC_ERR_DEVICE, "stream ordering failed: %s", hipGetErrorString(he));
     }
-    auto restore = [&]() {
-        for (int l = 0; l < L; ++l) engines[l]->stream = own[(size_t)l];
-    };
+    struct StreamGuard {
+        sc_engine *const *eng;
+        const std::vector<hipStream_t> &own;
+        int n;
+        ~StreamGuard() { for (int l = 0; l < n; ++l) eng[l]->stream = own[(size_t)l]; }
+    } guard{engines, own, L};
+    for (int l = 0; l < L; ++l) engines[l]->stream = main;
     const GridDesc g = grid_desc(e0);
     const uint32_t anb = (uint32_t)((uint64_t)e0->planes * abys * abzs);
     const size_t need = (size_t)anb * (size_t)V;
@@ -2111,9 +2116,11 @@ int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, c
         if (rc == SC_OK) e->fresh = false;
         arena_reset(e);  // (on the first engine's stream, which every later use of this engine's arena is behind)
     }
-    restore();
-    return rc;
+    if (rc == SC_OK) g_avg_labels_fused.fetch_add(1, std::memory_order_relaxed);
+    return rc;  // (the guard hands the engines their own streams back)
 }
+
+int64_t sc_average_labels_fused_count(void) { return g_avg_labels_fused.load(std::memory_order_relaxed); }
 
 int sc_flush(sc_engine *e) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");

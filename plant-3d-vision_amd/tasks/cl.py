@@ -15,11 +15,6 @@ import numpy as np
 
 logger = logging.getLogger(__name__)
 
-#: the class ``voxels_run`` (and so ``Voxels.run``) instantiates; ``None`` = ``plant3dvision_amd.cl.Backprojection``
-#: (the HIP engine).  A seam for callers that bring their own device layer -- the CPU tests put the
-#: oracle-backed class here; the product never sets it.
-BACKPROJECTION_CLS = None
-
 #: parameter defaults of the reference task (tasks/cl.py:83-91)
 VOXELS_DEFAULTS = dict(query={}, camera_metadata="colmap_camera", voxel_size=1.0, type="carving",
                        log=True, invert=False, labels=[], bounding_box=None)
@@ -113,9 +108,7 @@ def voxels_run(masks_files, bounding_box, voxel_size=1.0, type="carving", log=Tr
     ``{label: array}`` (NPZ, tasks/cl.py:176-182) when labels are in play, else the single
     array (``write_volume``, :184) -- and ``metadata = {'voxel_size', 'origin'}`` (:186).
     """
-    if backprojection_cls is None:
-        backprojection_cls = BACKPROJECTION_CLS
-    if backprojection_cls is None:
+    if backprojection_cls is None:  # the product: the HIP engine (an argument only: the CPU tests pass a class of theirs)
         from ..cl import Backprojection as backprojection_cls
     logger.info(f"Processing a list of {len(masks_files)} mask files...")
     if bounding_box is None:

@@ -1,7 +1,9 @@
 """CPU: the outer plugin boundary -- ``class Voxels(RomiTask)`` (reference ``plant3dvision/tasks/cl.py:18-186``)
 driven through minimal stand-ins of luigi / romitask / plantdb.io that live under ``tests/stubs``
 (none of the real packages is installed here).  The device layer is the oracle-backed
-``Backprojection`` (tests.helpers), injected through ``tasks.cl.BACKPROJECTION_CLS``."""
+``Backprojection`` (tests.helpers), handed to ``voxels_run`` through its ``backprojection_cls`` argument (the task class calls ``voxels_run`` by
+name: the fixture wraps that name for the test's duration)."""
+import functools
 import importlib
 import os
 import sys
@@ -26,9 +28,10 @@ def task_env():
     from plant3dvision_amd.tasks import cl as mod
     mod = importlib.reload(mod)
     assert mod.Voxels is not None, "the task class must exist when luigi/romitask import"
-    mod.BACKPROJECTION_CLS = OracleBackprojection
+    product_run = mod.voxels_run
+    mod.voxels_run = functools.partial(product_run, backprojection_cls=OracleBackprojection)
     yield mod, romitask
-    mod.BACKPROJECTION_CLS = None
+    mod.voxels_run = product_run
     sys.path.remove(STUBS)
     for name in [m for m in sys.modules if m.split(".")[0] in ("luigi", "romitask", "plantdb", "plant3dvision")]:
         del sys.modules[name]
@@ -197,7 +200,7 @@ def task_env_hip():
     import romitask
     from plant3dvision_amd.tasks import cl as mod
     mod = importlib.reload(mod)
-    assert mod.Voxels is not None and mod.BACKPROJECTION_CLS is None
+    assert mod.Voxels is not None and not isinstance(mod.voxels_run, functools.partial)
     yield mod, romitask
     sys.path.remove(STUBS)
     for name in [m for m in sys.modules if m.split(".")[0] in ("luigi", "romitask", "plantdb", "plant3dvision")]:
