@@ -246,6 +246,12 @@ int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t stagi
 /* Host code only (no device, no engine): the widening sc_get_values_wire2 does, by itself -- `voxels` labels at
  * 2 bits each in packed[(voxels + 15) / 16] (the layout above) into out[voxels] on the host pool (`threads` ignored). */
 int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int threads);
+/* Host code only: `world` ranks' packed planes (2 bits per label, rank-major, `rank_bytes` apart: what a gather of
+ * the ranks' sc_values_packed buffers gives) into ONE int32 grid out[nx][ny][nz] in global plane order -- the host
+ * end of ShardedBackprojection.gather_to_host (cl.py:229-232 get_values of a sharded run).  partition: 0 plane-cyclic
+ * (plane i is plane i / world of rank i % world), 1 slabs.  On the library's host pool. */
+int sc_widen_labels2_ranks(const uint32_t *packed, int64_t rank_bytes, int world, int partition, int64_t nx, int64_t ny,
+                           int64_t nz, int32_t *out);
 /* Host code only: the bit form in which sc_process_view sends a carve mask over PCIe (cl.py:215 + backprojection.c:79:
  * a pixel counts when it is != 0; SC_MASK_U8_INV / SC_MASK_BOOL_INV: after np.invert, cl.py:300-301) -- row-major,
  * out[H][(W + 31) / 32] words, pixel u of a row at bit u & 31 of word u >> 5, bits beyond W zero.  mask_dtype: the
@@ -329,6 +335,14 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
                const double origin[3], double voxel_size, double level_set_value,
                const double gauss_w[5], int device, double **points_out, double **normals_out,
                int64_t *count);
+/* The same from carve labels in their PACKED, rank-major form -- what an all-gather of the ranks' sc_values_packed
+ * buffers leaves on a device (`world` ranks x `rank_bytes`, `bits` 2 or 1 per label, `partition` 0 plane-cyclic /
+ * 1 slabs: the arguments of sc_unpack_labels).  Labels are -1 / 0 / 1, so the reference's `volume > 0.5`
+ * (proc3d.py:515) is `label == 1` and is read off the packed words: the full-size grid (1 GiB of int8 at 1024^3)
+ * is never written.  Runs on the device's default stream: the caller has waited for the collective. */
+int sc_vol2pcd_packed(const void *recv_dev, int64_t rank_bytes, int world, int partition, int bits, int64_t nx,
+                      int64_t ny, int64_t nz, const double origin[3], double voxel_size, double level_set_value,
+                      const double gauss_w[5], int device, double **points_out, double **normals_out, int64_t *count);
 const char *sc_vol2pcd_last_error(void);
 /* sc_vol2pcd keeps its device work buffers (49 bytes per voxel, per device) between calls while they are at most
  * 1 GiB (larger ones are freed when the call ends); this gives back what is kept.  The caller's current HIP

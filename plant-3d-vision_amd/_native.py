@@ -75,6 +75,8 @@ _SIGNATURES = {
     "sc_get_values_wire2": ("i", ["p", "p", "p", "q", "i"]),
     "sc_widen_labels2": ("i", ["p", "q", "p", "i"]),
     "sc_hostpack_bits": ("i", ["p", "i", "i", "i", "q", "p"]),
+    "sc_widen_labels2_ranks": ("i", ["p", "q", "i", "i", "q", "q", "q", "p"]),
+    "sc_vol2pcd_packed": ("i", ["p", "q", "i", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
@@ -408,6 +410,22 @@ def pose_records(entries):
         if shape is not None:
             i[q, 22:25] = [int(x) for x in shape]
     return rec
+
+
+def widen_labels2_ranks(packed, rank_bytes, world, partition, shape, out=None):
+    """``sc_widen_labels2_ranks``: ``world`` ranks' planes at 2 bits per label, rank-major and ``rank_bytes`` apart
+    (a gather of the ranks' ``values_packed(2)`` buffers), into one int32 grid in global plane order (host code)."""
+    packed = np.ascontiguousarray(packed).view(np.uint32).reshape(-1)
+    shape = [int(s) for s in shape]
+    if packed.size * 4 < int(rank_bytes) * int(world):
+        raise ValueError("packed buffer smaller than world * rank_bytes")
+    if out is None:
+        out = np.empty(shape, dtype=np.int32)
+    if out.dtype != np.int32 or out.size != int(np.prod(shape)) or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError("output buffer has the wrong dtype/size/layout")
+    check(backend().call("sc_widen_labels2_ranks", addr(packed), int(rank_bytes), int(world),
+                         0 if partition == "cyclic" else 1, shape[0], shape[1], shape[2], addr(out)), "sc_widen_labels2_ranks")
+    return out.reshape(shape)
 
 
 def hostpack_bits(mask, dtype_code=None):

@@ -189,7 +189,7 @@ class Backprojection(object):
     dtype : numpy.int32 ("carving") or numpy.float32 ("averaging")   (cl.py:145-150)
     kernel : str, "carve" or "average" -- the HIP kernel that will run
     values_h : numpy.ndarray, host copy of the volume (refreshed by ``get_values``)
-    values_d : int, device address of the volume (a property: fetched when read; None before ``init_buffers``)
+    values_d : int, device address of the volume as ``device_values()`` last returned it (``None`` before that)
     """
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, labels=None,
@@ -247,6 +247,7 @@ class Backprojection(object):
             self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
                                       default_value=float(self.default_value), device=self.device)
         self._lut = None
+        self._values_d = None
         if self.views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(self.views_per_launch))
         self._values_h = None  # cl.py:173 builds default * ones here; see the values_h property
@@ -360,12 +361,18 @@ class Backprojection(object):
 
     @property
     def values_d(self):
-        """Device address of the volume (the reference's ``values_d`` buffer, cl.py:175), fetched when asked for:
-        on a grid whose rows are padded on the device (nz not a multiple of 64) it is a snapshot without the
-        padding made by this call (``sc_values_device_ptr``), valid until the state changes."""
+        """The reference's ``values_d`` (cl.py:175) is a device buffer; here: the device address ``device_values()``
+        last handed out (``None`` before the first such call).  Reading the attribute does nothing on the device."""
+        return getattr(self, "_values_d", None)
+
+    def device_values(self):
+        """Device address of the volume as ``nx * ny * nz`` contiguous elements in the reference's order: pending
+        views are launched; on a grid whose rows are padded on the device (nz not a multiple of 64) this call makes
+        a snapshot without the padding (``sc_values_device_ptr``), valid until the state changes."""
         if getattr(self, "_engine", None) is None:
             return None
-        return self._engine.values_device_ptr()
+        self._values_d = self._engine.values_device_ptr()
+        return self._values_d
 
     def process_fileset(self, fs, camera_metadata, invert=False):
         """Processes a whole fileset (cl.py:234-257): one volume, or with ``labels`` a

@@ -2250,6 +2250,42 @@ int sc_widen_labels2(const uint32_t *packed, int64_t voxels, int32_t *out, int t
     return SC_OK;
 }
 
+int sc_widen_labels2_ranks(const uint32_t *packed, int64_t rank_bytes, int world, int partition, int64_t nx, int64_t ny,
+                           int64_t nz, int32_t *out) {
+    if (!packed || !out) return fail(SC_ERR_INVALID, "null argument");
+    if (partition != 0 && partition != 1) return fail(SC_ERR_INVALID, "partition: 0 plane-cyclic, 1 slabs");
+    if (world < 1 || nx < world || ny < 1 || nz < 1 || rank_bytes < 0 || (rank_bytes & 3)) return fail(SC_ERR_INVALID, "bad shape / world / stride");
+    const int64_t plane = ny * nz, pmax = (nx + world - 1) / world;
+    if (rank_bytes * 4 < pmax * plane) return fail(SC_ERR_INVALID, "rank stride too small for its planes");
+    const int64_t rw = rank_bytes / 4;
+    if (nx > (1 << 30)) return fail(SC_ERR_INVALID, "too many planes");
+    schost::parallel_for((int)nx, [&](int i) {
+        int64_t r, p;
+        if (partition == 0) {
+            r = i % world;
+            p = i / world;
+        } else {
+            r = ((int64_t)i * world + world - 1) / nx;
+            while (nx * r / world > i) --r;
+            while (nx * (r + 1) / world <= i) ++r;
+            p = i - nx * r / world;
+        }
+        const uint32_t *src = packed + r * rw;
+        const int64_t l0 = p * plane;  // first label of the plane in the rank's stream
+        int32_t *dst = out + (int64_t)i * plane;
+        if ((l0 & 15) == 0) {
+            // whole words from a word boundary: the fast loop, with dst shifted so that label l lands at dst[l - l0]
+            schost::widen2(src, dst - l0, l0 / 16, (l0 + plane + 15) / 16, l0 + plane);
+        } else {
+            for (int64_t q = 0; q < plane; ++q) {
+                const int64_t l = l0 + q;
+                dst[q] = (int32_t)(src[l >> 4] << (30 - 2 * (int)(l & 15))) >> 30;
+            }
+        }
+    });
+    return SC_OK;
+}
+
 int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t staging_bytes, int threads) {
     if (!e || !out) return fail(SC_ERR_INVALID, "null argument");
     (void)threads;

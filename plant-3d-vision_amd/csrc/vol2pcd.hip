@@ -141,6 +141,68 @@ __global__ __launch_bounds__(kB) void occ_kernel(const T *__restrict__ vol, uint
     }
 }
 
+// The same from carve labels as the ranks of a sharded run leave them after an all-gather: `world` ranks' planes at
+// 2 bits (label & 3) or 1 bit (label == 1) per voxel, rank-major ([world][rank_words] words; plane i of the grid is
+// plane i / world of rank i % world, or plane i - first(r) of the rank whose slab holds it).  A label is one of
+// -1, 0, 1, so `volume > 0.5` (proc3d.py:515) is `label == 1`: the occupancy is read off the packed form and the
+// full-size int8 / int32 grid is never written.  occ[0] is voxel 0 of global plane x0.
+struct PackedIn {
+    const uint32_t *recv;
+    uint64_t rank_words;
+    uint32_t world, nx_total;
+    int32_t cyclic, bits;
+};
+
+template <int BITS>
+__global__ __launch_bounds__(kB) void occ_packed_kernel(PackedIn pk, uint8_t *__restrict__ occ, int64_t n, uint64_t plane,
+                                                        uint32_t x0) {
+    constexpr uint32_t PER = 32u / BITS;
+    const int64_t i0 = ((int64_t)blockIdx.x * kB + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    auto locate = [&](uint64_t v, uint32_t &r, uint64_t &src) {  // v: voxel of the GLOBAL grid
+        const uint32_t i = (uint32_t)(v / plane);
+        const uint64_t within = v - (uint64_t)i * plane;
+        uint32_t p;
+        if (pk.cyclic) {
+            r = i % pk.world;
+            p = i / pk.world;
+        } else {  // slabs [nx r / world, nx (r + 1) / world)
+            r = (uint32_t)(((uint64_t)i * pk.world + pk.world - 1) / pk.nx_total);
+            while ((uint64_t)pk.nx_total * r / pk.world > i) --r;
+            while ((uint64_t)pk.nx_total * (r + 1) / pk.world <= i) ++r;
+            p = i - (uint32_t)((uint64_t)pk.nx_total * r / pk.world);
+        }
+        src = (uint64_t)p * plane + within;
+    };
+    const uint64_t g0 = (uint64_t)x0 * plane + (uint64_t)i0;
+    if (plane % PER == 0 && i0 + 16 <= n && (reinterpret_cast<uintptr_t>(occ) & 15) == 0) {  // the 16 voxels share a plane and a word
+        uint32_t r;
+        uint64_t src;
+        locate(g0, r, src);
+        const uint32_t word = pk.recv[(uint64_t)r * pk.rank_words + src / PER] >> (BITS * (uint32_t)(src % PER));
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t lab = (word >> (BITS * (q * 4 + e))) & (BITS == 2 ? 3u : 1u);
+                bits |= (lab == 1u ? 1u : 0u) << (8 * e);
+            }
+            w[q] = bits;
+        }
+        *reinterpret_cast<uint4 *>(occ + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        return;
+    }
+    for (int64_t i = i0; i < min(n, i0 + 16); ++i) {
+        uint32_t r;
+        uint64_t src;
+        locate(g0 + (uint64_t)(i - i0), r, src);
+        const uint32_t lab = (pk.recv[(uint64_t)r * pk.rank_words + src / PER] >> (BITS * (uint32_t)(src % PER))) & (BITS == 2 ? 3u : 1u);
+        occ[i] = lab == 1u ? 1 : 0;
+    }
+}
+
 // per 8^3 block: bit 0 = holds a foreground voxel, bit 1 = holds a background voxel
 __global__ __launch_bounds__(kB) void block_class_kernel(const uint8_t *__restrict__ occ, int nx, int ny,
                                                          int nz, int nbx, int nby, int nbz,
@@ -580,7 +642,7 @@ static size_t scratch_bytes(int64_t planes, int64_t ny, int64_t nz) {
 static int vol2pcd_range(const void *volume, int on_device, int dtype, int64_t nx, int64_t ny, int64_t nz, int xoff,
                          int cx0, int cx1, const double origin[3], double voxel_size, double level_set_value,
                          const double gauss_w[5], int device, double **points_out, double **normals_out,
-                         int64_t *count) {
+                         int64_t *count, const PackedIn *pk = nullptr) {  // pk: packed labels instead of `volume`
     *points_out = *normals_out = nullptr;
     *count = 0;
     const int64_t n = nx * ny * nz;
@@ -647,12 +709,18 @@ static int vol2pcd_range(const void *volume, int on_device, int dtype, int64_t n
     gz = reinterpret_cast<double *>(scratch + o_gz);
     v = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act, list_act, list_cols, xoff, cx0, cx1};
     vh = Vol{(int)nx, (int)ny, (int)nz, nby, nbz, act, list_halo, list_cols, xoff, cx0, cx1};
-    if (on_device) {
+    if (pk != nullptr) {
+        on_device = 1;  // (nothing of ours to free)
+    } else if (on_device) {
         vol_d = const_cast<void *>(volume);
     } else {
         V_TRY(hipMalloc(&vol_d, (size_t)n * esz));
         V_TRY(hipMemcpy(vol_d, volume, (size_t)n * esz, hipMemcpyHostToDevice));
     }
+    if (pk != nullptr) {
+        if (pk->bits == 2) hipLaunchKernelGGL(occ_packed_kernel<2>, dim3(blocks_for((n + 15) / 16)), block, 0, st, *pk, occ, n, (uint64_t)ny * (uint64_t)nz, (uint32_t)xoff);
+        else hipLaunchKernelGGL(occ_packed_kernel<1>, dim3(blocks_for((n + 15) / 16)), block, 0, st, *pk, occ, n, (uint64_t)ny * (uint64_t)nz, (uint32_t)xoff);
+    } else
     switch (dtype) {
         case 0: hipLaunchKernelGGL(occ_kernel<int32_t>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const int32_t *)vol_d, occ, n); break;
         case 1: hipLaunchKernelGGL(occ_kernel<float>, dim3(blocks_for((n + 15) / 16)), block, 0, st, (const float *)vol_d, occ, n); break;
@@ -740,11 +808,11 @@ static int64_t g_scratch_limit = (int64_t)8 << 30;
 
 void sc_vol2pcd_set_scratch_limit(int64_t bytes) { g_scratch_limit = bytes < 0 ? 0 : bytes; }
 
-int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t ny, int64_t nz,
-               const double origin[3], double voxel_size, double level_set_value,
-               const double gauss_w[5], int device, double **points_out, double **normals_out,
-               int64_t *count) {
-    if (!volume || !origin || !gauss_w || !points_out || !normals_out || !count)
+static int vol2pcd_driver(const void *volume, int on_device, int dtype, int64_t nx, int64_t ny, int64_t nz,
+                          const double origin[3], double voxel_size, double level_set_value,
+                          const double gauss_w[5], int device, double **points_out, double **normals_out,
+                          int64_t *count, const PackedIn *pk) {
+    if ((!volume && !pk) || !origin || !gauss_w || !points_out || !normals_out || !count)
         return fail_v(SC_ERR_INVALID, "null argument");
     if (nx < 2 || ny < 2 || nz < 2) return fail_v(SC_ERR_INVALID, "np.gradient needs at least 2 voxels per axis");
     if (nx > 65535 || ny > 65535) return fail_v(SC_ERR_INVALID, "x and y are limited to 65535 voxels");
@@ -761,7 +829,7 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     }
     if (planes >= nx)
         return vol2pcd_range(volume, on_device, dtype, nx, ny, nz, 0, 0, (int)nx, origin, voxel_size, level_set_value,
-                             gauss_w, device, points_out, normals_out, count);
+                             gauss_w, device, points_out, normals_out, count, pk);
     const int64_t S = planes - 2 * H;
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 4 : dtype == 2 ? 8 : 1;
     std::vector<double *> ps, ns;
@@ -772,8 +840,8 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
         const int64_t c1 = std::min(nx, c0 + S), a = std::max<int64_t>(0, c0 - H), b = std::min(nx, c1 + H);
         double *p = nullptr, *q = nullptr;
         int64_t c = 0;
-        rc = vol2pcd_range(static_cast<const char *>(volume) + (size_t)a * ny * nz * esz, on_device, dtype, b - a, ny, nz,
-                           (int)a, (int)(c0 - a), (int)(c1 - a), origin, voxel_size, level_set_value, gauss_w, device, &p, &q, &c);
+        rc = vol2pcd_range(pk ? nullptr : static_cast<const char *>(volume) + (size_t)a * ny * nz * esz, on_device, dtype, b - a, ny, nz,
+                           (int)a, (int)(c0 - a), (int)(c1 - a), origin, voxel_size, level_set_value, gauss_w, device, &p, &q, &c, pk);
         ps.push_back(p); ns.push_back(q); cs.push_back(c);
         total += c;
     }
@@ -798,6 +866,30 @@ int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t
     }
     for (size_t k = 0; k < ps.size(); ++k) { free(ps[k]); free(ns[k]); }
     return rc;
+}
+
+int sc_vol2pcd(const void *volume, int on_device, int dtype, int64_t nx, int64_t ny, int64_t nz,
+               const double origin[3], double voxel_size, double level_set_value,
+               const double gauss_w[5], int device, double **points_out, double **normals_out,
+               int64_t *count) {
+    return vol2pcd_driver(volume, on_device, dtype, nx, ny, nz, origin, voxel_size, level_set_value, gauss_w, device,
+                          points_out, normals_out, count, nullptr);
+}
+
+int sc_vol2pcd_packed(const void *recv_dev, int64_t rank_bytes, int world, int partition, int bits, int64_t nx,
+                      int64_t ny, int64_t nz, const double origin[3], double voxel_size, double level_set_value,
+                      const double gauss_w[5], int device, double **points_out, double **normals_out, int64_t *count) {
+    if (!recv_dev) return fail_v(SC_ERR_INVALID, "null argument");
+    if (bits != 1 && bits != 2) return fail_v(SC_ERR_INVALID, "bits must be 1 or 2");
+    if (partition != 0 && partition != 1) return fail_v(SC_ERR_INVALID, "partition: 0 plane-cyclic, 1 slabs");
+    if (world < 1 || nx < world || rank_bytes < 0 || (rank_bytes & 3)) return fail_v(SC_ERR_INVALID, "bad world / stride");
+    const uint64_t pmax = (uint64_t)(nx + world - 1) / world;
+    if ((uint64_t)rank_bytes * 8 < pmax * (uint64_t)ny * (uint64_t)nz * (uint64_t)bits)
+        return fail_v(SC_ERR_INVALID, "rank stride too small for its planes");
+    const PackedIn pk{static_cast<const uint32_t *>(recv_dev), (uint64_t)rank_bytes / 4, (uint32_t)world, (uint32_t)nx,
+                      partition == 0 ? 1 : 0, bits};
+    return vol2pcd_driver(nullptr, 1, 3, nx, ny, nz, origin, voxel_size, level_set_value, gauss_w, device, points_out,
+                          normals_out, count, &pk);
 }
 
 void sc_vol2pcd_release(void) {

@@ -56,9 +56,11 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
     """Converts a volume into a point-cloud with normals, on the GPU
     (``plant3dvision/proc3d.py:490-570``; same signature, ``device`` / ``as_open3d`` added).
 
-    ``volume`` may be a NumPy array (int32 / float32 / float64 / uint8, C-order) or a
+    ``volume`` may be a NumPy array (int32 / float32 / float64 / uint8, C-order), a
     ``Backprojection`` whose device-resident volume is used in place -- the 4N-byte grid then
-    never crosses PCIe, only the shell's points and normals come back.
+    never crosses PCIe, only the shell's points and normals come back -- or the ``PackedGrid`` of a
+    sharded run (``ShardedBackprojection.all_gather(compress="1bit" | "2bit", unpack=False)``): the
+    ranks' packed planes are read as they are and the full-size grid is never written.
     Returns an ``open3d.geometry.PointCloud`` when open3d is importable (and ``as_open3d``),
     else a :class:`PointCloud` with the same ``points`` / ``normals``.
     """
@@ -69,30 +71,39 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
     b = nat.backend()
     codes = {np.dtype(np.int32): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.uint8): 3}
     keep = None
-    if hasattr(volume, "_engine") and hasattr(volume, "shape"):  # a Backprojection: use its state in place
-        bp = volume
-        ptr = bp._engine.values_device_ptr()
-        bp._engine.synchronize()
-        shape = [int(s) for s in bp.shape]
-        code, on_device, device = codes[np.dtype(bp.dtype)], 1, bp.device
-    else:
-        vol = np.asarray(volume)
-        if vol.ndim != 3:
-            raise ValueError("volume must be 3-D")
-        if vol.dtype == np.bool_:
-            vol = vol.view(np.uint8)
-        if vol.dtype not in codes:
-            vol = vol.astype(np.float64)
-        keep = np.ascontiguousarray(vol)
-        ptr, shape, code, on_device = nat.addr(keep), list(keep.shape), codes[keep.dtype], 0
     origin64 = np.ascontiguousarray(np.asarray(origin, dtype=np.float64).reshape(3))
     gw = gaussian_weights(1.0)
     assert gw.size == 5
     out = np.zeros(2, dtype=np.uintp)
     cnt = np.zeros(1, dtype=np.int64)
-    rc = b.call("sc_vol2pcd", ptr, on_device, code, shape[0], shape[1], shape[2], nat.addr(origin64),
-                float(voxel_size), float(level_set_value), nat.addr(gw), int(device), nat.addr(out),
-                nat.addr(out) + 8, nat.addr(cnt))
+    if hasattr(volume, "recv") and hasattr(volume, "rank_bytes"):  # a sharded run's PackedGrid: read as it is
+        import torch
+        pg = volume
+        torch.cuda.synchronize(pg.recv.device)  # the collective that filled it
+        rc = b.call("sc_vol2pcd_packed", int(pg.recv.data_ptr()), int(pg.rank_bytes), int(pg.world),
+                    0 if pg.partition == "cyclic" else 1, int(pg.bits), pg.shape[0], pg.shape[1], pg.shape[2],
+                    nat.addr(origin64), float(voxel_size), float(level_set_value), nat.addr(gw), int(pg.device),
+                    nat.addr(out), nat.addr(out) + 8, nat.addr(cnt))
+    else:
+        if hasattr(volume, "_engine") and hasattr(volume, "shape"):  # a Backprojection: use its state in place
+            bp = volume
+            ptr = bp._engine.values_device_ptr()
+            bp._engine.synchronize()
+            shape = [int(s) for s in bp.shape]
+            code, on_device, device = codes[np.dtype(bp.dtype)], 1, bp.device
+        else:
+            vol = np.asarray(volume)
+            if vol.ndim != 3:
+                raise ValueError("volume must be 3-D")
+            if vol.dtype == np.bool_:
+                vol = vol.view(np.uint8)
+            if vol.dtype not in codes:
+                vol = vol.astype(np.float64)
+            keep = np.ascontiguousarray(vol)
+            ptr, shape, code, on_device = nat.addr(keep), list(keep.shape), codes[keep.dtype], 0
+        rc = b.call("sc_vol2pcd", ptr, on_device, code, shape[0], shape[1], shape[2], nat.addr(origin64),
+                    float(voxel_size), float(level_set_value), nat.addr(gw), int(device), nat.addr(out),
+                    nat.addr(out) + 8, nat.addr(cnt))
     if rc != 0:
         msg = b.string(b.call("sc_vol2pcd_last_error"))
         if rc == nat.SC_ERR_INVALID:

@@ -58,6 +58,27 @@ class _DeviceBuffer:
                                          "data": (int(ptr), False), "version": 2}
 
 
+class PackedGrid:
+    """The assembled grid as the all-gather left it: every rank's planes at ``bits`` per label, rank-major, on this
+    rank's device.  ``vol2pcd`` reads it as it is (``proc3d.vol2pcd(packed_grid, ...)``: the occupancy ``label == 1``
+    is what the reference binarises to, proc3d.py:515); ``unpack()`` makes the int8 / int32 grid in global order for
+    consumers that want one -- 1 GiB of writes per GPU at 1024^3 that a ``vol2pcd`` run never needs."""
+
+    def __init__(self, recv, rank_bytes, world, partition, shape, bits, device):
+        self.recv, self.rank_bytes, self.world = recv, int(rank_bytes), int(world)
+        self.partition, self.shape, self.bits, self.device = partition, [int(s) for s in shape], int(bits), int(device)
+
+    def unpack(self, widen=False, out=None):
+        import torch
+        n = int(np.prod(self.shape))
+        dt = torch.int32 if widen else torch.int8
+        if out is None or out.dtype != dt or out.numel() < n:
+            out = torch.empty(n, dtype=dt, device=self.recv.device)
+        nat.unpack_labels(self.device, torch.cuda.current_stream(self.recv.device).cuda_stream, self.recv.data_ptr(),
+                          self.rank_bytes, self.world, self.partition, self.shape, self.bits, out.data_ptr(), 4 if widen else 1)
+        return out[:n].view(self.shape)
+
+
 class ShardedBackprojection:
     """Slab-sharded ``Backprojection``: same per-view interface, one slab per rank."""
 
@@ -184,7 +205,7 @@ class ShardedBackprojection:
         """Bytes one rank contributes to a packed all-gather (its planes padded to the largest plane count)."""
         return nat.packed_bytes(self._planes_max() * self.shape[1] * self.shape[2], bits)
 
-    def _all_gather_packed(self, bits, widen, recv, out):
+    def _all_gather_packed(self, bits, widen, recv, out, unpack=True):
         """Labels at 2 bits each (or 1: the occupancy ``label == 1`` the consumer binarises to, proc3d.py:515)
         over the wire -- 1/16 (1/32) of the int32 planes: 32 MiB per rank at 1024^3 / 8 -- and ONE kernel
         (``sc_unpack_labels``) that unpacks and puts the planes in global order, as int8 or, ``widen``, int32."""
@@ -206,7 +227,7 @@ class ShardedBackprojection:
             local = torch.from_numpy(np.ascontiguousarray(self._engine.get_values_packed(bits)).view(np.uint8))
         n_out = int(np.prod(self.shape))
         out_dtype = torch.int32 if widen else torch.int8
-        if out is None or out.dtype != out_dtype or out.numel() < n_out:
+        if unpack and (out is None or out.dtype != out_dtype or out.numel() < n_out):
             out = torch.empty(n_out, dtype=out_dtype, device=local.device)
         single = W == 1 and not self.force_collective
         if single:
@@ -226,6 +247,14 @@ class ShardedBackprojection:
                 recv.copy_(hrecv)
             else:
                 dist.all_gather_into_tensor(recv, send)
+        if not unpack:
+            # the packed planes as they are (a PackedGrid): vol2pcd reads them directly.  A single rank's buffer is
+            # the engine's own and is overwritten by its next pack: copied, it is 1/16 of the grid
+            if single and recv.is_cuda:
+                recv = recv.clone()
+            if tstream is not None:
+                self._engine.order_after(tstream)
+            return PackedGrid(recv, rank_bytes, W, self.partition, self.shape, bits, self.device)
         if recv.is_cuda:
             nat.unpack_labels(self.device, torch.cuda.current_stream(recv.device).cuda_stream, recv.data_ptr(), rank_bytes, W,
                               self.partition, self.shape, bits, out.data_ptr(), 4 if widen else 1)
@@ -238,7 +267,7 @@ class ShardedBackprojection:
                                                             np.int32 if widen else np.int8).reshape(-1))
         return out[:n_out].view(self.shape)
 
-    def all_gather(self, compress=False, widen=True, recv=None, out=None):
+    def all_gather(self, compress=False, widen=True, recv=None, out=None, unpack=True):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
 
         compress=True sends carve labels as int8 (labels are in {-1, 0, 1} when default_value
@@ -250,11 +279,16 @@ class ShardedBackprojection:
         order by one kernel (``_all_gather_packed``).
         recv / out: reusable buffers (``W * P * ny * nz`` elements of the wire dtype; packed: recv
         ``W * packed_rank_bytes(bits)`` bytes, out ``nx * ny * nz`` int8 / int32).
+        unpack=False (packed forms only): no grid is written at all -- the result is a ``PackedGrid`` (the ranks'
+        packed planes on this device), which ``proc3d.vol2pcd`` consumes as it is and ``.unpack()`` turns into the
+        grid on demand.
         """
         import torch
         import torch.distributed as dist
         if compress in ("2bit", "1bit"):
-            return self._all_gather_packed(2 if compress == "2bit" else 1, widen, recv, out)
+            return self._all_gather_packed(2 if compress == "2bit" else 1, widen, recv, out, unpack)
+        if not unpack:
+            raise ValueError("unpack=False is for the packed forms (compress='2bit' / '1bit')")
         local = self._slab_tensor()
         if compress:
             if self.dtype != np.int32:
@@ -313,8 +347,18 @@ class ShardedBackprojection:
         its slab to the host and the host tensors are gathered."""
         import torch
         import torch.distributed as dist
+        two_bit = (self.dtype == np.int32 and float(self.default_value) in (-1.0, 0.0, 1.0)
+                   and compress in (None, "2bit") and hasattr(self._engine, "get_values_packed"))
+        if compress == "2bit" and not two_bit:
+            raise ValueError("the 2-bit wire carries carve labels of a default_value of -1, 0 or 1")
         if self.world_size == 1 and not self.force_collective:
+            if two_bit and self._on_gpu and int(np.prod(self.shape)) >= (1 << 24):
+                out = np.empty(self.shape, dtype=np.int32)
+                self._engine.get_values_wire2(out.reshape(-1))
+                return out
             return np.ascontiguousarray(self.get_local()).reshape(self.shape)
+        if two_bit:
+            return self._gather_to_host_2bit(dst)
         if compress is None:
             compress = self.dtype == np.int32 and -128 <= int(self.default_value) <= 127
         pad = self._planes_max() * self.shape[1] * self.shape[2]
@@ -335,6 +379,41 @@ class ShardedBackprojection:
             return None
         full = self._land(recv).cpu().numpy()
         return full.astype(self.dtype) if full.dtype != self.dtype else full
+
+    def _gather_to_host_2bit(self, dst):
+        """Three-state labels to ``dst``'s host memory over the 2-bit wire: every rank's planes packed on its device
+        (``sc_values_packed``), gathered to ``dst``'s GPU (RCCL; gloo: through the hosts), ONE PCIe copy of 1/16 of
+        the grid's bytes, and the host pool widens and interleaves the planes into the int32 grid of cl.py:229-232
+        (``sc_widen_labels2_ranks``)."""
+        import torch
+        import torch.distributed as dist
+        W = self.world_size
+        rank_bytes = self.packed_rank_bytes(2)
+        on_device = self._on_gpu and dist.get_backend() != "gloo"
+        if self._on_gpu:
+            ptr, nbytes = self._engine.values_packed(2)
+            if on_device:
+                tstream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+                self._engine.order_before(tstream)
+                local = torch.as_tensor(_DeviceBuffer(ptr, nbytes, "|u1"), device=f"cuda:{self.device}")
+            else:
+                local = torch.from_numpy(np.ascontiguousarray(self._engine.get_values_packed(2)).view(np.uint8))
+        else:
+            local = torch.from_numpy(np.ascontiguousarray(self._engine.get_values_packed(2)).view(np.uint8))
+        send = local
+        if local.numel() != rank_bytes:
+            send = torch.zeros(rank_bytes, dtype=torch.uint8, device=local.device)
+            send[: min(local.numel(), rank_bytes)] = local[:rank_bytes]
+        recv = None
+        if self.rank == dst:
+            recv = torch.empty(rank_bytes * W, dtype=torch.uint8, device=send.device)
+        dist.gather(send, list(recv.view(W, rank_bytes).unbind(0)) if recv is not None else None, dst=dst)
+        if on_device:
+            self._engine.order_after(tstream)  # the engine's next pack waits for the collective's read
+        if self.rank != dst:
+            return None
+        host = recv.cpu().numpy() if recv.is_cuda else recv.numpy()
+        return nat.widen_labels2_ranks(host, rank_bytes, W, self.partition, self.shape)
 
     def close(self):
         if self._engine is not None:

@@ -98,6 +98,8 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
                                                         (3, (17, 9, 8), "carving", "cyclic"),
                                                         (3, (17, 9, 8), "carving", "slab"),
                                                         (2, (16, 10, 12), "carving", "slab"),
+                                                        (3, (11, 8, 16), "carving", "cyclic"),   # planes of whole packed words
+                                                        (2, (10, 16, 32), "carving", "slab"),
                                                         (2, (9, 8, 12), "averaging", "cyclic")])
 def test_gloo_sharded_equals_single(world, shape, mode, partition):
     _, origin, vs, views = scene(tuple(shape), 5, "plant")
@@ -168,6 +170,19 @@ def _gpu_worker(rank, world, port, shape, partition, q):
         assert p2.is_cuda and p2.dtype == torch.int8
         p2w = sb.all_gather(compress="2bit")
         p1 = sb.all_gather(compress="1bit", widen=False)
+        # the assembled grid in its packed form, read by vol2pcd as it is (no full-size grid is written)
+        from plant3dvision_amd import proc3d
+        clouds = {}
+        for comp in ("1bit", "2bit"):
+            pg = sb.all_gather(compress=comp, unpack=False)
+            assert pg.recv.is_cuda and pg.bits == (1 if comp == "1bit" else 2)
+            assert np.array_equal(pg.unpack().cpu().numpy(), p1.cpu().numpy() if comp == "1bit" else p2.cpu().numpy())
+            pc = proc3d.vol2pcd(pg, origin, vs, 0.0, as_open3d=False)
+            clouds[comp] = (np.asarray(pc.points), np.asarray(pc.normals))
+        ref = proc3d.vol2pcd((full.cpu().numpy() == 1).astype(np.uint8), origin, vs, 0.0, as_open3d=False)
+        for comp, (pts, nrm) in clouds.items():
+            assert np.array_equal(pts, np.asarray(ref.points)) and np.array_equal(nrm, np.asarray(ref.normals)), comp
+        assert len(ref.points) > 0
         q.put({"rank": rank, "ag": full.cpu().numpy(), "ag8n": narrow.cpu().numpy(),
                "ag2n": p2.cpu().numpy(), "ag2": p2w.cpu().numpy(), "ag1": p1.cpu().numpy(),
                "ar": sb.all_reduce().cpu().numpy(), "host": sb.gather_to_host(dst=0)})
@@ -266,8 +281,16 @@ def test_collectives_through_rccl_with_a_process_group_of_one(gpu_device):
             p1 = sb.all_gather(compress="1bit", widen=False)
             assert np.array_equal(p1.cpu().numpy(), (want == 1).astype(np.int8))
             assert np.array_equal(sb.all_reduce().cpu().numpy(), want)
-            host = sb.gather_to_host(dst=0)
+            host = sb.gather_to_host(dst=0)  # the 2-bit wire + sc_widen_labels2_ranks
             assert host.dtype == np.int32 and np.array_equal(host, want)
+            host8 = sb.gather_to_host(dst=0, compress=True)  # the int8 route of rounds 2-3
+            assert host8.dtype == np.int32 and np.array_equal(host8, want)
+            from plant3dvision_amd import proc3d
+            pg = sb.all_gather(compress="1bit", unpack=False)
+            pc = proc3d.vol2pcd(pg, origin, vs, 0.0, as_open3d=False)
+            ref = proc3d.vol2pcd((want == 1).astype(np.uint8), origin, vs, 0.0, as_open3d=False)
+            assert len(ref.points) > 0 and np.array_equal(np.asarray(pc.points), np.asarray(ref.points))
+            assert np.array_equal(np.asarray(pc.normals), np.asarray(ref.normals))
             dist.barrier()
             sb.close()
     finally:

@@ -77,3 +77,25 @@ def test_widening_at_every_alignment_and_tail():
             out = buf[off:off + n]
             nat.widen_labels2(words, n, out=out)
             assert np.array_equal(out, lab), (n, off)
+
+
+@pytest.mark.parametrize("partition", ["cyclic", "slab"])
+@pytest.mark.parametrize("world,shape", [(1, (5, 4, 8)), (2, (16, 10, 12)), (3, (17, 9, 8)), (3, (11, 8, 16)), (4, (9, 16, 32)), (8, (64, 16, 16))])
+def test_ranks_packed_planes_widen_into_one_grid_in_global_order(world, shape, partition):
+    """The host end of gather_to_host: every rank's planes at 2 bits per label, rank-major and padded to the largest
+    plane count, into the int32 grid of cl.py:229-232 -- even and uneven plane counts, planes of whole packed words
+    and planes that start in the middle of one."""
+    from plant3dvision_amd import _native as nat
+    from plant3dvision_amd.sharded import rank_planes
+    rng = np.random.default_rng(world * 100 + shape[0])
+    grid = rng.integers(-1, 2, shape).astype(np.int32)
+    plane = shape[1] * shape[2]
+    pmax = max(len(rank_planes(shape[0], world, r, partition)) for r in range(world))
+    rank_bytes = nat.packed_bytes(pmax * plane, 2)
+    buf = np.zeros(world * rank_bytes // 4, dtype=np.uint32)
+    for r in range(world):
+        mine = grid[list(rank_planes(shape[0], world, r, partition))].reshape(-1)
+        w = pack_labels_np(mine, 2)
+        buf[r * rank_bytes // 4: r * rank_bytes // 4 + w.size] = w
+    got = nat.widen_labels2_ranks(buf, rank_bytes, world, partition, shape)
+    assert got.dtype == np.int32 and np.array_equal(got, grid)
