@@ -541,6 +541,17 @@ def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
            "steps": steps, "ms_per_step": dt / steps * 1e3,
            "value_with_assembly": n_total * V * steps / dt / 1e6,
            "bytes_received_per_rank": int(recv2.numel())}
+    # the same without the unpack: the assembled grid stays packed (a PackedGrid, what vol2pcd reads as it is)
+    def stepp():
+        eng.clear()
+        eng.process_views_device(*call, nat.SC_MASK_U8)
+        return sb.all_gather(compress="2bit", recv=recv2, unpack=False)
+
+    np_ = max(2, steps // 2)
+    dtp = run(stepp, np_)
+    res["packed_grid"] = {"ms_per_step": dtp / np_ * 1e3, "steps": np_, "value": n_total * V * np_ / dtp / 1e6,
+                          "note": "carve + all-gather at 2 bits per label, the grid left packed on every GPU "
+                                  "(ShardedBackprojection.all_gather(unpack=False) -> proc3d.vol2pcd reads it directly)"}
     del recv2
     # the int8 wire form (round 2), a few steps, for comparison
     pad = sb._planes_max() * sb.shape[1] * sb.shape[2]
@@ -557,13 +568,23 @@ def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
     res["int8_wire"] = {"ms_per_step": dt8 / n8 * 1e3, "steps": n8, "bytes_received_per_rank": int(recv.numel())}
     del recv, out, out8
     if host:
+        dest = np.zeros(sb.shape, dtype=np.int32) if dist.get_rank() == 0 else None  # (its pages touched: see below)
+        sb.gather_to_host(dst=0, out=dest)  # once untimed: the engine's packed buffer, RCCL's first gather
         dist.barrier()
         t0 = time.perf_counter()
-        hostvol = sb.gather_to_host(dst=0)
+        hostvol = sb.gather_to_host(dst=0, out=dest)
         dist.barrier()
         res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
-        res["gather_to_host_note"] = "labels to rank 0's GPU over the collective as int8, one PCIe copy, widened to int32 on the host"
-        del hostvol
+        dist.barrier()
+        t0 = time.perf_counter()
+        fresh = sb.gather_to_host(dst=0)
+        dist.barrier()
+        res["gather_to_host_fresh_array_ms"] = maxed(time.perf_counter() - t0) * 1e3
+        res["gather_to_host_note"] = ("labels at 2 bits each to rank 0's GPU over the collective, one PCIe copy of 1/16 of the "
+                                      "grid's bytes, widened and interleaved into the int32 grid by the host pool "
+                                      "(sc_widen_labels2_ranks); into an array whose pages have been touched -- a fresh "
+                                      "np.empty pays first-touch page faults for 4 bytes per voxel (gather_to_host_fresh_array_ms)")
+        del hostvol, fresh, dest
     return res
 
 

@@ -31,23 +31,34 @@ struct PixelBox {
 
 __device__ __forceinline__ PixelBox rect_box(const ViewDesc &d, const GridDesc &g, float x, int j0, int j1, int k0, int k1) {
     PixelBox bx{0.0f, 0.0f, 0.0f, 0.0f, false, false};
-    float ez = 0.0f, ex = 0.0f, ey = 0.0f, qxm = 0.0f, qym = 0.0f;
+    // The four corners (j0 | j1) x (k0 | k1) share their products: per row of R one with x, two with y, two with z
+    // -- 15 multiplications where corner by corner there are 36 -- and every corner's sums are the reference's own,
+    // in its order, ((R0 x + R1 y) + R2 z) + t (backprojection.c:11,17,18).  The rounding-error bound of a row,
+    // 8 x its worst case, is (|R0 x| + |R1 y| + |R2 z| + |t|) 2^-19 at the corner where that is largest: float
+    // addition is monotone in each operand, so that is the sum of the larger |R1 y| and the larger |R2 z| -- the
+    // same number the four sums' maximum gives, for a quarter of the additions.
+    const float y0 = g.oy + (float)j0 * g.vs, y1 = g.oy + (float)j1 * g.vs;  // :72
+    const float z0 = g.oz + (float)k0 * g.vs, z1 = g.oz + (float)k1 * g.vs;  // :73
+    float p[3][4], e[3];  // rows: depth, x, y; corners: (y0,z0) (y0,z1) (y1,z0) (y1,z1)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int q = r == 0 ? 6 : (r == 1 ? 0 : 3);
+        const float tt = d.t[r == 0 ? 2 : (r == 1 ? 0 : 1)];
+        const float a = d.R[q] * x, b0 = d.R[q + 1] * y0, b1 = d.R[q + 1] * y1, c0 = d.R[q + 2] * z0, c1 = d.R[q + 2] * z1;
+        const float s0 = a + b0, s1 = a + b1;
+        p[r][0] = (s0 + c0) + tt;
+        p[r][1] = (s0 + c1) + tt;
+        p[r][2] = (s1 + c0) + tt;
+        p[r][3] = (s1 + c1) + tt;
+        e[r] = (((fabsf(a) + fmaxf(fabsf(b0), fabsf(b1))) + fmaxf(fabsf(c0), fabsf(c1))) + fabsf(tt)) * 0x1p-19f;
+    }
+    const float ez = e[0], ex = e[1], ey = e[2];
+    float qxm = 0.0f, qym = 0.0f;
     float pzmin = INFINITY, pzmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool nan = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float y = g.oy + (float)((c >> 1) ? j1 : j0) * g.vs;  // backprojection.c:72
-        float z = g.oz + (float)((c & 1) ? k1 : k0) * g.vs;   // :73
-        float rzx = d.R[6] * x, rzy = d.R[7] * y, rzz = d.R[8] * z;
-        float rxx = d.R[0] * x, rxy = d.R[1] * y, rxz = d.R[2] * z;
-        float ryx = d.R[3] * x, ryy = d.R[4] * y, ryz = d.R[5] * z;
-        float pz = ((rzx + rzy) + rzz) + d.t[2];
-        float px = ((rxx + rxy) + rxz) + d.t[0];
-        float py = ((ryx + ryy) + ryz) + d.t[1];
-        // absolute rounding-error bounds of the three dot products (8x the worst case)
-        ez = fmaxf(ez, (fabsf(rzx) + fabsf(rzy) + fabsf(rzz) + fabsf(d.t[2])) * 0x1p-19f);
-        ex = fmaxf(ex, (fabsf(rxx) + fabsf(rxy) + fabsf(rxz) + fabsf(d.t[0])) * 0x1p-19f);
-        ey = fmaxf(ey, (fabsf(ryx) + fabsf(ryy) + fabsf(ryz) + fabsf(d.t[1])) * 0x1p-19f);
+        const float pz = p[0][c], px = p[1][c], py = p[2][c];
         // an ESTIMATE of the voxel kernels' correctly rounded quotients is enough here (v_rcp_f32
         // is good to 1 ulp, the product adds half of one); the slack below pays for it
         float rz = __builtin_amdgcn_rcpf(pz);

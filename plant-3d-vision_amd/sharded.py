@@ -337,14 +337,17 @@ class ShardedBackprojection:
                 dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full
 
-    def gather_to_host(self, dst=0, compress=None):
+    def gather_to_host(self, dst=0, compress=None, out=None):
         """Full grid as a NumPy array of the reference's dtype on rank ``dst`` (None elsewhere) --
         what ``get_values`` (cl.py:229-232) hands a ``Voxels`` run.
 
         RCCL: the slabs travel to ``dst``'s GPU over xGMI (``dist.gather`` of tensors; carve labels
         as int8 unless ``compress=False``), are put in global order there by the same strided copy
         as ``all_gather``, and cross PCIe once.  gloo (CPU rehearsal and tests): each rank copies
-        its slab to the host and the host tensors are gathered."""
+        its slab to the host and the host tensors are gathered.
+        Carve labels of a default value of -1 / 0 / 1 take the 2-bit wire instead (``_gather_to_host_2bit``);
+        ``out``: an int32 array of the grid's size to widen into on ``dst`` -- one whose pages have been touched
+        takes 512^3 labels in ~4 ms, a fresh ``np.empty`` ~30 (first-touch page faults, not the transfer)."""
         import torch
         import torch.distributed as dist
         two_bit = (self.dtype == np.int32 and float(self.default_value) in (-1.0, 0.0, 1.0)
@@ -353,12 +356,13 @@ class ShardedBackprojection:
             raise ValueError("the 2-bit wire carries carve labels of a default_value of -1, 0 or 1")
         if self.world_size == 1 and not self.force_collective:
             if two_bit and self._on_gpu and int(np.prod(self.shape)) >= (1 << 24):
-                out = np.empty(self.shape, dtype=np.int32)
+                if out is None or out.dtype != np.int32 or out.size != int(np.prod(self.shape)) or not out.flags["C_CONTIGUOUS"]:
+                    out = np.empty(self.shape, dtype=np.int32)
                 self._engine.get_values_wire2(out.reshape(-1))
-                return out
+                return out.reshape(self.shape)
             return np.ascontiguousarray(self.get_local()).reshape(self.shape)
         if two_bit:
-            return self._gather_to_host_2bit(dst)
+            return self._gather_to_host_2bit(dst, out)
         if compress is None:
             compress = self.dtype == np.int32 and -128 <= int(self.default_value) <= 127
         pad = self._planes_max() * self.shape[1] * self.shape[2]
@@ -380,7 +384,7 @@ class ShardedBackprojection:
         full = self._land(recv).cpu().numpy()
         return full.astype(self.dtype) if full.dtype != self.dtype else full
 
-    def _gather_to_host_2bit(self, dst):
+    def _gather_to_host_2bit(self, dst, out=None):
         """Three-state labels to ``dst``'s host memory over the 2-bit wire: every rank's planes packed on its device
         (``sc_values_packed``), gathered to ``dst``'s GPU (RCCL; gloo: through the hosts), ONE PCIe copy of 1/16 of
         the grid's bytes, and the host pool widens and interleaves the planes into the int32 grid of cl.py:229-232
@@ -413,7 +417,9 @@ class ShardedBackprojection:
         if self.rank != dst:
             return None
         host = recv.cpu().numpy() if recv.is_cuda else recv.numpy()
-        return nat.widen_labels2_ranks(host, rank_bytes, W, self.partition, self.shape)
+        if out is not None and (out.dtype != np.int32 or out.size != int(np.prod(self.shape)) or not out.flags["C_CONTIGUOUS"]):
+            out = None
+        return nat.widen_labels2_ranks(host, rank_bytes, W, self.partition, self.shape, out=out)
 
     def close(self):
         if self._engine is not None:
