@@ -78,6 +78,10 @@
                                      page-locked ring and are packed on the device (round 1-3 path)                 */
 #define SC_OPT_HOST_THREADS 40    /* threads of the library's host pool (mask bits, label widening): 0 = default,
                                      min(8, hardware threads / 2).  Process-wide; before the pool's first use        */
+#define SC_OPT_LDS_TILES 41       /* 0 (default) / 1: the dense stage loads the window of mask words a unit's 256 voxels
+                                     project onto into LDS once per view and the voxels read their words from there --
+                                     the north star's "LDS-staged mask tiles per wavefront".  Measured slower on every
+                                     scene: the gathers hit L2 and the stage is bound by its arithmetic */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

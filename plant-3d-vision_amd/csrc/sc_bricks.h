@@ -45,11 +45,100 @@ __device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db
     }
 }
 
+// EXPERIMENT (SC_OPT_LDS_TILES, off by default): the north star's "LDS-staged mask tiles per
+// wavefront".  The wavefront first projects its 256 voxels (a unit: 16 columns x 16 voxels), takes the window of
+// mask words their pixels fall on -- rows vmin .. vmax of tile columns tmin .. tmax, from the pixels themselves, no
+// bound needed --, loads that window ONCE, one word per lane, into its LDS buffer, and every voxel then reads its
+// word from LDS instead of gathering it from global memory (4 ds_read per lane and view in place of 4 global
+// loads, 1 global load per lane and view in place of 4).  A window of more than 64 words, or wider than two tile
+// columns, takes the plain gathers.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ void staged_words(const ViewDesc &d, const int (&u)[4], const int (&v)[4], const bool (&ok)[4],
+                                             uint32_t *buf, uint32_t lane, uint32_t (&w)[4]) {
+    int vmin = 0x7fffffff, vmax = -1, tmin = 0x7fffffff, tmax = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (ok[e]) {
+            vmin = min(vmin, v[e]); vmax = max(vmax, v[e]);
+            tmin = min(tmin, u[e] >> 5); tmax = max(tmax, u[e] >> 5);
+        }
+    }
+    vmin = __builtin_amdgcn_readfirstlane(wave_min_i32(vmin));
+    vmax = __builtin_amdgcn_readfirstlane(wave_max_i32(vmax));
+    tmin = __builtin_amdgcn_readfirstlane(wave_min_i32(tmin));
+    tmax = __builtin_amdgcn_readfirstlane(wave_max_i32(tmax));
+    const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
+    const int nrows = vmax - vmin + 1, ntx = tmax - tmin + 1;
+    if (vmax < 0) {  // nobody in the picture
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = 0u;
+        return;
+    }
+    if (ntx > 2 || nrows * ntx > 64) {  // wave-uniform: too wide a window, the plain gathers
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u[e], v[e], d.tiles_x) : 0u);
+        return;
+    }
+    const int r = ntx == 1 ? (int)lane : (int)(lane >> 1), c = ntx == 1 ? 0 : (int)(lane & 1u);
+    if (r < nrows) buf[lane] = load_mask_word(bits, mask_word_index((tmin + c) * 32, vmin + r, d.tiles_x));
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = ok[e] ? buf[(v[e] - vmin) * ntx + ((u[e] >> 5) - tmin)] : 0u;
+    __builtin_amdgcn_wave_barrier();  // (the buffer is free for the next view)
+}
+
+__device__ __forceinline__ void two_views_lds(const ViewDesc &da, const ViewDesc &db, bool two, float x, float y,
+                                              const float (&z)[4], int32_t (&lab)[4], uint32_t &alive, uint32_t *buf,
+                                              uint32_t lane) {
+    const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
+    const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
+    bool oka[4], okb[4];
+    uint32_t wa[4], wb[4];
+    int ua[4], va[4], ub[4], vb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool live = (alive >> e) & 1u;
+        oka[e] = project(aax, aay, aaz, z[e], da, ua[e], va[e]) & live;
+        okb[e] = project(bax, bay, baz, z[e], db, ub[e], vb[e]) & live & two;
+    }
+    staged_words(da, ua, va, oka, buf, lane, wa);
+    staged_words(db, ub, vb, okb, buf + 64, lane, wb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (oka[e]) {
+            if (((wa[e] >> (ua[e] & 31)) & 1u) == 0) {  // :79
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {  // :81
+                lab[e] = 1;
+            }
+        }
+        if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
+            if (((wb[e] >> (ub[e] & 31)) & 1u) == 0) {
+                lab[e] = -1;
+                alive &= ~(1u << e);
+            } else if (lab[e] == 0) {
+                lab[e] = 1;
+            }
+        }
+    }
+}
+
 template <bool FRESH>
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
-                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0) {
+                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0,
+                                             uint32_t *lds_tiles = nullptr) {  // non-null: the LDS-staging experiment
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
     // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
@@ -95,7 +184,8 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         const bool two = vi + 1 < nviews;      // wave-uniform
         const ViewDesc da = views[vi];
         const ViewDesc db = views[two ? vi + 1 : vi];
-        two_views(da, db, two, x, y, z, lab, alive);
+        if (lds_tiles != nullptr) two_views_lds(da, db, two, x, y, z, lab, alive, lds_tiles, lane);  // wave-uniform
+        else two_views(da, db, two, x, y, z, lab, alive);
     }
 
     if (vec) {
@@ -269,7 +359,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              const uint32_t *__restrict__ live,
                                                              ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
-                                                             uint32_t parity, int nverd_arg, uint32_t verd_max_live) {
+                                                             uint32_t parity, int nverd_arg, uint32_t verd_max_live,
+                                                             int lds_tiles) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
@@ -294,6 +385,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     // the brick is live because a 32x32 tile under it touches the plant, the unit lies beside it -- and projects the
     // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
     // tickets keep every wavefront busy whatever the bricks hold.)
+    __shared__ uint32_t s_tiles[kBlock / 64][128];  // the LDS-staging experiment: two views' windows per wavefront
+    uint32_t *my_tiles = lds_tiles ? s_tiles[threadIdx.x >> 6] : nullptr;
     const uint32_t nlive = ctl->nlive[parity];
     // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
     const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
@@ -370,7 +463,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u, my_tiles);
 #ifdef SC_TRACE_DENSE
             ++tr_units;
 #endif

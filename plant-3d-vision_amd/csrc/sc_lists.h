@@ -16,6 +16,28 @@ struct UnitItems {
 // carve_special_kernel): the FIRST survivor stage takes them as they are -- a unit's 256 voxels as chunks of its
 // own, the labels read where a list chunk reads its entries -- and appends what is left alive to its output list
 // like any other survivor.  Nobody copies them anywhere in between.
+// Room for `total` more entries in a sub-list, or 0xffffffff.  A reservation that does not fit leaves the counter as
+// it was (compare-and-swap, lane 0): the counter never passes the capacity and every entry below it has a writer, so
+// the stage that reads the list reads nothing that was not written.  (The dense stage appends with a plain add and,
+// when that runs over, raises the overflow flag, which makes every reader ignore the lists altogether; the kernels
+// behind it have no such way out -- a plain add that failed would leave a hole below the capacity.)
+__device__ __forceinline__ uint32_t list_reserve(uint32_t *counter, uint32_t total, uint32_t cap, uint32_t lane) {
+    uint32_t base = 0xffffffffu;
+    if (lane == 0) {
+        uint32_t old = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {  // ends: every turn either reserves, gives up, or has seen another reservation go through
+            if (old > cap || total > cap - old) break;
+            const uint32_t seen = atomicCAS(counter, old, old + total);
+            if (seen == old) {
+                base = old;
+                break;
+            }
+            old = seen;
+        }
+    }
+    return __shfl(base, 0);
+}
+
 struct UnitSpill {
     const uint32_t *units;  // null: no bulk list.  [kSub][cap] unit ids, counts in ctl->count[3]
     uint32_t cap, floor;
@@ -259,13 +281,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 tot += (uint32_t)__popcll(b[p]);
             }
             if (tot != 0) {  // wave-uniform
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctl->count[sout][s].n, tot);
-                base = __shfl(base, 0);
                 // The survivors of sub-list s do not outnumber its entries, but spilled bulk units append here too:
-                // without room (the count stays beyond the capacity, the readers clamp it) this wavefront takes its
-                // chunk through the remaining views itself -- these voxels are on no list, nobody else touches them
-                noroom = base + tot > subcap;
+                // without room (list_reserve leaves the counter alone) this wavefront takes its chunk through the
+                // remaining views itself -- these voxels are on no list, nobody else touches them
+                uint32_t base = list_reserve(&ctl->count[sout][s].n, tot, subcap, lane);
+                noroom = base == 0xffffffffu;
                 if (!noroom) {
                     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -575,24 +595,20 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (item_cost * 16u <= uj.bias * list_cost) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctl->count[4][sub].n, nitems);
-        pos = __shfl(pos, 0);
-        if (pos + nitems <= uj.icap) {
+        const uint32_t pos = list_reserve(&ctl->count[4][sub].n, nitems, uj.icap, lane);
+        if (pos != 0xffffffffu) {
             if (mine)
                 uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
                     make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
             return;
         }
-        // (no room: the count stays beyond the capacity, the reader clamps it; the voxels take the list)
+        // (no room among the items -- the counter is left as it was, no slot below it goes unwritten: the voxels take the list)
     }
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->count[0][sub].n, nalive);
-    base = __shfl(base, 0);
-    if (base + nalive > uj.subcap) {
-        // no room in the sub-list (its count stays beyond the capacity, the readers clamp it): this wavefront takes
-        // the unit through every view of the batch itself.  The overflow flag is the dense stage's alone -- the
-        // blocks of this kernel read it when they start -- and views applied twice change nothing.
+    const uint32_t base = list_reserve(&ctl->count[0][sub].n, nalive, uj.subcap, lane);
+    if (base == 0xffffffffu) {
+        // no room in the sub-list (list_reserve leaves its counter alone): this wavefront takes the unit through
+        // every view of the batch itself.  The overflow flag is the dense stage's alone -- the blocks of this
+        // kernel read it when they start -- and views applied twice change nothing.
         late_unit<false>(uj.labels, g, uj.views, uj.nall, 0, unit, uj.bricks_y, uj.bricks_z, lane);
         return;
     }

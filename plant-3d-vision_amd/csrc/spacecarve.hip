@@ -197,6 +197,7 @@ struct sc_engine {
 
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
+    int64_t lds_tiles = 0;  // the dense stage stages each unit's window of mask words in LDS (experiment)
     int64_t host_pack = 1;
     struct HostBits {
         char *pin = nullptr, *dev = nullptr;
@@ -1224,11 +1225,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -1725,6 +1726,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_BULK_FLOOR:
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
             e->bulk_floor = value;
+            return SC_OK;
+        case SC_OPT_LDS_TILES:
+            e->lds_tiles = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_HOST_PACK:
             if (!e->hp_pending.empty()) return fail(SC_ERR_STATE, "host-packed views are pending: flush first");

@@ -135,6 +135,35 @@ def test_survivor_list_overflow_takes_the_dense_pass(gpu_device, kind, shape, v,
     e.close()
 
 
+@pytest.mark.parametrize("device_masks", [True, False])
+def test_failed_reservations_leave_no_holes_in_the_lists(gpu_device, device_masks):
+    """Fuzz case 878 of round 4 (a GPU memory fault before the fix): all-foreground masks through a wide-angle
+    camera whose pictures the tall grid sticks out of, every unit with a voxel alive on the bulk list, two entries of
+    room per survivor sub-list.  The units' voxels find no room on the list; a plain atomic add that fails leaves
+    the counter beyond the capacity and the slots below it unwritten, and the final stage then read those slots as
+    entries.  Reservations are compare-and-swap now (list_reserve): a counter never passes its capacity."""
+    kw = dict(radius_factor=0.8, tilt_deg=0.0, voxel_size=1000.0, width=48, height=71, fx=24.813724957700188,
+              fy=131.65757157747763, cx=26.850375195941375, cy=22.261666802611273)
+    sh, origin, vs, views = scene((11, 13, 58), 15, "solid", **kw)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
+    assert 0 < (want == 0).sum() < want.size  # part of the grid is outside every picture
+    opts = {"SC_OPT_DENSE_VIEWS": 3, "SC_OPT_STAGE1_VIEWS": 64, "SC_OPT_DEFER_SHARE": 5, "SC_OPT_COMPACT": 1,
+            "SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_STAGE1_VOXELS": 1, "SC_OPT_VIEW_BRICK": 1,
+            "SC_OPT_STAGE1_LIST_BLOCKS": 1280, "SC_OPT_BULK_MIN": 1, "SC_OPT_ITEM_BIAS": 0, "SC_OPT_UNIT_CULL": 0,
+            "SC_OPT_LIST_CAP": 2}
+    for stage1 in (64, 4):  # a single (final) list stage, and two
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+        for k, v in opts.items():
+            e.set_option(getattr(nat, k), v)
+        e.set_option(nat.SC_OPT_STAGE1_VIEWS, stage1)
+        for rnd in range(2):
+            ptr = _batch(e, views, not device_masks)
+            assert np.array_equal(e.get_values(), want), (device_masks, stage1, rnd, histogram3(want))
+            if ptr is not None:
+                e.dev_free(ptr)
+        e.close()
+
+
 @pytest.mark.parametrize("nviews", [6, 7, 10, 11, 13])
 @pytest.mark.parametrize("kind,shape", [("dense", (9, 32, 192)), ("plant", (12, 48, 128))])
 def test_bulk_units_whatever_the_number_of_list_stages(gpu_device, nviews, kind, shape):
@@ -260,6 +289,8 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_UNIT_CULL": 0},                                              # no unit verdicts in the dense stage
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},  # ... asked whatever the tiles settled
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
+    {"SC_OPT_LDS_TILES": 1},                                              # the dense stage's mask words staged in LDS
+    {"SC_OPT_LDS_TILES": 1, "SC_OPT_DENSE_VIEWS": 3, "SC_OPT_UNIT_CULL": 0},
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
                                         ("dense", (14, 48, 192)),    # a bulky object: whole-brick masks at work
