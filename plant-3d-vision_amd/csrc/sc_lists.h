@@ -16,23 +16,16 @@ struct UnitItems {
 // carve_special_kernel): the FIRST survivor stage takes them as they are -- a unit's 256 voxels as chunks of its
 // own, the labels read where a list chunk reads its entries -- and appends what is left alive to its output list
 // like any other survivor.  Nobody copies them anywhere in between.
-// Room for `total` more entries in a sub-list, or 0xffffffff.  A reservation that does not fit leaves the counter as
-// it was (compare-and-swap, lane 0): the counter never passes the capacity and every entry below it has a writer, so
-// the stage that reads the list reads nothing that was not written.  (The dense stage appends with a plain add and,
-// when that runs over, raises the overflow flag, which makes every reader ignore the lists altogether; the kernels
-// behind it have no such way out -- a plain add that failed would leave a hole below the capacity.)
-__device__ __forceinline__ uint32_t list_reserve(uint32_t *counter, uint32_t total, uint32_t cap, uint32_t lane) {
-    uint32_t base = 0xffffffffu;
+// Room for `total` more entries in a sub-list, or 0xffffffff (see ListCounter: the first reservation that fails
+// marks where the written entries end; the dense stage's own appends raise the overflow flag instead, which makes
+// every reader ignore the lists altogether).
+__device__ __forceinline__ uint32_t list_reserve(ListCounter *counter, uint32_t total, uint32_t cap, uint32_t lane) {
+    uint32_t base = 0;
     if (lane == 0) {
-        uint32_t old = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {  // ends: every turn either reserves, gives up, or has seen another reservation go through
-            if (old > cap || total > cap - old) break;
-            const uint32_t seen = atomicCAS(counter, old, old + total);
-            if (seen == old) {
-                base = old;
-                break;
-            }
-            old = seen;
+        base = atomicAdd(&counter->n, total);
+        if (base > cap || total > cap - base) {
+            atomicMax(&counter->cut, ~min(base, cap));
+            base = 0xffffffffu;
         }
     }
     return __shfl(base, 0);
@@ -89,7 +82,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     const uint32_t bid = bx;
     constexpr uint32_t CH = 64u * P;
     {
-        uint32_t c = (min(ctl->count[sin][tid].n, subcap) + CH - 1u) / CH;  // kSub == kBlock
+        uint32_t c = (list_count(ctl->count[sin][tid], subcap) + CH - 1u) / CH;  // kSub == kBlock
         if (tid == 0) pref[0] = 0;
         pref[tid + 1] = c;
         __syncthreads();
@@ -122,7 +115,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         if (ipref[kSub] < us.floor) uchunks = ipref[kSub] * kUnitParts;  // (else the special kernel has dealt with them)
     }
     if (with_items) {
-        const uint32_t c = min(ctl->count[4][tid].n, ui.cap);
+        const uint32_t c = list_count(ctl->count[4][tid], ui.cap);
         if (tid == 0) ipref[0] = 0;
         ipref[tid + 1] = c;
         __syncthreads();
@@ -177,7 +170,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             if (pf[mid] <= key) lo = mid; else hi = mid;
         }
         const uint32_t s = lo;
-        const uint32_t cnt = min(ctl->count[sin][s].n, subcap);
+        const uint32_t cnt = list_count(ctl->count[sin][s], subcap);
         // P voxels per lane: the descriptor traffic and the scalar bookkeeping of a view are shared,
         // and a lane has P * U independent projection chains and gathers in flight
         uint32_t idx[P];
@@ -282,9 +275,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             }
             if (tot != 0) {  // wave-uniform
                 // The survivors of sub-list s do not outnumber its entries, but spilled bulk units append here too:
-                // without room (list_reserve leaves the counter alone) this wavefront takes its chunk through the
+                // without room (the counter's `cut` marks where the written entries end) this wavefront takes its chunk through the
                 // remaining views itself -- these voxels are on no list, nobody else touches them
-                uint32_t base = list_reserve(&ctl->count[sout][s].n, tot, subcap, lane);
+                uint32_t base = list_reserve(&ctl->count[sout][s], tot, subcap, lane);
                 noroom = base == 0xffffffffu;
                 if (!noroom) {
                     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -595,18 +588,18 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     const uint32_t item_cost = halves * ((nneed + 1u) / 2u) + nitems;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (item_cost * 16u <= uj.bias * list_cost) {
-        const uint32_t pos = list_reserve(&ctl->count[4][sub].n, nitems, uj.icap, lane);
+        const uint32_t pos = list_reserve(&ctl->count[4][sub], nitems, uj.icap, lane);
         if (pos != 0xffffffffu) {
             if (mine)
                 uj.items[(size_t)sub * uj.icap + pos + (uint32_t)__popcll(im & below)] =
                     make_uint4(unit * 2u + hq, wq * 64u, (uint32_t)mymask, (uint32_t)(mymask >> 32));
             return;
         }
-        // (no room among the items -- the counter is left as it was, no slot below it goes unwritten: the voxels take the list)
+        // (no room among the items -- the counter's `cut` marks where the written ones end: the voxels take the list)
     }
-    const uint32_t base = list_reserve(&ctl->count[0][sub].n, nalive, uj.subcap, lane);
+    const uint32_t base = list_reserve(&ctl->count[0][sub], nalive, uj.subcap, lane);
     if (base == 0xffffffffu) {
-        // no room in the sub-list (list_reserve leaves its counter alone): this wavefront takes the unit through
+        // no room in the sub-list (its counter's `cut` marks where the written entries end): this wavefront takes the unit through
         // every view of the batch itself.  The overflow flag is the dense stage's alone -- the blocks of this
         // kernel read it when they start -- and views applied twice change nothing.
         late_unit<false>(uj.labels, g, uj.views, uj.nall, 0, unit, uj.bricks_y, uj.bricks_z, lane);
