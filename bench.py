@@ -50,9 +50,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # averaging kernel has been measured ABOVE the 4-cycle figure on this chip (44 T lane-ops/s, 3.5 cycles per VALU
 # instruction per SIMD, profiles/r02_avg_sq_counters.json), so the 2-cycle figure is the ceiling used here.
 VALU_PEAK_TLANEOPS = 78.6
-# VALU lane-ops the `average` kernel executes per voxel.view: SQ_INSTS_VALU x 64 / (N x V) of a run in which
-# every (brick, view) pair is projected (profiles/r02_avg_sq_counters.json); SURVEY 8d estimated ~50
-LANE_OPS_PER_VOXEL_VIEW = 52.7
+# VALU lane-ops the `average` kernel executes per voxel.view: SQ_INSTS_VALU x 64 / (N x V) of a run in which every
+# (brick, view) pair is projected (random grey masks), re-measured in round 4 on the current kernels
+# (profiles/r04_avg_sq_counters.json, tools/r04_avg_counters.sh; round 2 read 52.7 before the certified-view path
+# shortened the projection; SURVEY 8d estimated ~50)
+LANE_OPS_PER_VOXEL_VIEW = {"u8": 47.7, "f32": 46.0}
+AVG_COUNTERS = "profiles/r04_avg_sq_counters.json"
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
 # x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
@@ -477,15 +480,16 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
             eng.flush()
 
         ms = host_timed(eng, torch, step, steps, warmup=1)
-        lane_ops = LANE_OPS_PER_VOXEL_VIEW * n * V
+        per_vv = LANE_OPS_PER_VOXEL_VIEW["u8" if name.startswith("u8") else "f32"]
+        lane_ops = per_vv * n * V
         ach = lane_ops / (ms * 1e-3) / 1e12
         ent = {"ms_per_step": ms, "value": n * V / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
                "timing": "best of 3 runs of that many steps",
                "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
                             "frac": ach / VALU_PEAK_TLANEOPS,
                             "lane_ops_per_step": lane_ops,
-                            "model": "%.1f VALU lane-ops per voxel.view (SQ_INSTS_VALU, profiles/r02_avg_sq_counters.json) "
-                                     "x N x V" % LANE_OPS_PER_VOXEL_VIEW}}
+                            "model": "%.1f VALU lane-ops per voxel.view (SQ_INSTS_VALU x 64 / (N x V), %s) x N x V"
+                                     % (per_vv, AVG_COUNTERS)}}
         if name in ("u8_binary", "f32"):
             # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
             # projecting: the model above counts work the kernel did not do
