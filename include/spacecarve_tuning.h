@@ -82,6 +82,9 @@
                                      project onto into LDS once per view and the voxels read their words from there --
                                      the north star's "LDS-staged mask tiles per wavefront".  Measured slower on every
                                      scene: the gathers hit L2 and the stage is bound by its arithmetic */
+#define SC_OPT_BULK_LIVE 42       /* sixteenths of the bricks (2): with fewer live bricks than that after the tile verdicts
+                                     the batch is a thin object and no unit goes on the bulk list (decided by the dense
+                                     stage on the device from the batch's own live count); 0: the list is always kept */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
                                                              uint32_t parity, int nverd_arg, uint32_t verd_max_live,
-                                                             int lds_tiles) {
+                                                             int lds_tiles, uint32_t bulk_min_live) {
     if (blockIdx.x >= nwalkers + nstore) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
@@ -390,6 +390,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     const uint32_t nlive = ctl->nlive[parity];
     // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
     const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
+    // ... and a batch whose tiles left only a sliver of the bricks live is a thin object: its few bulky units (a plant's
+    // 3 268 of 30 308) are not worth a list of their own -- their voxels go with the others (decided here, on the
+    // device, from this batch's own live count)
+    if (nlive < bulk_min_live) ap.bulk = nullptr;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t xcd = blockIdx.x & 7u;

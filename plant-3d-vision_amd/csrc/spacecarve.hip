@@ -177,6 +177,7 @@ struct sc_engine {
     // Whether the bulk units' verdicts pay is decided on the device, inside the batch, from the number of units its
     // own dense stage left (carve_special_kernel): fewer than this and their voxels take the ordinary lists
     int64_t bulk_floor = 8192;
+    int64_t bulk_live = 2;  // sixteenths of the bricks that must be live for the bulk list to be kept at all (0: always)
     int64_t list_cap = 0, list_cap_built = 0;  // entries per survivor sub-list (0: sized from the grid); tests of the overflow paths
     uint32_t *fill_list = nullptr;  // launches without survivor stages: settled bricks to fill (count in ctl->nfill)
     uint64_t flag_launches = 0;     // parity of the counters a flags kernel uses (see ListCtl)
@@ -1186,6 +1187,7 @@ int flush(sc_engine *e, size_t count = 0) {
                 // unit verdicts (cell level) by the views packed ahead, inside the dense stage
                 int nverd = 0;
                 const uint32_t verd_max_live = e->unit_cull == 2 ? 0xffffffffu : (uint32_t)(nbricks / 2);
+                const uint32_t bulk_min_live = (uint32_t)((uint64_t)nbricks * (uint64_t)e->bulk_live / 16u);
                 if (compact && e->unit_cull) {
                     nverd = std::min(packed_ahead, 16);
                     for (int q = 0; q < nverd; ++q)
@@ -1225,11 +1227,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles, bulk_min_live);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles, bulk_min_live);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -1722,6 +1724,10 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_UNIT_CULL:
             if (value < 0 || value > 2) return fail(SC_ERR_INVALID, "unit_cull must be 0, 1 or 2");
             e->unit_cull = value;
+            return SC_OK;
+        case SC_OPT_BULK_LIVE:
+            if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "bulk_live must be in [0, 16]");
+            e->bulk_live = value;
             return SC_OK;
         case SC_OPT_BULK_FLOOR:
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");

@@ -149,7 +149,7 @@ def test_failed_reservations_leave_no_holes_in_the_lists(gpu_device, device_mask
     assert 0 < (want == 0).sum() < want.size  # part of the grid is outside every picture
     opts = {"SC_OPT_DENSE_VIEWS": 3, "SC_OPT_STAGE1_VIEWS": 64, "SC_OPT_DEFER_SHARE": 5, "SC_OPT_COMPACT": 1,
             "SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_STAGE1_VOXELS": 1, "SC_OPT_VIEW_BRICK": 1,
-            "SC_OPT_STAGE1_LIST_BLOCKS": 1280, "SC_OPT_BULK_MIN": 1, "SC_OPT_ITEM_BIAS": 0, "SC_OPT_UNIT_CULL": 0,
+            "SC_OPT_STAGE1_LIST_BLOCKS": 1280, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_LIVE": 0, "SC_OPT_ITEM_BIAS": 0, "SC_OPT_UNIT_CULL": 0,
             "SC_OPT_LIST_CAP": 2}
     for stage1 in (64, 4):  # a single (final) list stage, and two
         e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
@@ -174,6 +174,7 @@ def test_bulk_units_whatever_the_number_of_list_stages(gpu_device, nviews, kind,
     for floor in (None, 0):
         e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
         e.set_option(nat.SC_OPT_BULK_MIN, 1)
+        e.set_option(nat.SC_OPT_BULK_LIVE, 0)  # the list is kept however few bricks are live
         if floor is not None:
             e.set_option(nat.SC_OPT_BULK_FLOOR, floor)
         ptr = _batch(e, views, False)
@@ -192,7 +193,7 @@ def test_bulk_unit_without_room_in_the_lists_is_carved_on_the_spot(gpu_device, k
     sh, origin, vs, views = scene(shape, 11, kind)
     want = oracle_c.carve(sh, origin, vs, views, nthreads=4)
     e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
-    for k, val in ((nat.SC_OPT_LIST_CAP, 2), (nat.SC_OPT_BULK_MIN, 1), (nat.SC_OPT_BULK_FLOOR, floor),
+    for k, val in ((nat.SC_OPT_LIST_CAP, 2), (nat.SC_OPT_BULK_MIN, 1), (nat.SC_OPT_BULK_LIVE, 0), (nat.SC_OPT_BULK_FLOOR, floor),
                    (nat.SC_OPT_ITEM_BIAS, 0), (nat.SC_OPT_UNIT_CULL, 0)):
         e.set_option(k, val)
     ptr = _batch(e, views, False)
@@ -276,10 +277,11 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_STAGE1_VOXELS": 4, "SC_OPT_VIEW_GROUP": 3},
     {"SC_OPT_BRICK_WALKERS": 8, "SC_OPT_FILL_BLOCKS": 1, "SC_OPT_VIEW_ORDER": 0},
     {"SC_OPT_BULK_MIN": 0},                                               # no unit is finished as a whole
-    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},                       # every unit with a voxel alive is, and asked
-    {"SC_OPT_BULK_MIN": 1},                                               # ... too few for the default floor: spilled
-    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_ITEM_BIAS": 64},  # items whatever they cost
-    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_ITEM_BIAS": 0},   # never items: asked, then the lists
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_BULK_LIVE": 0},  # every unit with a voxel alive is, and asked
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_BULK_LIVE": 16},  # ... unless every brick is live: never
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_LIVE": 0},                        # ... too few for the default floor: spilled
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_BULK_LIVE": 0, "SC_OPT_ITEM_BIAS": 64},  # items whatever they cost
+    {"SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_BULK_LIVE": 0, "SC_OPT_ITEM_BIAS": 0},   # never items: asked, then the lists
     {"SC_OPT_BULK_MIN": 256, "SC_OPT_FULL_BRICKS": 0, "SC_OPT_BULK_FLOOR": 0},
     {"SC_OPT_BULK_MIN": 40, "SC_OPT_DENSE_VIEWS": 1, "SC_OPT_LIST_BLOCKS": 8, "SC_OPT_BULK_FLOOR": 0},
     {"SC_OPT_BULK_MIN": 40, "SC_OPT_UNIT_BLOCKS": 1, "SC_OPT_BULK_FLOOR": 3},  # one block does all the special kernel has
@@ -380,6 +382,7 @@ def test_bulk_units_asked_as_a_whole(gpu_device, shape, default_value, bulk_min,
         want = oracle_c.carve(sh, origin, vs, vv, default_value, nthreads=4)
         e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=default_value)
         e.set_option(nat.SC_OPT_BULK_MIN, bulk_min)
+        e.set_option(nat.SC_OPT_BULK_LIVE, 0)
         e.set_option(nat.SC_OPT_BULK_FLOOR, 0)  # asked however few they are (a test grid has fewer than the default floor)
         e.set_option(nat.SC_OPT_FULL_BRICKS, full)
         stack = np.ascontiguousarray(np.stack(masks))
@@ -1232,7 +1235,7 @@ def test_brick_verdicts_on_adversarial_cameras(gpu_device, kw, kind):
     got, _ = _device_batch_carve(shape, origin, vs, views)
     assert np.array_equal(got, want), (kw, kind, "device batch", histogram3(got), histogram3(want))
     # the verdicts below the brick asked of every unit, whatever the heuristics would decide
-    got, _ = _device_batch_carve(shape, origin, vs, views, opts=((nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
+    got, _ = _device_batch_carve(shape, origin, vs, views, opts=((nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1), (nat.SC_OPT_BULK_LIVE, 0),
                                                                    (nat.SC_OPT_BULK_FLOOR, 0)))
     assert np.array_equal(got, want), (kw, kind, "device batch, unit verdicts forced", histogram3(got), histogram3(want))
     got = hip_carve(shape, origin, vs, views)
@@ -1375,7 +1378,7 @@ def test_masks_packed_in_bands(gpu_device, width, height, invert):
     want = oracle_c.carve(list(shape), origin, vs, [(K, R, t, (255 - m) if invert else m) for K, R, t, m in views], nthreads=4)
     for ride in (1, 0):
         e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
-        for k, v in ((nat.SC_OPT_PACK_ROWS, 3), (nat.SC_OPT_PACK_RIDE, ride), (nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1),
+        for k, v in ((nat.SC_OPT_PACK_ROWS, 3), (nat.SC_OPT_PACK_RIDE, ride), (nat.SC_OPT_UNIT_CULL, 2), (nat.SC_OPT_BULK_MIN, 1), (nat.SC_OPT_BULK_LIVE, 0),
                      (nat.SC_OPT_BULK_FLOOR, 0)):
             e.set_option(k, v)
         stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
