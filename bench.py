@@ -898,8 +898,10 @@ def main():
             out["roofline"]["traffic_write_bytes"] = live_traffic["write_bytes"]
             out["roofline"]["traffic_per_kernel"] = live_traffic["per_kernel"]
         out["lead_in"] = {"seconds_of_other_legs_before_warmup": t_device_before,
-                          "note": "stream + per_view legs run before the headline's warm-up (sustained device state); "
-                                  "0 with --skip-other-path"}
+                          "note": "the stream + per_view legs run before the headline's warm-up (the W warm-up and K timed "
+                                  "steps are unchanged); 0 with --skip-other-path.  Measured and NOT done: the "
+                                  "averaging forms and the other scenes in front as well -- behind 150 ms of "
+                                  "VALU-heavy averaging the same 20 steps read 0.1755-0.1840 ms (DESIGN_APPENDIX 12)"}
         if cold is not None:
             out["cold_first_batch_ms"] = cold["cold_first_batch_ms"]
             out["cold_first_batch"] = cold

@@ -39,7 +39,7 @@ def short(name):
     for key in ("carve_kernel_1<false", "carve_kernel_1<true", "carve_kernel<true", "carve_kernel<false",
                 "carve_brick_kernel<true", "carve_brick_kernel<false", "carve_brick_light_kernel<true",
                 "carve_brick_light_kernel<false", "brick_flags_kernel", "brick_confirm_kernel",
-                "carve_list_kernel<true", "carve_list_kernel<false", "carve_resume_kernel<true",
+                "carve_list_kernel<true", "carve_list_kernel<false", "carve_special_kernel", "bits_tiles_kernel", "carve_resume_kernel<true",
                 "carve_resume_kernel<false", "average_kernel", "pack16_kernel", "pack_band_kernel", "pack_kernel", "fill_kernel"):
         if key in name:
             return key + (">" if "<" in key else "")
@@ -84,7 +84,7 @@ def main():
             traffic[key] = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": f"profiles/{a.tag}_pmc.json",
                             "kernel": ent["kernel"], "read_correction": ent["read_correction"]}
     seq = ("pack16_kernel", "pack_band_kernel", "brick_flags_kernel", "carve_brick_kernel<true>", "brick_confirm_kernel", "carve_kernel<true>",
-           "carve_list_kernel<false>", "carve_list_kernel<true>", "carve_resume_kernel<true>")
+           "carve_special_kernel", "carve_list_kernel<false>", "carve_list_kernel<true>", "carve_resume_kernel<true>")
     parts = {s: per_kernel[s]["hbm_bytes_per_launch"] for s in seq
              if s in per_kernel and "hbm_bytes_per_launch" in per_kernel[s]}
     if "carve_list_kernel<true>" in parts:  # a run of the fused schedule (a stream run has pack and flags launches too)
