@@ -2214,7 +2214,13 @@ int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes) {
     rc = materialize(e);
     if (rc) return rc;
     const int64_t nbytes = sc_packed_bytes(e->n, bits);
-    if (!e->packed_labels) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->packed_labels), (size_t)sc_packed_bytes(e->n, 2)));
+    if (!e->packed_labels) {
+        const size_t cap = (size_t)sc_packed_bytes(e->n, 2);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->packed_labels), cap));
+        // the tail of the last 16-byte group lies behind the last word the pack kernel writes and travels with the
+        // buffer (all-gather, read-back): zero once, never garbage
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(e->packed_labels) + (cap - 16), 0, 16, e->stream));
+    }
     const uint64_t words = ((uint64_t)e->n + (32 / bits) - 1) / (32 / bits);
     // bricks an earlier launch found empty are all -1 until the next clear: not read (see the kernel)
     const uint32_t bys = (uint32_t)((e->ny + kBrickY - 1) / kBrickY), bzs = (uint32_t)((e->nz + kBrickZ - 1) / kBrickZ);
