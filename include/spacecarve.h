@@ -165,6 +165,15 @@ int sc_order_before(sc_engine *e, void *consumer_stream);
 int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
                     const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes);
 
+/* The file loop of Backprojection.process_label in one call (cl.py:282-303, for a carve engine and masks stored as
+ * 8-bit greyscale PNG -- what `io.write_image(f, im, 'png')` makes of tasks/proc2d.py's uint8 masks and what
+ * plantdb.io.read_image decodes for cl.py:298): V ENCODED files (png[q], sizes[q] bytes) with their poses, decoded on
+ * `threads` host threads of this call's own (<= 0: 16), each mask reduced to bits as it comes out of the decoder
+ * (invert != 0: np.invert on the uint8 pixels first, cl.py:300-301), the views enqueued in the order given.
+ * SC_ERR_INVALID, and nothing enqueued, if a file is not a PNG this decoder takes (sc_png_info) or is damaged. */
+int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, const float *t, const void *const *png,
+                         const int64_t *sizes, int invert, int threads);
+
 /* V views at once: K[V*4], R[V*9], t[V*3], masks[V] host pointers, common H, W, dtype. */
 int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const float *t,
                      const void *const *masks, int H, int W, int mask_dtype,

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "sc_process_view": ("i", ["p", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i", "q"]),
     "sc_process_views_device": ("i", ["p", "i", "p", "p", "p", "p", "i", "i", "i"]),
+    "sc_process_png_views": ("i", ["p", "i", "p", "p", "p", "p", "p", "i", "i"]),
     "sc_average_labels": ("i", ["p", "i", "i", "p", "p", "p", "p", "i", "i"]),
     "sc_average_labels_fused_count": ("q", []),
     "sc_flush": ("i", ["p"]),
@@ -579,6 +580,19 @@ class Engine:
         H, W = mask.shape
         self._call("sc_process_view", addr(K), addr(R), addr(t), addr(mask), H, W,
                    int(mask_dtype), 0)
+
+    def process_png_views(self, K, R, t, files, invert=False, threads=0):
+        """``sc_process_png_views``: ``files`` is a list of bytes-like objects holding 8-bit greyscale PNG masks;
+        decoded and reduced to bits on host threads inside the library, enqueued in the order given (carve engines).
+        Raises ``ValueError`` when a file is not such a PNG (nothing is enqueued then)."""
+        n = len(files)
+        K, R, t = self._pose(K, R, t)
+        if K.size != 4 * n or R.size != 9 * n or t.size != 3 * n:
+            raise ValueError("pose arrays do not match the file count")
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+        ptrs = np.array([b.ctypes.data for b in bufs], dtype=np.uintp)
+        sizes = np.array([b.size for b in bufs], dtype=np.int64)
+        self._call("sc_process_png_views", n, addr(K), addr(R), addr(t), addr(ptrs), addr(sizes), 1 if invert else 0, int(threads))
 
     def process_views_device(self, K, R, t, masks_dev, n_views, H, W, mask_dtype):
         K, R, t = self._pose(K, R, t)

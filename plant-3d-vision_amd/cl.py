@@ -424,6 +424,8 @@ class Backprojection(object):
             tvec = np.array(cam['tvec'], dtype=np.float32)  # :296
             self._submit_view(intrinsics, rot, tvec, mask, invert)  # :300-303
 
+        if self._submit_encoded(selected, invert):
+            return self.get_values()
         if self.decode_workers <= 1 or len(selected) <= 1:
             for fi, cam in selected:
                 submit(cam, read_image(fi))  # :298
@@ -447,6 +449,31 @@ class Backprojection(object):
                     submit(cam, mask)
 
         return self.get_values()
+
+    def _submit_encoded(self, selected, invert):
+        """The file loop (cl.py:282-303) handed to the library in one call when it can take it: a carve volume on one
+        engine, every file handing out its bytes (``read_raw``: plantdb's ``File``) and holding an 8-bit greyscale PNG
+        -- what a ``Masks`` / ``Segmentation2D`` fileset holds.  The files are decoded on the library's own threads and
+        each mask is reduced to bits as it comes out of the decoder (``sc_process_png_views``); same pixels, same order,
+        same ``np.invert``.  Returns False (and does nothing) otherwise: the decode-ahead loop below takes over."""
+        if self.dtype != np.int32 or self.decode_workers <= 1 or len(selected) < 2:
+            return False
+        if not hasattr(self._engine, "process_png_views") or not all(hasattr(fi, "read_raw") for fi, _ in selected):
+            return False
+        try:
+            raws = [fi.read_raw() for fi, _ in selected]
+        except Exception:
+            return False
+        if not all(isinstance(r, (bytes, bytearray, memoryview)) and len(r) > 33 for r in raws):
+            return False
+        K = np.array([cam["camera_model"]['params'][0:4] for _, cam in selected], dtype=np.float32)  # :293
+        R = np.array([sum(cam['rotmat'], []) for _, cam in selected], dtype=np.float32)  # :295
+        t = np.array([cam['tvec'] for _, cam in selected], dtype=np.float32)  # :296
+        try:
+            self._engine.process_png_views(K, R, t, raws, invert=invert, threads=max(self.decode_workers, 16))
+        except ValueError:  # some file is not a grey8 PNG: nothing was enqueued
+            return False
+        return True
 
     def clear(self):
         """Clear computed values (cl.py:307-311)."""

@@ -885,6 +885,8 @@ int hostbits_reserve(sc_engine *e, size_t bytes, char **out) {
     return SC_OK;
 }
 
+int hostbits_push_view(sc_engine *e, const float *K, const float *R, const float *t, uint64_t src_off, int H, int W);
+
 // A carve mask in HOST memory: its bits (pixel != 0 after the optional invert) are made here, on host threads, and
 // only they cross PCIe -- 1/8 of the bytes (1/32 of an int32 mask's); tiles, occupancy bytes and cell maps are a
 // device pass over the bits at the next flush (bits_tiles_kernel).  Appends one pending view.
@@ -906,9 +908,16 @@ int enqueue_hostbits(sc_engine *e, const float *K, const float *R, const float *
         const int r0 = par ? part * band : 0, r1 = par ? std::min(H, r0 + band) : H;
         schost::pack_rows(mask, row_stride, W, r0, r1, out, wpr, elem, flip);
     });
+    return hostbits_push_view(e, K, R, t, src_off, H, W);
+}
+
+// The device side of a host-packed view whose bits lie at `src_off` of the current arena: storage for its tiles,
+// occupancy bytes and cell map, its record for bits_tiles_kernel, its descriptor among the pending views.
+int hostbits_push_view(sc_engine *e, const float *K, const float *R, const float *t, uint64_t src_off, int H, int W) {
+    const int wpr = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     const size_t ntiles = (size_t)wpr * tiles_y;
     void *tiles = nullptr, *occ = nullptr, *cm = nullptr;
-    rc = arena_alloc(e, ntiles * 128, &tiles);
+    int rc = arena_alloc(e, ntiles * 128, &tiles);
     if (rc) return rc;
     rc = arena_alloc(e, ntiles, &occ);
     if (rc) return rc;
@@ -1899,6 +1908,70 @@ int sc_process_views(sc_engine *e, int V, const float *K, const float *R, const 
         if (rc) return rc;
     }
     return SC_OK;
+}
+
+int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, const float *t, const void *const *png,
+                         const int64_t *sizes, int invert, int threads) {
+    if (!e) return fail(SC_ERR_INVALID, "null engine");
+    if (V < 0 || (V > 0 && (!K || !R || !t || !png || !sizes))) return fail(SC_ERR_INVALID, "bad view batch");
+    if (V == 0) return SC_OK;
+    if (e->mode != SC_MODE_CARVE) return fail(SC_ERR_STATE, "encoded masks are carve masks (the averaging path converts pixels on the host)");
+    std::vector<int> Ws((size_t)V), Hs((size_t)V);
+    std::vector<size_t> offs((size_t)V);
+    size_t total = 0;
+    for (int q = 0; q < V; ++q) {
+        if (!png[q]) return fail(SC_ERR_INVALID, "null file %d", q);
+        if (sc_png_info(png[q], sizes[q], &Ws[(size_t)q], &Hs[(size_t)q]) != SC_OK)
+            return fail(SC_ERR_INVALID, "file %d: %s", q, sc_png_last_error());
+        offs[(size_t)q] = total;
+        total += ((size_t)Hs[(size_t)q] * (size_t)((Ws[(size_t)q] + kTile - 1) / kTile) * 4 + 255) & ~(size_t)255;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    rc = materialize_deferred(e);
+    if (rc) return rc;
+    char *base = nullptr;
+    rc = hostbits_reserve(e, total, &base);  // one reservation: the arena does not move while the threads write
+    if (rc) return rc;
+    auto &arena = e->hb[e->hb_cur];
+    const uint64_t base_off = (uint64_t)(base - arena.pin);
+    // decode + pack, a file per thread at a time.  Threads of this call's own (16 by default: inflate is the floor
+    // of the files -> volume time, ~1.3 ms per mask and thread, and the pool's 8 are sized for the per-mask hand-overs)
+    int nth = threads > 0 ? threads : 16;
+    nth = std::min(std::min(nth, V), 64);
+    std::atomic<int> next{0}, bad{-1};
+    const uint8_t flip = invert ? 255 : 0;
+    auto work = [&]() {
+        std::vector<uint8_t> pix;
+        for (;;) {
+            const int q = next.fetch_add(1, std::memory_order_relaxed);
+            if (q >= V || bad.load(std::memory_order_relaxed) >= 0) return;
+            const int W = Ws[(size_t)q], H = Hs[(size_t)q];
+            pix.resize((size_t)W * H);
+            if (sc_png_decode_gray8(png[q], sizes[q], pix.data(), W, H) != SC_OK) {
+                int expect = -1;
+                bad.compare_exchange_strong(expect, q);
+                return;
+            }
+            schost::pack_rows(pix.data(), W, W, 0, H, reinterpret_cast<uint32_t *>(base + offs[(size_t)q]), (W + kTile - 1) / kTile, 1, flip);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        pool.reserve((size_t)nth);
+        for (int i = 1; i < nth; ++i) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    if (bad.load() >= 0) {
+        arena.used -= total;  // nothing of this call stays
+        return fail(SC_ERR_INVALID, "file %d could not be decoded", bad.load());
+    }
+    for (int q = 0; q < V; ++q) {
+        rc = hostbits_push_view(e, K + 4 * q, R + 9 * q, t + 3 * q, base_off + offs[(size_t)q], Hs[(size_t)q], Ws[(size_t)q]);
+        if (rc) return rc;
+    }
+    return after_enqueue(e);
 }
 
 int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R, const float *t,

@@ -541,6 +541,67 @@ def test_host_mask_arena_grows_with_the_batch(gpu_device):
     e.close()
 
 
+class _PngFile:
+    """A fileset entry that hands out its bytes like plantdb's ``File`` (``read_raw``) and its pixels (``array``)."""
+
+    def __init__(self, fid, raw, array, cam):
+        self.id, self._raw, self.array, self._md = fid, raw, array, {"colmap_camera": cam, "channel": None}
+
+    def read_raw(self):
+        return self._raw
+
+    def get_metadata(self, key, default=None):
+        return self._md.get(key, default)
+
+
+def _png(arr, **kw):
+    import io
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(arr).save(bio, format="PNG", **kw)
+    return bio.getvalue()
+
+
+@pytest.mark.parametrize("w,h", [(160, 96), (101, 67), (1440, 1080)])
+@pytest.mark.parametrize("invert", [False, True])
+def test_fileset_of_png_masks_decoded_inside_the_library(gpu_device, w, h, invert):
+    """``process_fileset`` over files that hand out 8-bit greyscale PNG bytes: one call decodes them on the library's
+    threads and reduces each mask to bits as it comes out of the decoder (``sc_process_png_views``) -- the same
+    volume as the oracle on the decoded pixels (inverted like cl.py:300-301 where asked), grey levels included; a
+    fileset with a file the decoder refuses (RGB) falls back to the decode-ahead loop and gives the same volume."""
+    from plant3dvision_amd.scenes import camera_dict
+    n = 20 if w < 1000 else 28
+    shape, origin, vs, views = scene(n, 7, "plant", width=w, height=h, fx=0.8 * w, fy=0.8 * w, cx=w / 2.0, cy=h / 2.0)
+    rng = np.random.default_rng(w + h)
+    grey = [np.where(m != 0, rng.integers(1, 256, m.shape), 0).astype(np.uint8) for _, _, _, m in views]
+    want = oracle_c.carve(shape, origin, vs, [(K, R, t, np.invert(m) if invert else m) for (K, R, t, _), m in zip(views, grey)], nthreads=4)
+    files = [_PngFile(f"im{q}", _png(m, compress_level=int(q % 3) * 4), m, camera_dict(K, R, t))
+             for q, ((K, R, t, _), m) in enumerate(zip(views, grey))]
+    bp = Backprojection(shape, origin, vs)
+    calls = []
+    real = bp._engine.process_png_views
+    bp._engine.process_png_views = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    got = bp.process_fileset(files, "colmap_camera", invert=invert)
+    assert calls and np.array_equal(got, want), (w, h, invert, histogram3(want))
+    # one file the decoder does not take: the whole fileset goes through the usual loop, same result
+    from PIL import Image
+    import io
+    bio = io.BytesIO()
+    Image.fromarray(grey[2]).convert("RGB").save(bio, format="PNG")
+    files[2] = _PngFile("im2", bio.getvalue(), grey[2], files[2]._md["colmap_camera"])
+    bp.clear()
+    got = bp.process_fileset(files, "colmap_camera", invert=invert)
+    assert np.array_equal(got, want), "fallback"
+    # a damaged file: refused by the call, nothing enqueued, the loop reads the pixels another way
+    bad = bytearray(files[4]._raw); bad[len(bad) // 2] ^= 0xff
+    files[4] = _PngFile("im4", bytes(bad), grey[4], files[4]._md["colmap_camera"])
+    files[2] = _PngFile("im2", _png(grey[2]), grey[2], files[2]._md["colmap_camera"])
+    bp.clear()
+    got = bp.process_fileset(files, "colmap_camera", invert=invert)
+    assert np.array_equal(got, want), "damaged file"
+    bp.close()
+
+
 @pytest.mark.parametrize("w,h", [(160, 96), (33, 17), (1440, 1080)])
 def test_invert_folded_into_device_packing(gpu_device, w, h):
     """``process_fileset(invert=True)``: uint8 / bool masks are inverted by the pack kernels
