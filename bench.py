@@ -449,7 +449,6 @@ def scene_counts(eng):
     """What the last fused launch left at each stage, incl. the bulk units asked about as a whole and the
     work items their undecided views became."""
     c = eng.fused_counts_ex()
-    c.pop("bulk_hold", None)
     return c
 
 
@@ -820,7 +819,7 @@ def main():
     def roof(path, st, traffic, traffic_src=None):
         if path == "fused":
             # One "launch" of the fused schedule is the whole batch: pack16 -> brick_flags ->
-            # carve_brick -> carve_list<false> -> carve_list<true> (-> resume).  The timed steps are
+            # carve_brick -> brick_confirm -> carve_special -> carve_list<false> -> carve_list<true>.  The timed steps are
             # bracketed by ONE HIP event pair on the engine's stream (sc_span_begin / sc_span_end); a
             # batch's duration is that span over the number of batches in it (they run back to back;
             # an event pair per batch would put a barrier packet between them).  No single kernel of
@@ -832,7 +831,7 @@ def main():
             model = ("fused batch: 4 B/voxel label write (never read) + V*W*H uint8 mask bytes read once; "
                      "the 1-bit tiles and survivor lists are implementation traffic, not counted")
             units = n_local * V
-            kernel = "fused batch (pack_band_kernel + brick_flags_kernel + carve_brick_kernel + brick_confirm_kernel + carve_list_kernel x2 + carve_resume_kernel)"
+            kernel = "fused batch (pack_band_kernel + brick_flags_kernel + carve_brick_kernel + brick_confirm_kernel + carve_special_kernel + carve_list_kernel x2)"
         else:
             avg_ms = st["carve"]["avg_ms"]
             launches = st["carve"]["launches"]

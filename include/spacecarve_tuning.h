@@ -14,7 +14,7 @@
 
 #define SC_OPT_DENSE_VIEWS 6      /* views applied to every voxel before compaction (2)       */
 #define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
-#define SC_OPT_LIST_BLOCKS 8      /* persistent grid of the resume kernel and of list stages without store blocks (2048) */
+#define SC_OPT_LIST_BLOCKS 8      /* persistent grid of list stages without store blocks (2048)              */
 #define SC_OPT_VIEW_GROUP 9       /* the spans of the final survivor stage are a multiple of this many views (2) */
 #define SC_OPT_BRICK 10           /* 1 (default): for grids with nz <= 4096 and < 2^31 voxels the dense stage
                                      works on 16x64-voxel bricks with a conservative emptiness

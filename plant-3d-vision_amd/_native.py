@@ -689,7 +689,7 @@ class Engine:
         self._call("sc_fused_counts_ex", addr(out))
         return {"live_bricks": int(out[0]), "alive_after_dense_stage": int(out[1]),
                 "alive_after_first_list_stage": int(out[2]), "list_overflow": int(out[3]), "late_bricks": int(out[4]),
-                "bulk_units": int(out[5]), "unit_items": int(out[6]), "bulk_hold": int(out[7])}
+                "bulk_units": int(out[5]), "unit_items": int(out[6])}
 
     def selftest_division(self, count, seed=1, mode=1):
         """(mismatches, fast_pairs) of the shared-reciprocal division vs hipcc's IEEE division."""

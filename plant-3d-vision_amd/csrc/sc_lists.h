@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
         return;
     }
-    if (ctl->overflow) return;  // the dense resume kernel does the remaining views instead
+    if (ctl->overflow) return;  // the special kernel's dense pass has applied the remaining views instead
     const uint32_t bid = bx;
     constexpr uint32_t CH = 64u * P;
     {

@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t list_count(const ListCounter &c, uint32_t ca
 struct ListCtl {
     ListCounter count[5][kSub];  // entries appended per sub-list, one set per list stage; set 3: bulk units, set 4:
                                  // their work items
-    uint32_t overflow;           // a sub-list ran out of room: the dense resume kernel takes over
+    uint32_t overflow;           // a sub-list ran out of room in the DENSE stage: the special kernel's dense pass takes over
     uint32_t nlive[2];           // brick form: bricks no view found empty (entries of the live list); the flags
                                  // kernel of launch q counts in word q & 1 and zeroes the other one, so launches
                                  // that keep the same block (fewer than 6 views: no survivor stages) need no memset

@@ -227,7 +227,7 @@ struct sc_engine {
     int64_t dense_views = 2;     // views applied to every voxel before compaction
     int64_t stage1_views = 8;    // views applied to the first survivor list
     int64_t stage2_views = 0;    // views applied to the second survivor list (0: no such stage)
-    int64_t list_blocks = 2048;  // persistent grid of the list / resume kernels
+    int64_t list_blocks = 2048;  // persistent grid of list stages without store blocks
     int64_t view_group = 2;      // the spans of the final list stage are a multiple of this many views
 
     std::vector<TimedLaunch> timed[kNumKernels];
@@ -750,7 +750,7 @@ int ensure_lists(sc_engine *e) {
     }
     // room for 5/16 of the voxels: two views of coin-flip masks leave a quarter alive, which the hashed
     // sub-lists must hold with a margin for their unevenness (an overflow sends the batch down the dense
-    // resume path, 10 x slower)
+    // special kernel's dense pass, 10 x slower)
     uint64_t total = std::max<uint64_t>((uint64_t)e->n / 4 + (uint64_t)e->n / 16, (uint64_t)kSub * 1024);
     e->subcap = (uint32_t)((total + kSub - 1) / kSub);
     if (e->list_cap > 0) e->subcap = (uint32_t)e->list_cap;

@@ -1166,7 +1166,7 @@ def test_device_batch_packed_at_flush_equals_oracle(gpu_device, ride, kind, shap
 def test_full_candidates_rejected_by_a_late_view(gpu_device, odd, default_value):
     """Every view but one keeps every brick whole (all-foreground pictures); the odd one carves half
     of the volume.  Whether it is among the views packed ahead (and seen by the flags kernel) or among
-    the riders (the store blocks' confirmation, then the resume kernel's late bricks), the labels are
+    the riders (the store blocks' confirmation, then the special kernel's late bricks), the labels are
     the oracle's -- on a fresh volume and on a stored one."""
     shape, origin, vs, views = scene((12, 48, 128), 14, "solid")
     views = [list(v) for v in views]

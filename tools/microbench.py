@@ -33,7 +33,7 @@ if __name__ == "__main__":
     run("plant", 512, 1, vpl=1, label="plant 1 view stream fresh")
     run("plant", 512, 72, label="plant 72")
     run("plant", 512, 72, opts=[(6, 1), (7, 1)], label="plant 72 dense=1 (overflow?)")
-    run("solid", 512, 6, label="solid 6 (overflow->resume)")
+    run("solid", 512, 6, label="solid 6 (overflow -> the special kernel's dense pass)")
     shape, origin, vs, _ = scenes.make_scene(512, 1, "empty")
     e = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
     e.set_option(nat.SC_OPT_TIME_KERNELS, 1)
