@@ -85,6 +85,9 @@
 #define SC_OPT_BULK_LIVE 42       /* sixteenths of the bricks (2): with fewer live bricks than that after the tile verdicts
                                      the batch is a thin object and no unit goes on the bulk list (decided by the dense
                                      stage on the device from the batch's own live count); 0: the list is always kept */
+#define SC_OPT_SAFE_KERNELS 43    /* 1 (default): a batch whose views are ALL certified by the host (project(): every voxel
+                                     of the grid well in front of the camera, everything finite -- any real rig) runs the
+                                     survivor stages in instances compiled without the general path; 0: never        */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

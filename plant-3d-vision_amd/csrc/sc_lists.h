@@ -51,7 +51,7 @@ struct UnitSpill {
 //     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
 // (at most 80 SGPRs: with 82-96 the CU admits 7 such blocks instead of 8, with 98+ only 6 --
 // MI355X_MICROARCH.md, "Residency" -- and the store blocks need the slots the list blocks leave)
-template <bool FINAL, int P>  // P voxels per lane (an item is a chunk of 64 * P entries)
+template <bool FINAL, int P, bool ALL_SAFE = false>  // P voxels per lane (an item is a chunk of 64 * P entries); ALL_SAFE: see project()
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                             const ViewDesc *__restrict__ views,
                                                             int nviews,
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 for (int p = 0; p < P; ++p) {
                     int uu, vv;
                     // dead lanes project along (their carve below is masked): cheaper than a per-lane test here
-                    ok[q][p] = project(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
+                    ok[q][p] = project<ALL_SAFE>(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
                                        d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv);
                     uint32_t w = 0;
                     if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         int uu, vv;
-                        ok[q][p] = project(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
+                        ok[q][p] = project<ALL_SAFE>(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
                                            d.R[6] * x + d.R[7] * y[p], z, d, uu, vv);
                         uint32_t w = 0;
                         if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));

@@ -60,12 +60,15 @@ __device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
 // two unsigned comparisons of the truncated coordinates -- uf, vf are finite there, v_cvt_i32_f32
 // truncates toward zero ((-1, 0) -> 0, accepted like the reference's cast) and saturates, so
 // (unsigned)u < W is exactly  uf > -1 && uf < W.
+// ALL_SAFE: the host has certified EVERY view this kernel instance will see (certify_view), so the test of d.safe and
+// the general path behind it are compiled out of the view loop -- same arithmetic, fewer basic blocks.
+template <bool ALL_SAFE = false>
 __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
                                         const ViewDesc &d, int &u, int &v) {
     float pz = (az + d.R[8] * z) + d.t[2];  // :11
     float px = (ax + d.R[2] * z) + d.t[0];  // :17
     float py = (ay + d.R[5] * z) + d.t[1];  // :18
-    const bool safe = d.safe != 0;          // wave-uniform
+    const bool safe = ALL_SAFE || d.safe != 0;  // wave-uniform
     unsigned long long outside;             // lanes whose operands the fast division does not cover
     if (safe) {
         outside = __builtin_amdgcn_ballot_w64(!(fabsf(px) > 0x1p-40f)) | __builtin_amdgcn_ballot_w64(!(fabsf(py) > 0x1p-40f));

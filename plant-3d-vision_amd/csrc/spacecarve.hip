@@ -198,6 +198,7 @@ struct sc_engine {
 
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
+    int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
     int64_t lds_tiles = 0;  // the dense stage stages each unit's window of mask words in LDS (experiment)
     int64_t host_pack = 1;
     struct HostBits {
@@ -1312,9 +1313,13 @@ int flush(sc_engine *e, size_t count = 0) {
                 cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff, init};
                 fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
+            // every view of the batch certified by the host (certify_view: any real rig): the instances without the general path
+            bool all_safe = e->safe_kernels != 0;
+            for (size_t q = 0; q < nv && all_safe; ++q) all_safe = e->pending[q].safe != 0;
 #define LAUNCH_LIST(FIN, GRID, ...)                                                                      \
     do {                                                                                                 \
         if ((FIN ? e->final_voxels : e->stage1_voxels) == 4) hipLaunchKernelGGL((carve_list_kernel<FIN, 4>), GRID, block, 0, e->stream, __VA_ARGS__); \
+        else if ((FIN ? e->final_voxels : e->stage1_voxels) == 2 && all_safe) hipLaunchKernelGGL((carve_list_kernel<FIN, 2, true>), GRID, block, 0, e->stream, __VA_ARGS__); \
         else if ((FIN ? e->final_voxels : e->stage1_voxels) == 2) hipLaunchKernelGGL((carve_list_kernel<FIN, 2>), GRID, block, 0, e->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((carve_list_kernel<FIN, 1>), GRID, block, 0, e->stream, __VA_ARGS__);     \
     } while (0)
@@ -1741,6 +1746,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_BULK_FLOOR:
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
             e->bulk_floor = value;
+            return SC_OK;
+        case SC_OPT_SAFE_KERNELS:
+            e->safe_kernels = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_LDS_TILES:
             e->lds_tiles = value ? 1 : 0;

@@ -291,6 +291,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_UNIT_CULL": 0},                                              # no unit verdicts in the dense stage
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},  # ... asked whatever the tiles settled
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
+    {"SC_OPT_SAFE_KERNELS": 0},                                           # the list kernels with the general path compiled in
     {"SC_OPT_LDS_TILES": 1},                                              # the dense stage's mask words staged in LDS
     {"SC_OPT_LDS_TILES": 1, "SC_OPT_DENSE_VIEWS": 3, "SC_OPT_UNIT_CULL": 0},
 ])
