@@ -300,7 +300,9 @@ int sc_fused_counts_ex(sc_engine *e, int64_t out[8]);
 /* Self-test: runs the kernels' shared-reciprocal division and the compiler's IEEE division on
  * `count` pseudo-random operand triples (mode 0: raw bit patterns, 1: projection-like
  * magnitudes) and reports how many quotients differ bit-for-bit (must be 0) and how many
- * triples took the fast path. */
+ * triples took the fast path.  Mode 2: numerators of at most 2^-40 in magnitude (zero and denormals included) over
+ * denominators and intrinsics of a certified view -- there the PIXEL and the picture test are compared, not the
+ * quotient (csrc/sc_project.h says why that is what matters); every sample counts as fast. */
 int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                          uint64_t *mismatches, uint64_t *fast_pairs);
 

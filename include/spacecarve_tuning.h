@@ -43,8 +43,9 @@
                                      first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
 #define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
 #define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
-                                     that many persistent blocks walking the strips (512 = two per CU: a
-                                     wavefront's stores do not hold it up, so few keep the write path busy) */
+                                     that many persistent blocks walking the strips (256 = one per CU: a
+                                     wavefront's stores do not hold it up, so few keep the write path busy;
+                                     512 until round 4) */
 #define SC_OPT_FINAL_VOXELS 24      /* survivors per lane in the final survivor stage: 1, 2 (default) or 4         */
 #define SC_OPT_VIEW_BRICK 26        /* 1 (default): a launch of ONE view (the reference's cadence, cl.py:223-226)
                                      uses the brick verdicts too: bricks the view sees whole over background

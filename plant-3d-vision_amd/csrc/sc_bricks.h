@@ -249,38 +249,67 @@ struct Fill {
     int32_t init;   // ... and this is what an UNTOUCHED brick (flag 6) of a fresh volume gets
 };
 
-__device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g,
-                                                    const uint8_t *__restrict__ flags, uint32_t strip,
+// (f: the lane's flag of the strip -- lane b holds brick b's, see strip_flag: a persistent store block fetches the flags
+// of several strips before it stores any of them, because the wait for a load is also a wait for every store issued
+// before it: vector loads and stores retire through one in-order counter)
+__device__ __forceinline__ uint32_t strip_flag(const uint8_t *__restrict__ flags, uint32_t strip, uint32_t bricks_z) {
+    const uint32_t lane = threadIdx.x & 63;
+    return (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;  // (bricks_z <= 64: the brick form is for nz <= 4096)
+}
+__device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g, uint32_t f, uint32_t strip,
                                                     uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
-    const uint32_t j = by * kBrickY + wave * 4 + (lane >> 4);
-    const uint32_t f = (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;
+    const uint32_t j0 = by * kBrickY + wave * 4, j = j0 + (lane >> 4);
     const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
     // UNTOUCHED bricks (6) keep their labels: only a fresh volume, whose labels exist as `init` in name
     // only, has something to write there
     const unsigned long long untouched = fill.fresh ? __ballot(f == 6u) : 0ull;
     if (j >= g.ny) return;  // a strip at the far y face may stick out of the grid
+    const uint32_t l16 = lane & 15u;
+    const bool tail_ok = (bricks_z - 1u) * kBrickZ + l16 * 4u < g.nz;  // the last brick of a column may stick out of it
+    const unsigned long long last = 1ull << (bricks_z - 1u);
+    // EMPTY bricks, the bulk of the fill: a scalar walk over the set bits, and per brick ONE vector instruction -- the
+    // store, its address the wavefront's (scalar) plus the lane's 32-bit offset within the wavefront's four columns.
+    // (Round 4: the store blocks share their SIMDs with the survivor stages' wavefronts, whose vector instructions bound
+    // those stages; the compiler's form of this loop -- 64-bit shifts of the masks per lane, a 64-bit address per lane
+    // and turn -- was 5 M of the final stage's 34 M vector instructions.)
+    {
+        const char *wbase = reinterpret_cast<const char *>(labels) + ((uint64_t)il * g.ny + j0) * g.nzp * 4u;
+        const uint32_t voff = (lane >> 4) * g.nzp * 4u + l16 * 16u;
+        v4i minus = {-1, -1, -1, -1};
+        asm volatile("" : "+v"(minus));  // four registers for the life of the loop
+        unsigned long long body = culled & ~last;
+        while (body != 0) {  // wave-uniform
+            const uint32_t bz = (uint32_t)__builtin_ctzll(body);
+            body &= body - 1;
+            // streaming store: the fill is written once and not read again by this batch; kept
+            // out of the caches it does not evict the masks the next batch packs
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(voff), "v"(minus), "s"(wbase + bz * 256u) : "memory");
+        }
+        if ((culled & last) != 0 && tail_ok)
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(voff), "v"(minus), "s"(wbase + (bricks_z - 1u) * 256u) : "memory");
+        // a store of more than 8 bytes reads its data registers a little after it issues, and the compiler, which cannot
+        // see that the statements above are stores, would be free to reuse them at once: they stay live over two more
+        // wait states
+        asm volatile("s_nop 1" ::"v"(minus));
+    }
+    unsigned long long rest = full | untouched;
+    if (rest == 0) return;
     int32_t *col = labels + ((uint64_t)il * g.ny + j) * g.nzp;
-    const bool vec = (g.nzp & 3u) == 0;
-    for (uint32_t bz = 0; bz < bricks_z; ++bz) {
-        const bool isfull = (full >> bz) & 1ull, isunt = (untouched >> bz) & 1ull;
-        if (!((culled >> bz) & 1ull) && !isfull && !isunt) continue;
-        const uint32_t k0 = bz * kBrickZ + (lane & 15) * 4;
+    while (rest != 0) {  // rare: FULL bricks, and the UNTOUCHED ones of a fresh volume
+        const uint32_t bz = (uint32_t)__builtin_ctzll(rest);
+        rest &= rest - 1;
+        const bool isfull = (full >> bz) & 1ull;
+        const uint32_t k0 = bz * kBrickZ + l16 * 4;
         if (k0 >= g.nz) continue;
-        const uint32_t n = min(4u, g.nz - k0);
         if (!isfull || fill.fresh) {
-            const int32_t val = isunt ? fill.init : (isfull ? fill.kept : -1);
-            if (vec) {
-                // streaming store: the fill is written once and not read again by this batch; kept
-                // out of the caches it does not evict the masks the next batch packs
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                v4i vv = {val, val, val, val};
-                __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(col + k0));
-            } else {
-                for (uint32_t e = 0; e < n; ++e) col[k0 + e] = val;
-            }
+            const int32_t val = isfull ? fill.kept : fill.init;
+            const v4i vv = {val, val, val, val};
+            __builtin_nontemporal_store(vv, reinterpret_cast<v4i *>(col + k0));  // (rows are whole 64-voxel bricks: nzp % 64 == 0)
         } else {  // FULL brick of a stored volume: 0 -> 1, the rest as it is
+            const uint32_t n = min(4u, g.nz - k0);
             for (uint32_t e = 0; e < n; ++e)
                 if (col[k0 + e] == 0) col[k0 + e] = 1;
         }
@@ -361,11 +390,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              uint32_t nstore, PackJob ride, int pack_rows,
                                                              uint32_t parity, int nverd_arg, uint32_t verd_max_live,
                                                              int lds_tiles, uint32_t bulk_min_live) {
-    if (blockIdx.x >= nwalkers + nstore) {
+    // Behind the walkers come the riders, and the store blocks LAST: blocks start in the order of their numbers, and what
+    // the riders pack is waited for by the next kernel, while a store only has to be done by the end of this one
+    // (with the store blocks in front the riders started when the stores were through, and a sixteenth of the fill
+    // cost this kernel the 5.4 us it takes on its own).
+    const uint32_t nride = gridDim.x - nwalkers - nstore;
+    if (blockIdx.x >= nwalkers && blockIdx.x < nwalkers + nride) {
         // riders: the masks of the views the later stages apply are packed here, beside the walkers
         // (this stage waits on gathers and arithmetic, the packing on HBM reads).  One short block per
         // panel: persistent riders measured the same or slower.
-        const uint32_t b = blockIdx.x - nwalkers - nstore;
+        const uint32_t b = blockIdx.x - nwalkers;
         if (pack_rows == 0) pack_band_block(ride, b);
         else if (pack_rows == 1) pack16_block<1>(ride, b);
         else if (pack_rows == 2) pack16_block<2>(ride, b);
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         return;
     }
     if (blockIdx.x >= nwalkers) {
-        store_culled_bricks(labels, g, flags, blockIdx.x - nwalkers, bricks_y, bricks_z,
+        store_culled_bricks(labels, g, strip_flag(flags, blockIdx.x - nwalkers - nride, bricks_z), blockIdx.x - nwalkers - nride, bricks_y, bricks_z,
                             Fill{init == 0 ? 1 : init, FRESH ? 1 : 0, init});
         return;
     }

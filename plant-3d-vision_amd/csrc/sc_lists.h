@@ -31,6 +31,13 @@ __device__ __forceinline__ uint32_t list_reserve(ListCounter *counter, uint32_t 
     return __shfl(base, 0);
 }
 
+// Is this lane's bit set in a wavefront mask held in scalar registers?  (bit_lo / bit_hi: the lane's own bit in the low /
+// high half, two vector registers for the life of the kernel; three full-rate instructions where a 64-bit shift by the
+// lane number would be a two-pass one)
+__device__ __forceinline__ bool lane_in(unsigned long long m, uint32_t bit_lo, uint32_t bit_hi) {
+    return (((uint32_t)m & bit_lo) | ((uint32_t)(m >> 32) & bit_hi)) != 0u;
+}
+
 struct UnitSpill {
     const uint32_t *units;  // null: no bulk list.  [kSub][cap] unit ids, counts in ctl->count[3]
     uint32_t cap, floor;
@@ -74,8 +81,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         // one short block per strip, or (fill_blocks > 0) that many blocks walking the strips: a
         // wavefront's stores do not hold it up, so few of them keep the write path busy and the
         // wavefront slots go to the list blocks
-        for (uint32_t strip = cs.first + (bx - nbid); strip < cs.nstrips; strip += nstore)
-            store_culled_bricks(labels, g, cs.flags, strip, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
+        constexpr uint32_t kAhead = 4;  // strips whose flags are fetched together
+        for (uint32_t strip = cs.first + (bx - nbid); strip < cs.nstrips; strip += nstore * kAhead) {
+            uint32_t f[kAhead];
+#pragma unroll
+            for (uint32_t u = 0; u < kAhead; ++u) {
+                const uint32_t st = strip + u * nstore;
+                f[u] = st < cs.nstrips ? strip_flag(cs.flags, st, cs.bricks_z) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kAhead; ++u) {
+                const uint32_t st = strip + u * nstore;
+                if (st < cs.nstrips) store_culled_bricks(labels, g, f[u], st, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
+            }
+        }
         return;
     }
     if (ctl->overflow) return;  // the special kernel's dense pass has applied the remaining views instead
@@ -96,6 +115,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     const uint32_t chunks = pref[kSub];
     const uint32_t lane = tid & 63u;
+    const uint32_t bit_lo = lane < 32u ? 1u << lane : 0u, bit_hi = lane < 32u ? 0u : 1u << (lane - 32u);  // see lane_in
     __shared__ uint32_t ipref[kSub + 1];  // FINAL: the work items' prefix; else: the spilled bulk units'
     const bool with_items = FINAL && ui.items != nullptr;  // grid-uniform
     uint32_t uchunks = 0;  // chunks made of spilled bulk units, behind the list's own
@@ -172,9 +192,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         const uint32_t s = lo;
         const uint32_t cnt = list_count(ctl->count[sin][s], subcap);
         // P voxels per lane: the descriptor traffic and the scalar bookkeeping of a view are shared,
-        // and a lane has P * U independent projection chains and gathers in flight
+        // and a lane has P * U independent projection chains and gathers in flight.
+        // What a lane knows about its voxels -- alive, label still 0, 0 -> 1 pending -- is kept as WAVEFRONT masks in
+        // scalar registers (round 4): the comparisons of a projection leave lane masks anyway, so the whole of
+        // backprojection.c:79-83 becomes scalar and/or on them, and vector instructions are spent on a store or a
+        // compare-and-swap only in the turns where some lane has one to make (the byte-per-lane booleans the compiler
+        // made of `bool alive[P]` cost 8 vector instructions per voxel and turn).
         uint32_t idx[P];
-        bool zero[P], flipped[P], alive[P];
+        unsigned long long alive_m[P], zero_m[P], flip_m[P];
         float x[P], y[P], z[P];
         uint32_t unit = 0, upart = 0;
         if (from_unit) {
@@ -194,20 +219,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 idx[p] = inside ? (il * g.ny + j) * g.nzp + k : 0u;
                 int32_t lab = -1;
                 if (inside) lab = labels[idx[p]];
-                alive[p] = lab != -1;   // backprojection.c:67
-                zero[p] = lab == 0;
+                alive_m[p] = __ballot(lab != -1);   // backprojection.c:67
+                zero_m[p] = __ballot(lab == 0);
             } else {
                 const uint32_t e = (c - pref[s]) * CH + (uint32_t)p * 64u + lane;
-                alive[p] = e < cnt;
+                const bool in = e < cnt;
                 uint32_t entry = 0;
-                if (alive[p]) entry = lin[(size_t)s * subcap + e];
+                if (in) entry = lin[(size_t)s * subcap + e];
                 idx[p] = entry & 0x7fffffffu;
-                zero[p] = (entry >> 31) != 0;  // label is still 0
+                alive_m[p] = __ballot(in);
+                zero_m[p] = __ballot((entry >> 31) != 0);  // label is still 0
             }
-            flipped[p] = false;
-            const uint32_t col = idx[p] / g.nzp;  // entries index the padded rows
+            flip_m[p] = 0;
+            const uint32_t col = fdiv(idx[p], g.by_nzp);  // entries index the padded rows (below 2^31)
             const uint32_t k = idx[p] - col * g.nzp;
-            const uint32_t il = col / g.ny;
+            const uint32_t il = fdiv(col, g.by_ny);
             const uint32_t j = col - il * g.ny;
             x[p] = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
             y[p] = g.oy + (float)(int)j * g.vs;
@@ -218,11 +244,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         constexpr int U = P >= 4 ? 1 : (FINAL ? 2 : 4);
         for (;;) {  // (once; a second time over the views behind this stage's for a chunk whose survivors find no room)
         for (int vi = v0; vi < v1; vi += U) {
-            bool any = false;
+            unsigned long long any = 0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) any |= alive[p];
-            if (__ballot(any) == 0) break;
-            bool ok[U][P], fg[U][P];
+            for (int p = 0; p < P; ++p) any |= alive_m[p];
+            if (any == 0) break;
+            unsigned long long okm[U][P];
+            uint32_t w[U][P];
+            int sh[U][P];
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 // past the end of the range the last view is applied once more: a view applied twice
@@ -233,46 +261,50 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 // tiles_x and the mask pointer one by one where they are first used, three
                 // more scalar-load round trips inside each projection
                 asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+                const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    int uu, vv;
+                    int vv;
                     // dead lanes project along (their carve below is masked): cheaper than a per-lane test here
-                    ok[q][p] = project<ALL_SAFE>(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
-                                       d.R[6] * x[p] + d.R[7] * y[p], z[p], d, uu, vv);
-                    uint32_t w = 0;
-                    if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
-                    fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
+                    const bool ok = project<ALL_SAFE>(d.R[0] * x[p] + d.R[1] * y[p], d.R[3] * x[p] + d.R[4] * y[p],
+                                                      d.R[6] * x[p] + d.R[7] * y[p], z[p], d, sh[q][p], vv, okm[q][p]);
+                    w[q][p] = 0;
+                    if (ok) w[q][p] = load_mask_at(d.mask, mask_byte_offset(sh[q][p], vv, tile_row));
                 }
             }
             // U applications of backprojection.c:79-83; a zero pixel in any of the views wins
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                bool carve = false, keep = false;
+                unsigned long long carve = 0, keep = 0;
 #pragma unroll
                 for (int q = 0; q < U; ++q) {
-                    carve |= ok[q][p] & !fg[q][p];
-                    keep |= ok[q][p] & fg[q][p];
+                    const unsigned long long fg = __ballot(__builtin_amdgcn_ubfe(w[q][p], (uint32_t)sh[q][p], 1u) != 0u);  // (a word not loaded is 0)
+                    carve |= okm[q][p] & ~fg;
+                    keep |= fg;
                 }
-                if (carve & alive[p]) {
-                    alive[p] = false;
-                    zero[p] = false;
-                    labels[idx[p]] = -1;
-                } else if (zero[p] & keep) {
-                    zero[p] = false;
-                    if (FINAL) atomicCAS(&labels[idx[p]], 0, 1); else flipped[p] = true;
+                carve &= alive_m[p];
+                if (carve != 0) {  // wave-uniform
+                    if (lane_in(carve, bit_lo, bit_hi)) labels[idx[p]] = -1;
+                    alive_m[p] &= ~carve;
+                    zero_m[p] &= ~carve;
+                }
+                keep &= zero_m[p];
+                if (keep != 0) {
+                    if (FINAL) {
+                        if (lane_in(keep, bit_lo, bit_hi)) atomicCAS(&labels[idx[p]], 0, 1);
+                    } else {
+                        flip_m[p] |= keep;
+                    }
+                    zero_m[p] &= ~keep;
                 }
             }
         }
         if (FINAL) break;
         bool noroom = false;
         if (v1 < nrest) {  // views behind this stage: what is still alive goes on the output list
-            unsigned long long b[P];
             uint32_t tot = 0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                b[p] = __ballot(alive[p]);
-                tot += (uint32_t)__popcll(b[p]);
-            }
+            for (int p = 0; p < P; ++p) tot += (uint32_t)__popcll(alive_m[p]);
             if (tot != 0) {  // wave-uniform
                 // The survivors of sub-list s do not outnumber its entries, but spilled bulk units append here too:
                 // without room (the counter's `cut` marks where the written entries end) this wavefront takes its chunk through the
@@ -280,12 +312,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 uint32_t base = list_reserve(&ctl->count[sout][s], tot, subcap, lane);
                 noroom = base == 0xffffffffu;
                 if (!noroom) {
-                    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        if (alive[p])
-                            lout[(size_t)s * subcap + base + (uint32_t)__popcll(b[p] & below)] = idx[p] | (zero[p] ? 0x80000000u : 0u);
-                        base += (uint32_t)__popcll(b[p]);
+                        if (lane_in(alive_m[p], bit_lo, bit_hi))
+                            lout[(size_t)s * subcap + base + lanes_below(alive_m[p])] = idx[p] | (lane_in(zero_m[p], bit_lo, bit_hi) ? 0x80000000u : 0u);
+                        base += (uint32_t)__popcll(alive_m[p]);
                     }
                 }
             }
@@ -296,8 +327,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
         }
         if (!FINAL) {
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (alive[p] && flipped[p]) labels[idx[p]] = 1;
+            for (int p = 0; p < P; ++p) {
+                const unsigned long long m = alive_m[p] & flip_m[p];
+                if (m != 0 && lane_in(m, bit_lo, bit_hi)) labels[idx[p]] = 1;
+            }
         }
     }
     if (with_items) {
@@ -324,7 +357,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
             const float z = g.oz + (float)(int)k * g.vs;
             uint32_t idx[2];
-            bool alive[2], zero[2];
+            unsigned long long alive_m[2], zero_m[2];
             float y[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -333,14 +366,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 idx[p] = (il * g.ny + j) * g.nzp + k;
                 int32_t lab = -1;
                 if (inside) lab = labels[idx[p]];
-                alive[p] = lab != -1;
-                zero[p] = lab == 0;
+                alive_m[p] = __ballot(lab != -1);
+                zero_m[p] = __ballot(lab == 0);
                 y[p] = g.oy + (float)(int)j * g.vs;
             }
             unsigned long long m = ((unsigned long long)it.w << 32) | it.z;
             const uint32_t vbase = it.y;
             while (m != 0) {
-                if (__ballot(alive[0] | alive[1]) == 0) break;
+                if ((alive_m[0] | alive_m[1]) == 0) break;
                 const uint32_t a = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
                 uint32_t b = a;  // a lone view is applied twice: nothing changes the second time
@@ -348,32 +381,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     b = (uint32_t)__builtin_ctzll(m);
                     m &= m - 1;
                 }
-                bool ok[2][2], fg[2][2];
+                unsigned long long okm[2][2];
+                uint32_t w[2][2];
+                int sh[2][2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const ViewDesc d = ui.views[vbase + (q ? b : a)];
                     asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+                    const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        int uu, vv;
-                        ok[q][p] = project<ALL_SAFE>(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
-                                           d.R[6] * x + d.R[7] * y[p], z, d, uu, vv);
-                        uint32_t w = 0;
-                        if (ok[q][p]) w = load_mask_word(d.mask, mask_word_index(uu, vv, d.tiles_x));
-                        fg[q][p] = ((w >> (uu & 31)) & 1u) != 0;
+                        int vv;
+                        const bool ok = project<ALL_SAFE>(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
+                                                          d.R[6] * x + d.R[7] * y[p], z, d, sh[q][p], vv, okm[q][p]);
+                        w[q][p] = 0;
+                        if (ok) w[q][p] = load_mask_at(d.mask, mask_byte_offset(sh[q][p], vv, tile_row));
                     }
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const bool carve = (ok[0][p] & !fg[0][p]) | (ok[1][p] & !fg[1][p]);
-                    const bool keep = (ok[0][p] & fg[0][p]) | (ok[1][p] & fg[1][p]);
-                    if (carve & alive[p]) {
-                        alive[p] = false;
-                        zero[p] = false;
-                        labels[idx[p]] = -1;
-                    } else if (zero[p] & keep) {
-                        zero[p] = false;
-                        atomicCAS(&labels[idx[p]], 0, 1);
+                    unsigned long long carve = 0, keep = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned long long fg = __ballot(__builtin_amdgcn_ubfe(w[q][p], (uint32_t)sh[q][p], 1u) != 0u);
+                        carve |= okm[q][p] & ~fg;
+                        keep |= fg;
+                    }
+                    carve &= alive_m[p];
+                    if (carve != 0) {
+                        if (lane_in(carve, bit_lo, bit_hi)) labels[idx[p]] = -1;
+                        alive_m[p] &= ~carve;
+                        zero_m[p] &= ~carve;
+                    }
+                    keep &= zero_m[p];
+                    if (keep != 0) {
+                        if (lane_in(keep, bit_lo, bit_hi)) atomicCAS(&labels[idx[p]], 0, 1);
+                        zero_m[p] &= ~keep;
                     }
                 }
             }

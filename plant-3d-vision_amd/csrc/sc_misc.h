@@ -22,6 +22,22 @@ __global__ __launch_bounds__(kBlock) void div_selftest_kernel(uint64_t count, ui
             n2 = __uint_as_float((b & 0x807fffffu) | ((110u + ((e >> 5) & 31u)) << 23));
             dd = __uint_as_float((c & 0x007fffffu) | ((118u + ((e >> 10) & 15u)) << 23));
         }
+        if (mode == 2) {  // certified views: numerators the short division is not proved for (|n| <= 2^-40, zero and
+                          // denormals included) -- the PIXEL and the picture test must be those of the exact quotient
+            n1 = (e & 0x80000000u) ? __uint_as_float(a & 0x80000000u) : __uint_as_float((a & 0x807fffffu) | ((e & 127u) % 88u) << 23);
+            dd = __uint_as_float((c & 0x007fffffu) | ((117u + ((e >> 10) & 63u) % 40u) << 23));
+            const float k = __uint_as_float((b & 0x807fffffu) | (((e >> 16) & 255u) % 157u) << 23);
+            const uint32_t h = mix32(e ^ 0x51ed270bu);
+            const float cc = __uint_as_float((h & 0x807fffffu) | (((h >> 23) & 255u) % 157u) << 23);
+            const int W = 1 + (int)(mix32(h) & 0xffffffu);
+            ++fast;
+            const float r = refined_rcp(dd);
+            const float uf = div_by_rcp(n1, dd, r) * k + cc, wf = (n1 / dd) * k + cc;
+            const int u = (int)uf, w = (int)wf;
+            const bool oku = (uint32_t)u < (uint32_t)W, okw = (wf > -1.0f) & (wf < (float)W);
+            bad += (oku != okw) || (okw && u != w);
+            continue;
+        }
         if (div_fast_range(n1, n2, dd)) {
             ++fast;
             float r = refined_rcp(dd);

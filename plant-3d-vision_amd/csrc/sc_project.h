@@ -18,15 +18,18 @@ __device__ __forceinline__ uint32_t spread_block(uint32_t bid, uint32_t nblocks)
 }
 
 // Correctly rounded p/pz for BOTH image coordinates from ONE reciprocal.
-// hipcc expands an IEEE f32 division into  div_scale x2, rcp, 2 fma (Newton step on the
-// reciprocal), mul, 4 fma (two corrections of the quotient), div_fmas, div_fixup.  When the
-// operands are in a range where v_div_scale scales nothing and v_div_fixup fixes nothing
-// (denominator and both numerators normal, within 2^+-40: see the V_DIV_SCALE_F32 rules), that
-// expansion is exactly the plain-FMA sequence below, so running it by hand with the refined
-// reciprocal SHARED between the two numerators gives bit-identical quotients with 13
-// instructions instead of 22 (and one quarter-rate v_rcp_f32 instead of two).  Any lane outside
-// the range sends its whole wavefront through the compiler's division.
-// sc_selftest_division() compares the two bit-for-bit on 2^32 operand pairs.
+// hipcc expands an IEEE f32 division into  div_scale x2, rcp, 2 fma (Newton step on the reciprocal), mul, 4 fma (two
+// corrections of the quotient), div_fmas, div_fixup: 22 instructions and two quarter-rate v_rcp_f32 for the two image
+// coordinates.  Here: the reciprocal, refined by one Newton step, is SHARED between the two numerators, and each
+// quotient takes ONE correction:  q = n r;  q += r (n - d q)  -- 9 instructions in all.
+// That this is the correctly rounded quotient was established exhaustively (round 4, tools/probes/div_exhaustive.hip,
+// profiles/r04_div_exhaustive.json): all 2^23 x 2^23 = 7.04e13 pairs of significands against hipcc's division on an
+// MI355X, 0 differences (the same sequence from the UNREFINED reciprocal differs on 47 045 pairs, so the probe can see
+// a failure).  Every operation is a multiplication or an FMA, hence a power-of-two scale of n or d scales every
+// intermediate exactly as long as none of them leaves the normal range, and the rounding decisions depend on the
+// significands alone: with d and |n| within 2^+-40 the smallest intermediate (the residual n - d q, a multiple of
+// 2^-47 |n|) is above 2^-88.  Any lane outside that range sends its whole wavefront through the compiler's division.
+// sc_selftest_division() compares the two bit-for-bit on 2^32 sampled operand pairs with the exponents spread.
 __device__ __forceinline__ bool div_fast_range(float px, float py, float pz) {
     // fmin/fmax drop a NaN operand, so NaNs are excluded by explicit (ordered) comparisons
     bool ordered = !__builtin_isunordered(px, py);
@@ -43,8 +46,6 @@ __device__ __forceinline__ float refined_rcp(float d) {
 __device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
     float q = n * r;
     float e = __builtin_fmaf(-d, q, n);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e, r, q);
 }
 
@@ -54,38 +55,54 @@ __device__ __forceinline__ float div_by_rcp(float n, float d, float r) {
 // What the instructions cost on gfx950 (tools/probes/valu_probe.hip, cycles of a SIMD per wavefront
 // instruction, independent instructions, 8 wavefronts per SIMD): v_mul_f32 / v_add_f32 / v_sub_f32 /
 // v_and / v_lshrrev / v_add_u32 / v_mov 2.6; every three-operand or VOP3-only form (v_fma_f32, v_cmp_*,
-// v_cvt_*, v_min/max, v_bfi, v_mad_*) 4.3-4.7; v_rcp_f32 8.3.  Where the host has certified the pose
-// (d.safe: every voxel of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30, intrinsics finite and below
-// 2^30) the range test of the fast division is the two comparisons left of it and the picture test is
-// two unsigned comparisons of the truncated coordinates -- uf, vf are finite there, v_cvt_i32_f32
-// truncates toward zero ((-1, 0) -> 0, accepted like the reference's cast) and saturates, so
-// (unsigned)u < W is exactly  uf > -1 && uf < W.
-// ALL_SAFE: the host has certified EVERY view this kernel instance will see (certify_view), so the test of d.safe and
-// the general path behind it are compiled out of the view loop -- same arithmetic, fewer basic blocks.
+// v_cvt_*, v_min/max, v_bfi, v_mad_*) 4.3-4.7; v_rcp_f32 8.3.
+//
+// CERTIFIED views (d.safe, set by certify_view on the host: every voxel of the grid has 2^-10 < pz and |px|, |py|,
+// pz < 2^30 under this pose, intrinsics finite and below 2^30) take the short division with NO test of the operands:
+//  * 2^-90 <= |n| < 2^30 (n = px or py): every rounded intermediate is normal (q >= 2^-120) and the residual, a
+//    multiple of 2^-47 |n| >= 2^-137, is exactly representable (denormals are not flushed: Makefile), so the scaling
+//    argument above holds and q is the correctly rounded quotient;
+//  * |n| < 2^-90 (zero and denormals included): the exact and the short quotient are both below 2^-78 in magnitude
+//    (r < 2^10 (1 + 2^-22), and the residual of a quotient rounded on the denormal grid is below 2^-119), so
+//    |q K| < 2^-48 for K < 2^30, and  uf = q K + c  is  c  itself in both when |c| >= 2^-23 (the addend is below a
+//    quarter of c's last place) and below 1 in magnitude in both otherwise: (int)uf and the picture test agree.
+//    sc_selftest_division mode 2 samples that regime (the pixel and the picture test, not the quotient's bits).
+// The picture test there is two unsigned comparisons of the truncated coordinates -- uf, vf are finite, v_cvt_i32_f32
+// truncates toward zero ((-1, 0) -> 0, accepted like the reference's cast) and saturates, so (unsigned)u < W is
+// exactly  uf > -1 && uf < W.
+// ALL_SAFE: the host has certified EVERY view this kernel instance will see, so the test of d.safe and the general
+// path behind it are compiled out: the projection is straight-line code.
+// okm: the wavefront's mask of the lanes that return true (for the kernels that keep their per-lane state as masks
+// in scalar registers: as the AND of the two comparisons' own masks it costs no vector instruction).
 template <bool ALL_SAFE = false>
 __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
-                                        const ViewDesc &d, int &u, int &v) {
+                                        const ViewDesc &d, int &u, int &v, unsigned long long &okm) {
     float pz = (az + d.R[8] * z) + d.t[2];  // :11
     float px = (ax + d.R[2] * z) + d.t[0];  // :17
     float py = (ay + d.R[5] * z) + d.t[1];  // :18
-    const bool safe = ALL_SAFE || d.safe != 0;  // wave-uniform
-    unsigned long long outside;             // lanes whose operands the fast division does not cover
-    if (safe) {
-        outside = __builtin_amdgcn_ballot_w64(!(fabsf(px) > 0x1p-40f)) | __builtin_amdgcn_ballot_w64(!(fabsf(py) > 0x1p-40f));
-        asm volatile("" : "+s"(outside));  // keeps the two ballots apart: merged, the lane predicate
-    } else {                               // travels through a vector register and back (two more instructions)
-        outside = __builtin_amdgcn_ballot_w64(!div_fast_range(px, py, pz));
-        asm volatile("" : "+s"(outside));
-    }
-    if (outside == 0) {
+    if (ALL_SAFE || d.safe != 0) {  // wave-uniform
         const float r = refined_rcp(pz);
         // (the packed forms v_pk_mul/fma_f32 were tried for the two chains: no faster in these kernels)
         const float uf = div_by_rcp(px, pz, r) * d.K[0] + d.K[2];  // :20
         const float vf = div_by_rcp(py, pz, r) * d.K[1] + d.K[3];  // :21
         u = (int)uf;
         v = (int)vf;
-        if (safe) return ((uint32_t)u < (uint32_t)d.W) & ((uint32_t)v < (uint32_t)d.H);
-        return (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);  // pz > 0 here
+        const bool in_u = (uint32_t)u < (uint32_t)d.W, in_v = (uint32_t)v < (uint32_t)d.H;
+        okm = __builtin_amdgcn_ballot_w64(in_u) & __builtin_amdgcn_ballot_w64(in_v);
+        return in_u & in_v;
+    }
+    // lanes whose operands the short division does not cover
+    unsigned long long outside = __builtin_amdgcn_ballot_w64(!div_fast_range(px, py, pz));
+    asm volatile("" : "+s"(outside));
+    if (outside == 0) {
+        const float r = refined_rcp(pz);
+        const float uf = div_by_rcp(px, pz, r) * d.K[0] + d.K[2];  // :20
+        const float vf = div_by_rcp(py, pz, r) * d.K[1] + d.K[3];  // :21
+        u = (int)uf;
+        v = (int)vf;
+        const bool ok = (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);  // pz > 0 here
+        okm = __builtin_amdgcn_ballot_w64(ok);
+        return ok;
     }
     const float qx = px / pz, qy = py / pz;
     float uf = qx * d.K[0] + d.K[2];  // :20
@@ -97,7 +114,13 @@ __device__ __forceinline__ bool project(float ax, float ay, float az, float z,
     bool ok = !(pz < 0.0f) & (uf > -1.0f) & (uf < d.Wf) & (vf > -1.0f) & (vf < d.Hf);
     u = (int)uf;
     v = (int)vf;
+    okm = __builtin_amdgcn_ballot_w64(ok);
     return ok;
+}
+template <bool ALL_SAFE = false>
+__device__ __forceinline__ bool project(float ax, float ay, float az, float z, const ViewDesc &d, int &u, int &v) {
+    unsigned long long okm;
+    return project<ALL_SAFE>(ax, ay, az, z, d, u, v, okm);
 }
 
 __device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
@@ -111,6 +134,20 @@ __device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
 typedef const __attribute__((address_space(1))) uint32_t *gmask_t;
 __device__ __forceinline__ uint32_t load_mask_word(const void *mask, uint32_t word) {
     return ((gmask_t)(uintptr_t)mask)[word];
+}
+
+// The same as a BYTE offset, for loads of the form  scalar base + 32-bit lane offset  (no 64-bit address arithmetic per
+// lane): tile row v >> 5 starts at (v & ~31) * tile_row bytes with tile_row = 4 * tiles_x (a row of tiles is
+// 128 * tiles_x bytes), tile u >> 5 of it at (u & ~31) * 4, row v & 31 of the tile at (v & 31) * 4.  Both factors of the
+// product are below 2^24 (check_view_args: H <= 2^24, W <= 2^24) and a view's bits are below 2^32 bytes (H W <= 2^34).
+__device__ __forceinline__ uint32_t mask_byte_offset(int u, int v, uint32_t tile_row) {
+    uint32_t in_row;  // (u & ~31) | (v & 31): one v_bfi_b32 (left to itself the compiler makes v_and + v_and_or of it)
+    asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(in_row) : "v"(v), "v"(u));
+    return __umul24((uint32_t)v & ~31u, tile_row) + (in_row << 2);
+}
+typedef const __attribute__((address_space(1))) char *gbytes_t;
+__device__ __forceinline__ uint32_t load_mask_at(const void *mask, uint32_t byte_offset) {
+    return *(gmask_t)((gbytes_t)(uintptr_t)mask + byte_offset);
 }
 
 struct Vox4 {

@@ -22,6 +22,19 @@ struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave
 };
 static_assert(sizeof(ViewDesc) == 128, "ViewDesc layout");
 
+// n / d for n < 2^31 without a division (Granlund & Montgomery): t = mulhi(n, m); q = (t + n) >> s, exact for every
+// n below 2^31 (t + n cannot overflow there) with s = ceil(log2 d), m = floor(2^32 (2^s - d) / d) + 1 (host: fast_div).
+struct FastDiv {
+    uint32_t m, s;
+};
+__host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__umulhi(n, f.m) + n) >> f.s;
+#else
+    return (uint32_t)((((uint64_t)n * f.m) >> 32) + n) >> f.s;
+#endif
+}
+
 struct GridDesc {
     float ox, oy, oz, vs;
     uint32_t ny, nz;
@@ -31,6 +44,7 @@ struct GridDesc {
     uint32_t istride;   // global x step between the engine's planes (1: slab, W: plane-cyclic)
     uint32_t nzp;       // row pitch of the state in voxels: nz rounded up to a multiple of 64 (a row = one
                         // (plane, column) run of nz voxels, 256-byte aligned; the padding is never read back)
+    FastDiv by_nzp, by_ny;  // for the survivor stages' decode of an entry (an element index below 2^31)
 };
 
 constexpr int kBlock = 256;

@@ -155,7 +155,7 @@ struct sc_engine {
     bool dead_clean = false;   // `dead` describes the labels (false after a clear: the next flags kernel rewrites it)
     int64_t final_voxels = 2;  // voxels per lane in the final survivor stage (1 or 2)
     int64_t stage1_voxels = 2; // ... in the stages before it
-    int64_t fill_blocks = 512; // persistent store blocks of a list stage (0: one short block per strip)
+    int64_t fill_blocks = 256; // persistent store blocks of a list stage (0: one short block per strip); round 4: 256 (one per CU) from 512, measured after their loop lost its vector instructions
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
     int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
@@ -308,6 +308,12 @@ struct LaunchTimer {
     }
 };
 
+FastDiv fast_div(uint32_t d) {  // see fdiv (sc_types.h); d >= 1
+    uint32_t s = 0;
+    while (((uint64_t)1 << s) < d) ++s;
+    return FastDiv{(uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - d)) / d + 1u), s};
+}
+
 GridDesc grid_desc(const sc_engine *e) {
     GridDesc g;
     g.ox = e->origin[0];
@@ -321,6 +327,8 @@ GridDesc grid_desc(const sc_engine *e) {
     g.nzp = (uint32_t)e->nzp;
     g.gpc = (uint32_t)(e->nzp / 4);
     g.ngroups = (uint64_t)e->planes * (uint64_t)e->ny * g.gpc;
+    g.by_nzp = fast_div(g.nzp);
+    g.by_ny = fast_div(g.ny);
     return g;
 }
 
@@ -1042,7 +1050,7 @@ int flush(sc_engine *e, size_t count = 0) {
             for (size_t q = 0; q < nv; ++q) pj.order[q] = (uint16_t)perm[q];
             const FusedPlan fp = fused_plan(e, nv, true);
             int ahead = (int)nv;
-            if (e->pack_ride && fp.brick && fp.compact && fp.defer_stores && fp.dense_store_strips == 0)
+            if (e->pack_ride && fp.brick && fp.compact && fp.defer_stores)  // (the dense stage may carry store blocks AND riders)
                 ahead = std::min<int>((int)nv, std::max(fp.flag_views, fp.s1));
             pj.slot0 = 0;
             pj.nslots = ahead;
@@ -1452,7 +1460,7 @@ int check_view_args(const sc_engine *e, const float *K, const float *R, const fl
                     const void *mask, int H, int W) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     if (!K || !R || !t || !mask) return fail(SC_ERR_INVALID, "null view argument");
-    if (H <= 0 || W <= 0 || H > (1 << 24) || W > (1 << 24))
+    if (H <= 0 || W <= 0 || H > (1 << 24) || W > (1 << 24) || (int64_t)H * W > ((int64_t)1 << 34))  // (a view's bits: below 2^32 bytes)
         return fail(SC_ERR_INVALID, "bad mask shape %d x %d", H, W);
     return SC_OK;
 }

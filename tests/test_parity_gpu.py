@@ -44,15 +44,16 @@ def test_library_sees_gfx950(gpu_device):
     assert nat.device_count() >= 1
 
 
-@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 77), (0, 5)])
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 77), (0, 5), (2, 3), (2, 2024)])
 def test_shared_reciprocal_division_is_bit_identical(gpu_device, mode, seed):
     """The kernels divide p_x and p_y by p_z through one refined reciprocal; inside its
-    operand range that must equal hipcc's IEEE division bit for bit (2^32 triples a run)."""
+    operand range that must equal hipcc's IEEE division bit for bit (2^32 triples a run).  Mode 2: numerators
+    below that range under a certified view -- the pixel and the picture test must be the exact quotient's."""
     e = nat.Engine([4, 4, 4], [0, 0, 0], 1.0, nat.SC_MODE_CARVE)
     bad, fast = e.selftest_division(1 << 32, seed=seed, mode=mode)
     e.close()
     assert bad == 0
-    if mode == 1:
+    if mode in (1, 2):
         assert fast == 1 << 32  # projection-like operands all take the fast path
     else:
         assert 0 < fast < 1 << 31  # raw bit patterns mostly fall outside the range
@@ -292,6 +293,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0},  # ... asked whatever the tiles settled
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
     {"SC_OPT_SAFE_KERNELS": 0},                                           # the list kernels with the general path compiled in
+    {"SC_OPT_FILL_BLOCKS": 64, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_STAGE1_STORE_SHARE": 3},  # few store blocks, odd shares
     {"SC_OPT_LDS_TILES": 1},                                              # the dense stage's mask words staged in LDS
     {"SC_OPT_LDS_TILES": 1, "SC_OPT_DENSE_VIEWS": 3, "SC_OPT_UNIT_CULL": 0},
 ])

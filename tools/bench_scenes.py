@@ -36,6 +36,9 @@ def main():
     for kind in a.scenes.split(","):
         if kind == "literal":
             shape, origin, vs, views = scenes.literal_real_plant_scene(60, "plant")
+        elif kind == "empty":  # the plant's rig over pictures without foreground: every brick is carved whole (the fill alone)
+            shape, origin, vs, views = scenes.make_scene(a.n, a.views, "plant")
+            views = [(K, R, t, np.zeros_like(m)) for K, R, t, m in views]
         else:
             shape, origin, vs, views = scenes.make_scene(a.n, a.views, kind)
         eng = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, device=0)
