@@ -79,10 +79,11 @@
                                      page-locked ring and are packed on the device (round 1-3 path)                 */
 #define SC_OPT_HOST_THREADS 40    /* threads of the library's host pool (mask bits, label widening): 0 = default,
                                      min(8, hardware threads / 2).  Process-wide; before the pool's first use        */
-#define SC_OPT_LDS_TILES 41       /* 0 (default) / 1: the dense stage loads the window of mask words a unit's 256 voxels
-                                     project onto into LDS once per view and the voxels read their words from there --
-                                     the north star's "LDS-staged mask tiles per wavefront".  Measured slower on every
-                                     scene: the gathers hit L2 and the stage is bound by its arithmetic */
+#define SC_OPT_LDS_TILES 41       /* accepted, no effect.  Was: the dense stage loads the window of mask words a unit's 256
+                                     voxels project onto into LDS once per view and the voxels read their words from there
+                                     -- the north star's "LDS-staged mask tiles per wavefront".  Built, exact, measured
+                                     slower on every scene (DESIGN_APPENDIX.md 12: the gathers hit L2 and the stage is
+                                     bound by its arithmetic) and removed when the stage's lane state moved to scalar masks */
 #define SC_OPT_BULK_LIVE 42       /* sixteenths of the bricks (2): with fewer live bricks than that after the tile verdicts
                                      the batch is a thin object and no unit goes on the bulk list (decided by the dense
                                      stage on the device from the batch's own live count); 0: the list is always kept */

@@ -4,132 +4,51 @@
 // Two views applied to the four voxels of a lane: both projections first, then the eight gathers of a
 // lane in one flight (the kernels that call this wait on memory, not on arithmetic), then
 // backprojection.c:79-83 for the first view and, for what it left alive, for the second.
+// What a lane knows about its voxels is kept as WAVEFRONT masks in scalar registers (round 4, as in the survivor
+// stages): alive[e] -- voxel e of the lane is not carved (:67) --, kept[e] -- some view so far has found it over
+// foreground while it was alive (:81: a label 0 becomes 1; what the label was is looked at once, when the labels are
+// written).  The comparisons of a projection leave lane masks anyway, so :79-83 is scalar and/or on them; the vector
+// instructions of a (voxel, view) pair beyond its projection are the offset select, the gather and the bit test.
+template <bool ALL_SAFE = false>
 __device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db, bool two, float x, float y,
-                                          const float (&z)[4], int32_t (&lab)[4], uint32_t &alive) {
+                                          const float (&z)[4], unsigned long long (&alive)[4], unsigned long long (&kept)[4]) {
     const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
     const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
-    const uint32_t *bita = static_cast<const uint32_t *>(da.mask);
-    const uint32_t *bitb = static_cast<const uint32_t *>(db.mask);
-    bool oka[4], okb[4];
+    const uint32_t rowa = (uint32_t)da.tiles_x * 4u, rowb = (uint32_t)db.tiles_x * 4u;
+    unsigned long long oka[4], okb[4];
     uint32_t wa[4], wb[4];
     int sha[4], shb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        int u, v;
-        const bool live = (alive >> e) & 1u;
-        oka[e] = project(aax, aay, aaz, z[e], da, u, v) & live;
-        sha[e] = u & 31;
-        wa[e] = load_mask_word(bita, oka[e] ? mask_word_index(u, v, da.tiles_x) : 0u);
-        okb[e] = project(bax, bay, baz, z[e], db, u, v) & live & two;
-        shb[e] = u & 31;
-        wb[e] = load_mask_word(bitb, okb[e] ? mask_word_index(u, v, db.tiles_x) : 0u);
+        int v;
+        // (dead lanes and lanes outside the picture gather word 0: cheaper than a branch around the load)
+        bool ok = project<ALL_SAFE>(aax, aay, aaz, z[e], da, sha[e], v, oka[e]);
+        wa[e] = load_mask_at(da.mask, ok ? mask_byte_offset(sha[e], v, rowa) : 0u);
+        ok = project<ALL_SAFE>(bax, bay, baz, z[e], db, shb[e], v, okb[e]);
+        wb[e] = load_mask_at(db.mask, ok ? mask_byte_offset(shb[e], v, rowb) : 0u);
     }
+    const unsigned long long second = two ? ~0ull : 0ull;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (oka[e]) {
-            if (((wa[e] >> sha[e]) & 1u) == 0) {  // :79
-                lab[e] = -1;
-                alive &= ~(1u << e);
-            } else if (lab[e] == 0) {  // :81
-                lab[e] = 1;
-            }
-        }
-        if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
-            if (((wb[e] >> shb[e]) & 1u) == 0) {
-                lab[e] = -1;
-                alive &= ~(1u << e);
-            } else if (lab[e] == 0) {
-                lab[e] = 1;
-            }
-        }
+        unsigned long long fg = __ballot(__builtin_amdgcn_ubfe(wa[e], (uint32_t)sha[e], 1u) != 0u);
+        unsigned long long seen = oka[e] & alive[e];
+        alive[e] &= ~(seen & ~fg);  // :79
+        kept[e] |= seen & fg;       // :81
+        fg = __ballot(__builtin_amdgcn_ubfe(wb[e], (uint32_t)shb[e], 1u) != 0u);
+        seen = okb[e] & alive[e] & second;  // a voxel the first view carved is skipped (:67)
+        alive[e] &= ~(seen & ~fg);
+        kept[e] |= seen & fg;
     }
 }
 
-// EXPERIMENT (SC_OPT_LDS_TILES, off by default): the north star's "LDS-staged mask tiles per
-// wavefront".  The wavefront first projects its 256 voxels (a unit: 16 columns x 16 voxels), takes the window of
-// mask words their pixels fall on -- rows vmin .. vmax of tile columns tmin .. tmax, from the pixels themselves, no
-// bound needed --, loads that window ONCE, one word per lane, into its LDS buffer, and every voxel then reads its
-// word from LDS instead of gathering it from global memory (4 ds_read per lane and view in place of 4 global
-// loads, 1 global load per lane and view in place of 4).  A window of more than 64 words, or wider than two tile
-// columns, takes the plain gathers.
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ void staged_words(const ViewDesc &d, const int (&u)[4], const int (&v)[4], const bool (&ok)[4],
-                                             uint32_t *buf, uint32_t lane, uint32_t (&w)[4]) {
-    int vmin = 0x7fffffff, vmax = -1, tmin = 0x7fffffff, tmax = -1;
+// The labels of a lane's four voxels behind two_views: carved -> -1; kept by some view and 0 before -> 1; else as before.
+__device__ __forceinline__ void labels_behind(int32_t (&lab)[4], const unsigned long long (&alive)[4],
+                                              const unsigned long long (&kept)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (ok[e]) {
-            vmin = min(vmin, v[e]); vmax = max(vmax, v[e]);
-            tmin = min(tmin, u[e] >> 5); tmax = max(tmax, u[e] >> 5);
-        }
-    }
-    vmin = __builtin_amdgcn_readfirstlane(wave_min_i32(vmin));
-    vmax = __builtin_amdgcn_readfirstlane(wave_max_i32(vmax));
-    tmin = __builtin_amdgcn_readfirstlane(wave_min_i32(tmin));
-    tmax = __builtin_amdgcn_readfirstlane(wave_max_i32(tmax));
-    const uint32_t *bits = static_cast<const uint32_t *>(d.mask);
-    const int nrows = vmax - vmin + 1, ntx = tmax - tmin + 1;
-    if (vmax < 0) {  // nobody in the picture
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = 0u;
-        return;
-    }
-    if (ntx > 2 || nrows * ntx > 64) {  // wave-uniform: too wide a window, the plain gathers
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u[e], v[e], d.tiles_x) : 0u);
-        return;
-    }
-    const int r = ntx == 1 ? (int)lane : (int)(lane >> 1), c = ntx == 1 ? 0 : (int)(lane & 1u);
-    if (r < nrows) buf[lane] = load_mask_word(bits, mask_word_index((tmin + c) * 32, vmin + r, d.tiles_x));
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = ok[e] ? buf[(v[e] - vmin) * ntx + ((u[e] >> 5) - tmin)] : 0u;
-    __builtin_amdgcn_wave_barrier();  // (the buffer is free for the next view)
-}
-
-__device__ __forceinline__ void two_views_lds(const ViewDesc &da, const ViewDesc &db, bool two, float x, float y,
-                                              const float (&z)[4], int32_t (&lab)[4], uint32_t &alive, uint32_t *buf,
-                                              uint32_t lane) {
-    const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
-    const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
-    bool oka[4], okb[4];
-    uint32_t wa[4], wb[4];
-    int ua[4], va[4], ub[4], vb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool live = (alive >> e) & 1u;
-        oka[e] = project(aax, aay, aaz, z[e], da, ua[e], va[e]) & live;
-        okb[e] = project(bax, bay, baz, z[e], db, ub[e], vb[e]) & live & two;
-    }
-    staged_words(da, ua, va, oka, buf, lane, wa);
-    staged_words(db, ub, vb, okb, buf + 64, lane, wb);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (oka[e]) {
-            if (((wa[e] >> (ua[e] & 31)) & 1u) == 0) {  // :79
-                lab[e] = -1;
-                alive &= ~(1u << e);
-            } else if (lab[e] == 0) {  // :81
-                lab[e] = 1;
-            }
-        }
-        if (okb[e] && ((alive >> e) & 1u)) {  // a voxel the first view carved is skipped (:67)
-            if (((wb[e] >> (ub[e] & 31)) & 1u) == 0) {
-                lab[e] = -1;
-                alive &= ~(1u << e);
-            } else if (lab[e] == 0) {
-                lab[e] = 1;
-            }
-        }
+        const int32_t up = lab[e] == 0 ? 1 : lab[e];
+        const int32_t live = __builtin_amdgcn_inverse_ballot_w64(kept[e]) ? up : lab[e];
+        lab[e] = __builtin_amdgcn_inverse_ballot_w64(alive[e]) ? live : -1;
     }
 }
 
@@ -137,14 +56,12 @@ template <bool FRESH>
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
-                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0,
-                                             uint32_t *lds_tiles = nullptr) {  // non-null: the LDS-staging experiment
+                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0) {
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
-    // may be short, and when nz % 4 != 0 groups are not 16-byte aligned (element accesses)
+    // may be short (the pitch is a multiple of 64: groups are 16-byte aligned)
     const bool inside = j < g.ny && k0 < g.nz;
     const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
-    const bool vec = (g.nzp & 3u) == 0;  // grid-uniform (the pitch is a multiple of 64: always)
     const uint64_t elem = ((uint64_t)il * g.ny + j) * g.nzp + k0;
     int32_t *p = labels + elem;
     int32_t lab[4], was[4];
@@ -154,24 +71,19 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (e < nvalid) lab[e] = init;
-    } else if (vec) {
-        if (inside) {
-            int4 q = *reinterpret_cast<const int4 *>(p);
-            lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
-        }
-    } else {
+    } else if (inside) {
+        int4 q = *reinterpret_cast<const int4 *>(p);
+        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (e < nvalid) lab[e] = p[e];
+            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
     }
-    uint32_t alive = 0;
+    unsigned long long alive[4], kept[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         was[e] = lab[e];
-        if (lab[e] != -1) alive |= 1u << e;  // :67
+        alive[e] = __ballot(lab[e] != -1);  // :67
+        kept[e] = 0;
     }
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
     const float y = g.oy + (float)(int)j * g.vs;
@@ -180,32 +92,22 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
 
     for (int vi = 0; vi < nviews; vi += 2) {
-        if (__ballot(alive != 0) == 0) break;  // nothing left alive in this wavefront
+        if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0) break;  // nothing left alive in this wavefront
         const bool two = vi + 1 < nviews;      // wave-uniform
         const ViewDesc da = views[vi];
         const ViewDesc db = views[two ? vi + 1 : vi];
-        if (lds_tiles != nullptr) two_views_lds(da, db, two, x, y, z, lab, alive, lds_tiles, lane);  // wave-uniform
-        else two_views(da, db, two, x, y, z, lab, alive);
+        two_views(da, db, two, x, y, z, alive, kept);
     }
+    labels_behind(lab, alive, kept);
 
-    if (vec) {
-        bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
-        if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (e < nvalid && (FRESH || lab[e] != was[e])) p[e] = lab[e];
-    }
+    const bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
+    if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
 
     if (ap.list != nullptr) {
         ap.sub = (lb * 0x9E3779B1u) >> 24;
-        unsigned long long b[4];
         uint32_t total = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b[e] = __ballot((alive >> e) & 1u);
-            total += (uint32_t)__popcll(b[e]);
-        }
+        for (int e = 0; e < 4; ++e) total += (uint32_t)__popcll(alive[e]);
         bool bulked = false;
         if (ap.bulk != nullptr && total >= ap.bulk_min) {  // wave-uniform
             uint32_t pos = 0;
@@ -223,15 +125,12 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
                 if (lane == 0) ap.ctl->overflow = 1u;
             } else {
                 uint32_t *dst = ap.list + (size_t)ap.sub * ap.subcap + base;
-                unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
                 uint32_t off = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if ((alive >> e) & 1u) {
-                        uint32_t rank = off + (uint32_t)__popcll(b[e] & below);
-                        dst[rank] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
-                    }
-                    off += (uint32_t)__popcll(b[e]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(alive[e]))
+                        dst[off + lanes_below(alive[e])] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
+                    off += (uint32_t)__popcll(alive[e]);
                 }
             }
         }
@@ -380,7 +279,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
 // the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
 // stage fills the others, see carve_list_kernel).
 template <bool FRESH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
                                                              uint32_t bricks_y, uint32_t bricks_z,
@@ -389,7 +288,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                                                              ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
                                                              uint32_t parity, int nverd_arg, uint32_t verd_max_live,
-                                                             int lds_tiles, uint32_t bulk_min_live) {
+                                                             uint32_t bulk_min_live) {
     // Behind the walkers come the riders, and the store blocks LAST: blocks start in the order of their numbers, and what
     // the riders pack is waited for by the next kernel, while a store only has to be done by the end of this one
     // (with the store blocks in front the riders started when the stores were through, and a sixteenth of the fill
@@ -419,8 +318,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     // the brick is live because a 32x32 tile under it touches the plant, the unit lies beside it -- and projects the
     // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
     // tickets keep every wavefront busy whatever the bricks hold.)
-    __shared__ uint32_t s_tiles[kBlock / 64][128];  // the LDS-staging experiment: two views' windows per wavefront
-    uint32_t *my_tiles = lds_tiles ? s_tiles[threadIdx.x >> 6] : nullptr;
     const uint32_t nlive = ctl->nlive[parity];
     // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
     const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
@@ -501,7 +398,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u, my_tiles);
+            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
 #ifdef SC_TRACE_DENSE
             ++tr_units;
 #endif
@@ -528,7 +425,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
 // block per strip of the grid -- after the first views nearly every brick is dead and a launch costs
 // what its few live and newly settled bricks cost, not a pass over the grid.
 template <bool FRESH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_brick_light_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void carve_brick_light_kernel(
     int32_t *__restrict__ labels, GridDesc g, const ViewDesc *__restrict__ views, int nviews, int32_t init,
     uint32_t bricks_y, uint32_t bricks_z, const uint32_t *__restrict__ live, const uint32_t *__restrict__ fill_list,
     const ListCtl *ctl, uint32_t nwalkers, uint32_t parity) {

@@ -31,13 +31,6 @@ __device__ __forceinline__ uint32_t list_reserve(ListCounter *counter, uint32_t 
     return __shfl(base, 0);
 }
 
-// Is this lane's bit set in a wavefront mask held in scalar registers?  (bit_lo / bit_hi: the lane's own bit in the low /
-// high half, two vector registers for the life of the kernel; three full-rate instructions where a 64-bit shift by the
-// lane number would be a two-pass one)
-__device__ __forceinline__ bool lane_in(unsigned long long m, uint32_t bit_lo, uint32_t bit_hi) {
-    return (((uint32_t)m & bit_lo) | ((uint32_t)(m >> 32) & bit_hi)) != 0u;
-}
-
 struct UnitSpill {
     const uint32_t *units;  // null: no bulk list.  [kSub][cap] unit ids, counts in ctl->count[3]
     uint32_t cap, floor;
@@ -115,7 +108,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     }
     const uint32_t chunks = pref[kSub];
     const uint32_t lane = tid & 63u;
-    const uint32_t bit_lo = lane < 32u ? 1u << lane : 0u, bit_hi = lane < 32u ? 0u : 1u << (lane - 32u);  // see lane_in
     __shared__ uint32_t ipref[kSub + 1];  // FINAL: the work items' prefix; else: the spilled bulk units'
     const bool with_items = FINAL && ui.items != nullptr;  // grid-uniform
     uint32_t uchunks = 0;  // chunks made of spilled bulk units, behind the list's own
@@ -284,14 +276,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 }
                 carve &= alive_m[p];
                 if (carve != 0) {  // wave-uniform
-                    if (lane_in(carve, bit_lo, bit_hi)) labels[idx[p]] = -1;
+                    if (__builtin_amdgcn_inverse_ballot_w64(carve)) labels[idx[p]] = -1;
                     alive_m[p] &= ~carve;
                     zero_m[p] &= ~carve;
                 }
                 keep &= zero_m[p];
                 if (keep != 0) {
                     if (FINAL) {
-                        if (lane_in(keep, bit_lo, bit_hi)) atomicCAS(&labels[idx[p]], 0, 1);
+                        if (__builtin_amdgcn_inverse_ballot_w64(keep)) atomicCAS(&labels[idx[p]], 0, 1);
                     } else {
                         flip_m[p] |= keep;
                     }
@@ -314,8 +306,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 if (!noroom) {
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        if (lane_in(alive_m[p], bit_lo, bit_hi))
-                            lout[(size_t)s * subcap + base + lanes_below(alive_m[p])] = idx[p] | (lane_in(zero_m[p], bit_lo, bit_hi) ? 0x80000000u : 0u);
+                        if (__builtin_amdgcn_inverse_ballot_w64(alive_m[p]))
+                            lout[(size_t)s * subcap + base + lanes_below(alive_m[p])] = idx[p] | (__builtin_amdgcn_inverse_ballot_w64(zero_m[p]) ? 0x80000000u : 0u);
                         base += (uint32_t)__popcll(alive_m[p]);
                     }
                 }
@@ -329,7 +321,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const unsigned long long m = alive_m[p] & flip_m[p];
-                if (m != 0 && lane_in(m, bit_lo, bit_hi)) labels[idx[p]] = 1;
+                if (m != 0 && __builtin_amdgcn_inverse_ballot_w64(m)) labels[idx[p]] = 1;
             }
         }
     }
@@ -409,13 +401,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                     }
                     carve &= alive_m[p];
                     if (carve != 0) {
-                        if (lane_in(carve, bit_lo, bit_hi)) labels[idx[p]] = -1;
+                        if (__builtin_amdgcn_inverse_ballot_w64(carve)) labels[idx[p]] = -1;
                         alive_m[p] &= ~carve;
                         zero_m[p] &= ~carve;
                     }
                     keep &= zero_m[p];
                     if (keep != 0) {
-                        if (lane_in(keep, bit_lo, bit_hi)) atomicCAS(&labels[idx[p]], 0, 1);
+                        if (__builtin_amdgcn_inverse_ballot_w64(keep)) atomicCAS(&labels[idx[p]], 0, 1);
                         zero_m[p] &= ~keep;
                     }
                 }
@@ -464,11 +456,12 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
         for (int e = 0; e < 4; ++e)
             if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
     }
-    uint32_t alive = 0;
+    unsigned long long alive[4], kept[4];  // see two_views
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         was[e] = lab[e];
-        if (lab[e] != -1) alive |= 1u << e;  // :67
+        alive[e] = __ballot(lab[e] != -1);  // :67
+        kept[e] = 0;
     }
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
     const float y = g.oy + (float)(int)j * g.vs;
@@ -477,7 +470,7 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
     for (int e = 0; e < 4; ++e) z[e] = g.oz + (float)(int)(k0 + e) * g.vs;  // :73
     bool seen = false;
     for (int base = 0; base < nall; base += 64) {
-        if (__ballot(alive != 0) == 0) break;
+        if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0) break;
         const int vi = base + (int)lane;
         uint32_t v = 8u;  // no such view
         if (vi < nall) {
@@ -488,13 +481,12 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
         unsigned long long need = __ballot(v == 0u);
         if (empty != 0) {  // some view carves every voxel of the unit
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lab[e] = -1;
-            alive = 0;
+            for (int e = 0; e < 4; ++e) alive[e] = 0;
             break;
         }
         seen |= full != 0;
         while (need != 0) {
-            if (__ballot(alive != 0) == 0) break;
+            if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0) break;
             const int a = __builtin_ctzll(need);
             need &= need - 1;
             int b = a;
@@ -505,14 +497,14 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
             }
             const ViewDesc da = views[base + a];
             const ViewDesc db = views[base + b];
-            two_views(da, db, two, x, y, z, lab, alive);
+            two_views(da, db, two, x, y, z, alive, kept);
         }
     }
-    if (seen) {
+    if (seen) {  // :81 by a view that kept the whole unit
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (lab[e] == 0) lab[e] = 1;  // :81 by a view that kept the whole unit
+        for (int e = 0; e < 4; ++e) kept[e] = ~0ull;
     }
+    labels_behind(lab, alive, kept);
     const bool changed = FRESH || lab[0] != was[0] || lab[1] != was[1] || lab[2] != was[2] || lab[3] != was[3];
     if (inside && changed) *reinterpret_cast<int4 *>(p) = make_int4(lab[0], lab[1], lab[2], lab[3]);
 }

@@ -199,7 +199,6 @@ struct sc_engine {
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
     int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
-    int64_t lds_tiles = 0;  // the dense stage stages each unit's window of mask words in LDS (experiment)
     int64_t host_pack = 1;
     struct HostBits {
         char *pin = nullptr, *dev = nullptr;
@@ -1245,11 +1244,11 @@ int flush(sc_engine *e, size_t count = 0) {
                 } else if (e->fresh)
                     hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles, bulk_min_live);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, bulk_min_live);
                 else
                     hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
                                        dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, (int)e->lds_tiles, bulk_min_live);
+                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, bulk_min_live);
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
@@ -1758,8 +1757,7 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_SAFE_KERNELS:
             e->safe_kernels = value ? 1 : 0;
             return SC_OK;
-        case SC_OPT_LDS_TILES:
-            e->lds_tiles = value ? 1 : 0;
+        case SC_OPT_LDS_TILES:  // the experiment was measured and removed (DESIGN_APPENDIX.md 12): accepted, no effect
             return SC_OK;
         case SC_OPT_HOST_PACK:
             if (!e->hp_pending.empty()) return fail(SC_ERR_STATE, "host-packed views are pending: flush first");
