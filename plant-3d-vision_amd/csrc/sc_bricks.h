@@ -52,7 +52,7 @@ __device__ __forceinline__ void labels_behind(int32_t (&lab)[4], const unsigned 
     }
 }
 
-template <bool FRESH>
+template <bool FRESH, bool ALL_SAFE = false>  // ALL_SAFE: every view is certified (project())
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
@@ -96,7 +96,7 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         const bool two = vi + 1 < nviews;      // wave-uniform
         const ViewDesc da = views[vi];
         const ViewDesc db = views[two ? vi + 1 : vi];
-        two_views(da, db, two, x, y, z, alive, kept);
+        two_views<ALL_SAFE>(da, db, two, x, y, z, alive, kept);
     }
     labels_behind(lab, alive, kept);
 
@@ -124,13 +124,22 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
             if (base + total > ap.subcap) {
                 if (lane == 0) ap.ctl->overflow = 1u;
             } else {
+                // In ADDRESS order (round 4): the survivors of lower lanes first, then the lane's own in z order -- lanes
+                // 4 c .. 4 c + 3 hold 16 consecutive voxels of column c.  A chunk of the survivor stage behind is then
+                // a run of neighbouring voxels: its lanes gather from the same mask words, and where most of them are
+                // carved (the noise scene: 33 M) their -1 stores fill whole lines (element-major order -- voxel e of
+                // every lane, then e + 1 -- made every such store a 4-byte piece of a 16-byte stride: 16 bytes of write
+                // traffic per label).
                 uint32_t *dst = ap.list + (size_t)ap.sub * ap.subcap + base;
-                uint32_t off = 0;
+                uint32_t rank = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rank += lanes_below(alive[e]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(alive[e]))
-                        dst[off + lanes_below(alive[e])] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
-                    off += (uint32_t)__popcll(alive[e]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(alive[e])) {
+                        dst[rank] = (uint32_t)(elem + e) | (lab[e] == 0 ? 0x80000000u : 0u);
+                        ++rank;
+                    }
                 }
             }
         }
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
 // (neighbouring bricks, which project onto the same mask lines) stay on one XCD.  Blocks behind
 // the walkers, one per strip, fill the bricks found empty of strips [0, nstore) (the final list
 // stage fills the others, see carve_list_kernel).
-template <bool FRESH>
+template <bool FRESH, bool ALL_SAFE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void carve_brick_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                              const ViewDesc *__restrict__ views,
                                                              int nviews, int32_t init, Append ap,
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-            brick_voxels<FRESH>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+            brick_voxels<FRESH, ALL_SAFE>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
 #ifdef SC_TRACE_DENSE
             ++tr_units;
 #endif

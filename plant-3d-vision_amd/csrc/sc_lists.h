@@ -641,11 +641,15 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
         return;
     }
     uint32_t *dst = uj.list + (size_t)sub * uj.subcap + base;
-    uint32_t off = 0;
+    uint32_t rank = 0;  // in address order (see brick_voxels)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rank += (uint32_t)__popcll(b[e] & below);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if ((alive >> e) & 1u) dst[off + (uint32_t)__popcll(b[e] & below)] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
-        off += (uint32_t)__popcll(b[e]);
+        if ((alive >> e) & 1u) {
+            dst[rank] = (elem + (uint32_t)e) | (lab[e] == 0 ? 0x80000000u : 0u);
+            ++rank;
+        }
     }
 }
 

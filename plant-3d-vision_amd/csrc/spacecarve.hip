@@ -1241,14 +1241,20 @@ int flush(sc_engine *e, size_t count = 0) {
                     else
                         hipLaunchKernelGGL((carve_brick_light_kernel<false>), lgrid, block, 0, e->stream, st, g, vd,
                                            dense_views, init, bys, bzs, e->live, e->fill_list, e->ctl, nwalkers, parity);
-                } else if (e->fresh)
-                    hipLaunchKernelGGL((carve_brick_kernel<true>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, bulk_min_live);
-                else
-                    hipLaunchKernelGGL((carve_brick_kernel<false>), bgrid, block, 0, e->stream, st, g, vd,
-                                       dense_views, init, ap, bys, bzs, e->flags, e->live, e->ctl, nwalkers,
-                                       dense_store_strips, ride, pack_form(e, ride), parity, nverd, verd_max_live, bulk_min_live);
+                } else {
+                    // (every dense view certified by the host: the instance without the general projection path)
+                    bool dense_safe = e->safe_kernels != 0;
+                    for (int q = 0; q < dense_views && dense_safe; ++q) dense_safe = e->pending[(size_t)q].safe != 0;
+#define LAUNCH_BRICK(F, S)                                                                                          \
+    hipLaunchKernelGGL((carve_brick_kernel<F, S>), bgrid, block, 0, e->stream, st, g, vd, dense_views, init, ap, bys, bzs, \
+                       e->flags, e->live, e->ctl, nwalkers, dense_store_strips, ride, pack_form(e, ride), parity, nverd,    \
+                       verd_max_live, bulk_min_live)
+                    if (e->fresh && dense_safe) LAUNCH_BRICK(true, true);
+                    else if (e->fresh) LAUNCH_BRICK(true, false);
+                    else if (dense_safe) LAUNCH_BRICK(false, true);
+                    else LAUNCH_BRICK(false, false);
+#undef LAUNCH_BRICK
+                }
             } else {
 #define LAUNCH_CARVE(F, V)                                                                    \
     hipLaunchKernelGGL((carve_kernel<F, V>), grid, block, 0, e->stream, st, g, vd, dense_views, \
