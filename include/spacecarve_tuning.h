@@ -90,6 +90,9 @@
 #define SC_OPT_SAFE_KERNELS 43    /* 1 (default): a batch whose views are ALL certified by the host (project(): every voxel
                                      of the grid well in front of the camera, everything finite -- any real rig) runs the
                                      survivor stages in instances compiled without the general path; 0: never        */
+#define SC_OPT_DENSE_EXTRA 44     /* 1 (default): a unit (16 columns x 16 voxels) that the dense views thinned out without
+                                     emptying -- 32 .. 128 of its 256 voxels left -- takes one more pair of views inside the
+                                     dense stage (masks that carve voxel by voxel: the noise scene); 0: never */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

@@ -1,0 +1,44 @@
+// hostwait.h -- how the library's host threads wait for the device.
+// hipStreamSynchronize / hipEventSynchronize hand a wait of more than a few microseconds to the runtime's blocking
+// path, and on this stack that path now and then returns tens of milliseconds late: round 4 caught a 3 ms wait for
+// the stream taking 47-54 ms in one process out of seven (tools/dbg/literal_outlier.sh; the device was idle long
+// before), which turned a 0.25 ms batch into "1.8 ms" when averaged over thirty.  The waits here poll the stream or
+// the event instead (a status read, no system call): spinning for the first microseconds, yielding the core after
+// that, and only after 200 ms -- a wait that long is a long kernel, not a race -- falling back to the blocking call.
+#ifndef SC_HOSTWAIT_H
+#define SC_HOSTWAIT_H
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <thread>
+
+namespace schost {
+
+template <typename Query, typename Block>
+inline hipError_t poll_then_block(Query query, Block block) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = query();
+        if (q != hipErrorNotReady) return q;  // done, or a real error
+        if (spins < 256) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        } else {
+            std::this_thread::yield();
+            if ((spins & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return block();
+        }
+    }
+}
+
+inline hipError_t wait_stream(hipStream_t s) {
+    return poll_then_block([s] { return hipStreamQuery(s); }, [s] { return hipStreamSynchronize(s); });
+}
+inline hipError_t wait_event(hipEvent_t ev) {
+    return poll_then_block([ev] { return hipEventQuery(ev); }, [ev] { return hipEventSynchronize(ev); });
+}
+
+}  // namespace schost
+
+#endif

@@ -9,6 +9,7 @@
 // here each dot product is evaluated left to right without FMA.
 #include <hip/hip_runtime.h>
 
+
 #include <cmath>
 #include <cstdint>
 #include <cstring>

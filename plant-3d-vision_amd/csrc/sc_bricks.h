@@ -56,7 +56,8 @@ template <bool FRESH, bool ALL_SAFE = false>  // ALL_SAFE: every view is certifi
 __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const GridDesc &g,
                                              const ViewDesc *__restrict__ views, int nviews,
                                              int32_t init, Append ap, uint32_t il, uint32_t j,
-                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0) {
+                                             uint32_t k0, uint32_t lb, uint32_t lane, uint32_t unit = 0,
+                                             int nextra = 0) {  // views behind the `nviews` whose masks are packed too
     // bricks at the far y / z faces of the grid may stick out of it: lanes beyond ny or nz own
     // nothing (they still take part in the wave-wide ballots), a group at the end of a column
     // may be short (the pitch is a multiple of 64: groups are 16-byte aligned)
@@ -97,6 +98,19 @@ __device__ __forceinline__ void brick_voxels(int32_t *__restrict__ labels, const
         const ViewDesc da = views[vi];
         const ViewDesc db = views[two ? vi + 1 : vi];
         two_views<ALL_SAFE>(da, db, two, x, y, z, alive, kept);
+    }
+    // One more pair of views for a unit the dense views thinned out without emptying (32 .. 128 of its 256 voxels left):
+    // masks that carve voxel by voxel (the noise scene: a quarter left after two views, a sixteenth after four), where a
+    // survivor costs the lists more than a whole unit costs here.  A plant's units hold fewer, a solid's more.  The
+    // survivor stage behind applies those two views again -- nothing changes the second time (a carve is final, a kept
+    // 0 is already 1).
+    if (nextra >= 2 && ap.list != nullptr) {  // wave-uniform
+        const uint32_t left = (uint32_t)(__popcll(alive[0]) + __popcll(alive[1]) + __popcll(alive[2]) + __popcll(alive[3]));
+        if (left >= 32u && left <= 128u) {
+            const ViewDesc da = views[nviews];
+            const ViewDesc db = views[nviews + 1];
+            two_views<ALL_SAFE>(da, db, true, x, y, z, alive, kept);
+        }
     }
     labels_behind(lab, alive, kept);
 
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
                                                              ListCtl *ctl, uint32_t nwalkers,
                                                              uint32_t nstore, PackJob ride, int pack_rows,
                                                              uint32_t parity, int nverd_arg, uint32_t verd_max_live,
-                                                             uint32_t bulk_min_live) {
+                                                             uint32_t bulk_min_live, int nextra) {
     // Behind the walkers come the riders, and the store blocks LAST: blocks start in the order of their numbers, and what
     // the riders pack is waited for by the next kernel, while a store only has to be done by the end of this one
     // (with the store blocks in front the riders started when the stores were through, and a sixteenth of the fill
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
                 continue;
             }
-            brick_voxels<FRESH, ALL_SAFE>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u);
+            brick_voxels<FRESH, ALL_SAFE>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u, nextra);
 #ifdef SC_TRACE_DENSE
             ++tr_units;
 #endif

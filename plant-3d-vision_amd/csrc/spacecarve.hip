@@ -36,6 +36,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "hostwait.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -198,6 +200,7 @@ struct sc_engine {
 
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
+    int64_t dense_extra = 1;   // a unit the dense views thinned out to 32 .. 128 voxels takes one more pair of views there
     int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
     int64_t host_pack = 1;
     struct HostBits {
@@ -401,7 +404,7 @@ void arena_reset(sc_engine *e) {
 
 int ensure_slots(sc_engine *e, size_t bytes) {
     if (bytes <= e->slot_bytes) return SC_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     for (int s = 0; s < kSlots; ++s) {
         if (e->pin[s]) (void)hipHostFree(e->pin[s]);
         if (e->raw[s]) (void)hipFree(e->raw[s]);
@@ -752,7 +755,7 @@ constexpr int kMinFusedViews = 6;  // below this a fused launch stays dense
 int ensure_lists(sc_engine *e) {
     if (e->lists && e->list_cap_built == e->list_cap) return SC_OK;
     if (e->lists) {  // the capacity knob moved (tests of the overflow paths): rebuilt behind the stream
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(schost::wait_stream(e->stream));
         (void)hipFree(e->lists);
         e->lists = nullptr;
     }
@@ -862,7 +865,7 @@ int materialize_deferred(sc_engine *e) {
 int hostbits_reserve(sc_engine *e, size_t bytes, char **out) {
     auto &a = e->hb[e->hb_cur];
     if (a.used == 0 && a.armed) {
-        HIP_TRY(hipEventSynchronize(a.ev));
+        HIP_TRY(schost::wait_event(a.ev));
         a.armed = false;
     }
     if (a.used + bytes > a.cap) {
@@ -878,7 +881,7 @@ int hostbits_reserve(sc_engine *e, size_t bytes, char **out) {
         if (a.pin) {
             // the old blocks may be the source / target of a copy still on the stream (a.used > 0 means: not of this
             // batch's, but an earlier flush's): wait before they go
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(schost::wait_stream(e->stream));
             (void)hipHostFree(a.pin);
             (void)hipFree(a.dev);
         }
@@ -1091,7 +1094,7 @@ int flush(sc_engine *e, size_t count = 0) {
             order_views(e->pending);
         // descriptor ring: slots are reused only after a wrap, which waits for the stream
         if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(schost::wait_stream(e->stream));
             e->views_head = 0;
         }
         if (nv > e->views_cap) {
@@ -1099,7 +1102,7 @@ int flush(sc_engine *e, size_t count = 0) {
             if (e->views_pin) (void)hipHostFree(e->views_pin);
             e->views_dev = e->views_pin = nullptr;
             e->views_cap = 0;
-            size_t cap = std::max<size_t>(nv * 4, 1024);
+            size_t cap = std::max<size_t>(nv * 8, 4096);  // (a wrap every 56 batches of 72 views; 1024 until round 4)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->views_dev), cap * sizeof(ViewDesc)));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->views_pin), cap * sizeof(ViewDesc),
                                   hipHostMallocDefault));
@@ -1243,12 +1246,14 @@ int flush(sc_engine *e, size_t count = 0) {
                                            dense_views, init, bys, bzs, e->live, e->fill_list, e->ctl, nwalkers, parity);
                 } else {
                     // (every dense view certified by the host: the instance without the general projection path)
+                    // (a thinned-out unit may take one more pair of the views packed ahead: brick_voxels)
+                    const int nextra = e->dense_extra ? std::max(0, std::min(2, packed_ahead - dense_views)) : 0;
                     bool dense_safe = e->safe_kernels != 0;
-                    for (int q = 0; q < dense_views && dense_safe; ++q) dense_safe = e->pending[(size_t)q].safe != 0;
+                    for (int q = 0; q < dense_views + nextra && dense_safe; ++q) dense_safe = e->pending[(size_t)q].safe != 0;
 #define LAUNCH_BRICK(F, S)                                                                                          \
     hipLaunchKernelGGL((carve_brick_kernel<F, S>), bgrid, block, 0, e->stream, st, g, vd, dense_views, init, ap, bys, bzs, \
                        e->flags, e->live, e->ctl, nwalkers, dense_store_strips, ride, pack_form(e, ride), parity, nverd,    \
-                       verd_max_live, bulk_min_live)
+                       verd_max_live, bulk_min_live, nextra)
                     if (e->fresh && dense_safe) LAUNCH_BRICK(true, true);
                     else if (e->fresh) LAUNCH_BRICK(true, false);
                     else if (dense_safe) LAUNCH_BRICK(false, true);
@@ -1377,7 +1382,7 @@ int flush(sc_engine *e, size_t count = 0) {
             const uint32_t anb = (uint32_t)((uint64_t)e->planes * abys * abzs);
             const size_t need = (size_t)anb * nv;
             if (need > e->verd_cap) {
-                HIP_TRY(hipStreamSynchronize(e->stream));
+                HIP_TRY(schost::wait_stream(e->stream));
                 if (e->verd) (void)hipFree(e->verd);
                 e->verd = nullptr;
                 e->verd_cap = 0;
@@ -1385,7 +1390,7 @@ int flush(sc_engine *e, size_t count = 0) {
                 e->verd_cap = need;
             }
             if (any_f32 && need > e->verdf_cap) {  // the flat values of float32 views
-                HIP_TRY(hipStreamSynchronize(e->stream));
+                HIP_TRY(schost::wait_stream(e->stream));
                 if (e->verdf) (void)hipFree(e->verdf);
                 e->verdf = nullptr;
                 e->verdf_cap = 0;
@@ -1577,7 +1582,7 @@ int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_
 void sc_destroy(sc_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)schost::wait_stream(e->stream);
     for (int k = 0; k < kNumKernels; ++k)
         for (auto &tl : e->timed[k]) {
             (void)hipEventDestroy(tl.start);
@@ -1760,6 +1765,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
             e->bulk_floor = value;
             return SC_OK;
+        case SC_OPT_DENSE_EXTRA:
+            e->dense_extra = value ? 1 : 0;
+            return SC_OK;
         case SC_OPT_SAFE_KERNELS:
             e->safe_kernels = value ? 1 : 0;
             return SC_OK;
@@ -1797,7 +1805,7 @@ int sc_set_lut(sc_engine *e, const float *lut256) {
     if (rc) return rc;
     rc = flush(e);  // views already enqueued keep the old table
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     if (!e->lut_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->lut_dev), 256 * sizeof(float)));
     HIP_TRY(hipMemcpy(e->lut_dev, lut256, 256 * sizeof(float), hipMemcpyHostToDevice));
     return SC_OK;
@@ -1809,7 +1817,7 @@ int sc_set_stream(sc_engine *e, void *hip_stream) {
     if (rc) return rc;
     rc = flush(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
     return SC_OK;
 }
@@ -1874,7 +1882,7 @@ int sc_process_view(sc_engine *e, const float K[4], const float R[9], const floa
     int s = e->next_slot;
     e->next_slot = (s + 1) % kSlots;
     if (e->slot_armed[s]) {
-        HIP_TRY(hipEventSynchronize(e->slot_ev[s]));
+        HIP_TRY(schost::wait_event(e->slot_ev[s]));
         e->slot_armed[s] = false;
     }
     // consume the caller's buffer now (tight rows in the pinned slot)
@@ -2053,7 +2061,7 @@ int sc_process_views_device(sc_engine *e, int V, const float *K, const float *R,
 // The first nv pending descriptors of an engine into its device ring, by a copy on its stream.
 static int stage_descriptors(sc_engine *e, size_t nv, const ViewDesc **out) {
     if (nv > e->views_cap || e->views_head + nv > e->views_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(schost::wait_stream(e->stream));
         e->views_head = 0;
     }
     if (nv > e->views_cap) {
@@ -2152,7 +2160,7 @@ int sc_average_labels(sc_engine *const *engines, int L, int V, const float *K, c
         rc = stage_descriptors(e, (size_t)V, &vd[l < 64 ? l : 0]);
         if (rc) break;
         if (need > e->verd_cap) {
-            hipError_t he = hipStreamSynchronize(main);
+            hipError_t he = schost::wait_stream(main);
             if (e->verd) (void)hipFree(e->verd);
             e->verd = nullptr;
             e->verd_cap = 0;
@@ -2235,7 +2243,7 @@ int sc_flush(sc_engine *e) {
 int sc_synchronize(sc_engine *e) {
     int rc = sc_flush(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     return SC_OK;
 }
 
@@ -2249,7 +2257,7 @@ int sc_get_values(sc_engine *e, void *out) {
     rc = dense_state(e, &src);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, src, (size_t)e->n * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     return SC_OK;
 }
 
@@ -2276,7 +2284,7 @@ int sc_get_values_i8(sc_engine *e, int8_t *out) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, e->narrow, (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     return SC_OK;
 }
 
@@ -2431,7 +2439,7 @@ int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t stagi
     {
         schost::TaskGroup tg;
         for (int64_t k = 0; k < queued && err == hipSuccess; ++k) {
-            err = hipEventSynchronize(evs[(size_t)k]);
+            err = schost::wait_event(evs[(size_t)k]);
             if (err != hipSuccess) break;
             const int64_t w0 = k * piece, w1 = std::min(words, (k + 1) * piece);
             // two halves per piece: a finer grain for the pool at the transfer's end
@@ -2441,7 +2449,7 @@ int sc_get_values_wire2(sc_engine *e, int32_t *out, void *staging, int64_t stagi
         }
         tg.wait();
     }
-    (void)hipStreamSynchronize(e->stream);  // (every copy has landed or failed before the events go back)
+    (void)schost::wait_stream(e->stream);  // (every copy has landed or failed before the events go back)
     for (int64_t k = 0; k < queued; ++k) e->event_pool.push_back(evs[(size_t)k]);
     if (err != hipSuccess) return fail(SC_ERR_DEVICE, "label read-back failed: %s", hipGetErrorString(err));
     return SC_OK;
@@ -2455,7 +2463,7 @@ int sc_get_values_packed(sc_engine *e, int bits, void *out) {
     if (rc) return rc;
     const int64_t words = (e->n + (32 / bits) - 1) / (32 / bits);
     HIP_TRY(hipMemcpyAsync(out, ptr, (size_t)words * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     return SC_OK;
 }
 
@@ -2495,7 +2503,7 @@ int sc_kernel_stats(sc_engine *e, int kernel_id, int64_t *launches, double *tota
     if (kernel_id < 0 || kernel_id >= kNumKernels) return fail(SC_ERR_INVALID, "bad kernel id");
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     double sum = 0.0;
     for (auto &tl : e->timed[kernel_id]) {
         float ms = 0.0f;
@@ -2511,7 +2519,7 @@ int sc_reset_kernel_stats(sc_engine *e) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     for (int k = 0; k < kNumKernels; ++k) {
         for (auto &tl : e->timed[k]) {
             e->event_pool.push_back(tl.start);
@@ -2547,7 +2555,7 @@ int sc_span_end(sc_engine *e, double *ms) {
     rc = get_event(e, &stop);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(stop, e->stream));
-    HIP_TRY(hipEventSynchronize(stop));
+    HIP_TRY(schost::wait_event(stop));
     float f = 0.0f;
     HIP_TRY(hipEventElapsedTime(&f, e->span_start, stop));
     *ms = (double)f;
@@ -2579,7 +2587,7 @@ int sc_fused_counts(sc_engine *e, int64_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     if (!e->ctl) return SC_OK;  // no fused carve launched yet
     std::vector<ListCtl> host(1);
     HIP_TRY(hipMemcpy(host.data(), e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
@@ -2614,7 +2622,7 @@ int sc_selftest_division(sc_engine *e, int64_t count, uint32_t seed, int mode,
                        seed, mode, out);
     hipError_t he = hipGetLastError();
     if (he == hipSuccess) he = hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = schost::wait_stream(e->stream);
     (void)hipFree(out);
     if (he != hipSuccess) return fail(SC_ERR_DEVICE, "division self-test failed: %s", hipGetErrorString(he));
     *mismatches = host[0];
@@ -2688,7 +2696,7 @@ int sc_selftest_project(sc_engine *e, int64_t count, uint32_t seed, int nposes, 
                            seed, (uint32_t)nposes, dp, dijk, didx, dw, dd);
         he = hipGetLastError();
     }
-    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = schost::wait_stream(e->stream);
     if (he == hipSuccess && words_out) he = hipMemcpy(words_out, dw, (size_t)count * 4, hipMemcpyDeviceToHost);
     if (he == hipSuccess && digests_out) he = hipMemcpy(digests_out, dd, ndig * 8, hipMemcpyDeviceToHost);
     (void)hipFree(dp); (void)hipFree(dijk); (void)hipFree(didx); (void)hipFree(dw); (void)hipFree(dd);
@@ -2720,7 +2728,7 @@ int sc_dev_free(sc_engine *e, void *ptr) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     HIP_TRY(hipFree(ptr));
     return SC_OK;
 }
@@ -2737,7 +2745,7 @@ int sc_dev_download(sc_engine *e, void *dst_host, const void *src_dev, int64_t b
     if (!e || !dst_host || !src_dev || bytes < 0) return fail(SC_ERR_INVALID, "bad argument");
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(schost::wait_stream(e->stream));
     HIP_TRY(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
     return SC_OK;
 }
@@ -2896,7 +2904,7 @@ int sc_group_get_values(sc_group *g, void *out) {
     for (auto *e : g->eng) {
         int rc = use_device(e);
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(schost::wait_stream(e->stream));
     }
     return SC_OK;
 }

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

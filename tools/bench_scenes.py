@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--tag", default="")
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event breakdown (a separate pass)")
+    ap.add_argument("--trace-steps", action="store_true", help="host time of every call of the timed steps; reports the slowest step")
     a = ap.parse_args()
     opts = []
     for kv in a.opt:
@@ -60,12 +61,23 @@ def main():
         eng.synchronize()
         eng.span_begin()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
+        worst = (0.0, -1, "")
+        for i in range(a.steps):
+            if a.trace_steps:  # where does a slow step spend its host time?
+                t1 = time.perf_counter(); eng.clear()
+                t2 = time.perf_counter(); eng.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+                t3 = time.perf_counter(); eng.flush()
+                t4 = time.perf_counter()
+                if t4 - t1 > worst[0]:
+                    worst = (t4 - t1, i, f"clear {1e3 * (t2 - t1):.3f} enqueue {1e3 * (t3 - t2):.3f} flush {1e3 * (t4 - t3):.3f} ms")
+            else:
+                step()
         ms_dev = eng.span_end() / a.steps
         eng.synchronize()
         ms_host = (time.perf_counter() - t0) / a.steps * 1e3
         ent = {"ms": round(ms_dev, 4), "ms_host": round(ms_host, 4)}
+        if a.trace_steps:
+            ent["slowest_step"] = {"step": worst[1], "host_ms": round(1e3 * worst[0], 3), "parts": worst[2]}
         try:
             ent["counts"] = eng.fused_counts_ex()
         except Exception as exc:  # an older build of the library
