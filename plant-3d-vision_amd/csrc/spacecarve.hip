@@ -1052,7 +1052,11 @@ int flush(sc_engine *e, size_t count = 0) {
             for (size_t q = 0; q < nv; ++q) pj.order[q] = (uint16_t)perm[q];
             const FusedPlan fp = fused_plan(e, nv, true);
             int ahead = (int)nv;
-            if (e->pack_ride && fp.brick && fp.compact && fp.defer_stores)  // (the dense stage may carry store blocks AND riders)
+            // (not when the dense kernel fills a share of the strips itself: with riders the flags kernel leaves FULL
+            // candidates open until the confirm kernel -- behind the dense kernel -- and only the list stages' store
+            // blocks come after that.  Round 4 tried both together for the fill's sake: 4 of 2 600 fuzz cases, all with
+            // SC_OPT_DEFER_SHARE 5, kept bricks that nobody filled.)
+            if (e->pack_ride && fp.brick && fp.compact && fp.defer_stores && fp.dense_store_strips == 0)
                 ahead = std::min<int>((int)nv, std::max(fp.flag_views, fp.s1));
             pj.slot0 = 0;
             pj.nslots = ahead;
