@@ -93,6 +93,10 @@
 #define SC_OPT_DENSE_EXTRA 44     /* 1 (default): a unit (16 columns x 16 voxels) that the dense views thinned out without
                                      emptying -- 32 .. 128 of its 256 voxels left -- takes one more pair of views inside the
                                      dense stage (masks that carve voxel by voxel: the noise scene); 0: never */
+#define SC_OPT_SPEC_SHARE 45      /* sixteenths of the strips (3) whose labels are set to -1 AHEAD of the brick verdicts, by
+                                     persistent fill blocks in front of the flags kernel's own (fresh volumes only: every
+                                     brick that is not EMPTY is written again by a later kernel of the batch); 0: none  */
+#define SC_OPT_SPEC_BLOCKS 46     /* ... that many blocks of 512 threads (64)                                             */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

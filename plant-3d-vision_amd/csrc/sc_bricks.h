@@ -179,12 +179,12 @@ __device__ __forceinline__ uint32_t strip_flag(const uint8_t *__restrict__ flags
     return (lane < bricks_z) ? flags[strip * bricks_z + lane] : 0u;  // (bricks_z <= 64: the brick form is for nz <= 4096)
 }
 __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels, const GridDesc &g, uint32_t f, uint32_t strip,
-                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill) {
+                                                    uint32_t bricks_y, uint32_t bricks_z, Fill fill, bool prefilled = false) {  // prefilled: its labels are -1 already (SpecFill)
     typedef int v4i __attribute__((ext_vector_type(4)));
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t il = strip / bricks_y, by = strip - il * bricks_y;
     const uint32_t j0 = by * kBrickY + wave * 4, j = j0 + (lane >> 4);
-    const unsigned long long culled = __ballot(f == 1u), full = __ballot(f == 2u);
+    const unsigned long long culled = prefilled ? 0ull : __ballot(f == 1u), full = __ballot(f == 2u);
     // UNTOUCHED bricks (6) keep their labels: only a fresh volume, whose labels exist as `init` in name
     // only, has something to write there
     const unsigned long long untouched = fill.fresh ? __ballot(f == 6u) : 0ull;

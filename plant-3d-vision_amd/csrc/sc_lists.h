@@ -68,24 +68,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     // kernel found empty by HBM writes, so the two run side by side instead of one after the
     // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
     const bool split = cs.flags != nullptr;
-    const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : cs.nstrips - cs.first) : 0u;
+    const uint32_t nown = cs.nstrips - cs.first, nvirt = nown + cs.spec;  // the share proper, and the prefilled strips behind it
+    const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : nvirt) : 0u;
     const uint32_t nbid = gdim - nstore;
     if (split && bx >= nbid) {
         // one short block per strip, or (fill_blocks > 0) that many blocks walking the strips: a
         // wavefront's stores do not hold it up, so few of them keep the write path busy and the
         // wavefront slots go to the list blocks
         constexpr uint32_t kAhead = 4;  // strips whose flags are fetched together
-        for (uint32_t strip = cs.first + (bx - nbid); strip < cs.nstrips; strip += nstore * kAhead) {
+        for (uint32_t t = bx - nbid; t < nvirt; t += nstore * kAhead) {
             uint32_t f[kAhead];
 #pragma unroll
             for (uint32_t u = 0; u < kAhead; ++u) {
-                const uint32_t st = strip + u * nstore;
-                f[u] = st < cs.nstrips ? strip_flag(cs.flags, st, cs.bricks_z) : 0u;
+                const uint32_t tt = t + u * nstore;
+                f[u] = tt < nvirt ? strip_flag(cs.flags, tt < nown ? cs.first + tt : tt - nown, cs.bricks_z) : 0u;
             }
 #pragma unroll
             for (uint32_t u = 0; u < kAhead; ++u) {
-                const uint32_t st = strip + u * nstore;
-                if (st < cs.nstrips) store_culled_bricks(labels, g, f[u], st, cs.bricks_y, cs.bricks_z, Fill{cs.kept, cs.fresh, cs.init});
+                const uint32_t tt = t + u * nstore;
+                if (tt < nvirt)
+                    store_culled_bricks(labels, g, f[u], tt < nown ? cs.first + tt : tt - nown, cs.bricks_y, cs.bricks_z,
+                                        Fill{cs.kept, cs.fresh, cs.init}, tt >= nown);
             }
         }
         return;

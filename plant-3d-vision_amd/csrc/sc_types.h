@@ -96,4 +96,6 @@ struct CullStores {
     int32_t kept, fresh;   // see Fill
     uint32_t fill_blocks;  // 0: one store block per strip; n: n persistent store blocks
     int32_t init;          // see Fill
+    uint32_t spec;         // strips [0, spec) were set to -1 ahead of the verdicts (SpecFill): this stage's store blocks
+                           // also walk them, for their FULL / UNTOUCHED bricks only
 };

@@ -231,19 +231,39 @@ constexpr int kFlagWaves = 8;
 // device array the later kernels read -- no separate host-to-device copy on the stream.
 struct FlagViews { ViewDesc v[kFlagWaves]; };
 struct DescCopy { const uint32_t *src; uint32_t *dst; uint32_t words; };
+// The fill that waits for nobody (round 4).  Every label of the batch is written exactly once, three quarters of
+// them the -1 of bricks some view finds empty -- and that fill, 537 MB at 512^3, is what bounds the final survivor
+// stage, while HBM idles under the kernels in front (packing, these verdicts).  In a FRESH volume (labels exist as
+// `init` in name only since the last clear) a brick's labels are whatever its verdict makes the later kernels
+// write -- the dense stage writes every voxel of a live brick, the store blocks `kept` / `init` over FULL /
+// UNTOUCHED ones, late_unit every voxel of a late one -- so the first `bytes` of the volume can be set to -1 HERE,
+// before any verdict exists: the EMPTY bricks among them are then done, and the others are overwritten by kernels
+// that come later on the stream.  `nblocks` persistent blocks in front of the verdict blocks write them in address
+// order, 8 KB per block and turn (the order a plain fill kernel uses: 6.4-7.0 TB/s, tools/probes/fill_probe.hip).
+struct SpecFill { int32_t *labels; uint64_t bytes; uint32_t nblocks; };
 
 __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
     FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch,
-    uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list) {
+    uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list, SpecFill sf) {
     __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves], s_seen[kFlagWaves];
-    if (blockIdx.x == 0) {
+    if (blockIdx.x < sf.nblocks) {  // block-uniform
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i minus = {-1, -1, -1, -1};
+        char *base = reinterpret_cast<char *>(sf.labels);
+        for (uint64_t off = ((uint64_t)blockIdx.x * (64 * kFlagWaves) + threadIdx.x) * 16u; off < sf.bytes;
+             off += (uint64_t)sf.nblocks * (64 * kFlagWaves * 16))
+            __builtin_nontemporal_store(minus, reinterpret_cast<v4i *>(base + off));
+        return;
+    }
+    const uint32_t bid = blockIdx.x - sf.nblocks;
+    if (bid == 0) {
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
         if (threadIdx.x == 0) ctl->nlive[parity ^ 1u] = ctl->nfill[parity ^ 1u] = 0u;  // the next launch's counters
     }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t lb = blockIdx.x * 64u + lane;
+    const uint32_t lb = bid * 64u + lane;
     // DEAD bricks: an earlier launch found the brick empty, every voxel is -1 and stays so whatever
     // is carved later (backprojection.c:67) -- until the next clear.  They get no verdict, no fill and
     // no place on the live list (flag 4): the reference's cadence of one launch per view touches a few

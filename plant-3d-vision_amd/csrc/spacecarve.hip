@@ -200,6 +200,8 @@ struct sc_engine {
 
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
+    int64_t spec_share = 3;    // sixteenths of the strips set to -1 by fill blocks in front of the flags kernel (fresh volumes)
+    int64_t spec_blocks = 64;  // ... that many persistent blocks of 512 threads (64: a fill that does not saturate HBM leaves the verdicts their memory round trips; 128 measured 2 % slower per batch, 48 too)
     int64_t dense_extra = 1;   // a unit the dense views thinned out to 32 .. 128 voxels takes one more pair of views there
     int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
     int64_t host_pack = 1;
@@ -1141,6 +1143,12 @@ int flush(sc_engine *e, size_t count = 0) {
         int dense_views = (int)nv;
         const uint32_t bys = fp.bys, bzs = fp.bzs, nbricks = fp.nbricks, nstrips = fp.nstrips;
         const uint32_t dense_store_strips = fp.dense_store_strips;
+        // strips set to -1 ahead of the verdicts, by fill blocks in front of the flags kernel's own (SpecFill): a fresh
+        // volume whose fill is all the list stages' (so that everything behind the flags kernel that writes labels
+        // comes later on the stream)
+        uint32_t spec_strips = 0;
+        if (fp.brick && fp.compact && fp.defer_stores && dense_store_strips == 0 && e->fresh && e->spec_share > 0)
+            spec_strips = (uint32_t)((uint64_t)fp.nstrips * (uint64_t)e->spec_share / 16u);
         const bool desc_by_flags = brick && flag_views <= kFlagWaves;
         if (!desc_by_flags) {
             rc = upload_desc();
@@ -1229,11 +1237,17 @@ int flush(sc_engine *e, size_t count = 0) {
                                   (uint32_t)(nv * sizeof(ViewDesc) / 4)};
                     desc_uploaded = true;
                 }
-                hipLaunchKernelGGL(brick_flags_kernel, dim3((nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
+                SpecFill sf{nullptr, 0u, 0u};
+                if (spec_strips > 0) {
+                    // strip s starts at column (s / bys) * ny + (s % bys) * 16; the columns are contiguous rows of nzp labels
+                    const uint64_t cols = (uint64_t)(spec_strips / bys) * (uint64_t)e->ny + (uint64_t)(spec_strips % bys) * kBrickY;
+                    sf = SpecFill{st, cols * (uint64_t)e->nzp * 4u, (uint32_t)e->spec_blocks};
+                }
+                hipLaunchKernelGGL(brick_flags_kernel, dim3(sf.nblocks + (nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
                                    flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
                                    desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv, e->dead,
-                                   dead_stale, parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list);
+                                   dead_stale, parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list, sf);
                 e->last_parity = parity;
                 rc = ltf.end();
                 if (rc) return rc;
@@ -1287,7 +1301,7 @@ int flush(sc_engine *e, size_t count = 0) {
             if (rc) return rc;
             int vg = (int)e->view_group;
             // open FULL candidates exist only when packing rode beside the dense stage
-            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0}, cs = none;
+            CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0, 0u}, cs = none;
             if (ride_blocks) {
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
                 // (one block per 64 bricks up to 4096 blocks; without candidates a block leaves after one scalar load)
@@ -1324,15 +1338,17 @@ int flush(sc_engine *e, size_t count = 0) {
             dim3 grid1(list_blocks);
             if (defer_stores) {
                 // the first list stage may take a share of the fill as well (it waits on memory)
-                uint32_t mid = dense_store_strips;
+                const uint32_t first = std::max(dense_store_strips, spec_strips);  // (one of the two is 0)
+                uint32_t mid = first;
                 if ((size_t)s1 < nv && e->stage1_store_share > 0) {
-                    mid += (uint32_t)((uint64_t)(nstrips - dense_store_strips) * (uint64_t)e->stage1_store_share / 16u);
-                    const uint32_t n1 = mid - dense_store_strips, f1 = std::min<uint32_t>((uint32_t)e->fill_blocks, n1);
-                    cs1 = CullStores{e->flags, bys, bzs, mid, dense_store_strips, init == 0 ? 1 : init, e->fresh ? 1 : 0, f1, init};
+                    mid += (uint32_t)((uint64_t)(nstrips - first) * (uint64_t)e->stage1_store_share / 16u);
+                    const uint32_t n1 = mid - first, f1 = std::min<uint32_t>((uint32_t)e->fill_blocks, n1);
+                    cs1 = CullStores{e->flags, bys, bzs, mid, first, init == 0 ? 1 : init, e->fresh ? 1 : 0, f1, init, 0u};
                     grid1 = dim3((uint32_t)e->stage1_list_blocks + (f1 ? f1 : n1));
                 }
-                const uint32_t nf = nstrips - mid, ff = std::min<uint32_t>((uint32_t)e->fill_blocks, nf);
-                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff, init};
+                // (the final stage also walks the strips filled ahead, for their FULL / UNTOUCHED bricks)
+                const uint32_t nf = nstrips - mid + spec_strips, ff = std::min<uint32_t>((uint32_t)e->fill_blocks, nf);
+                cs = CullStores{e->flags, bys, bzs, nstrips, mid, init == 0 ? 1 : init, e->fresh ? 1 : 0, ff, init, spec_strips};
                 fgrid = dim3((uint32_t)e->defer_stores + (ff ? ff : nf));
             }
             // every view of the batch certified by the host (certify_view: any real rig): the instances without the general path
@@ -1768,6 +1784,14 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_BULK_FLOOR:
             if (value < 0 || value > 0x7fffffffLL) return fail(SC_ERR_INVALID, "bulk_floor must be in [0, 2^31)");
             e->bulk_floor = value;
+            return SC_OK;
+        case SC_OPT_SPEC_SHARE:
+            if (value < 0 || value > 16) return fail(SC_ERR_INVALID, "spec_share must be in [0, 16]");
+            e->spec_share = value;
+            return SC_OK;
+        case SC_OPT_SPEC_BLOCKS:
+            if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "spec_blocks must be in [1, 4096]");
+            e->spec_blocks = value;
             return SC_OK;
         case SC_OPT_DENSE_EXTRA:
             e->dense_extra = value ? 1 : 0;

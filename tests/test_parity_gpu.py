@@ -294,6 +294,9 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_UNIT_CULL": 2, "SC_OPT_PACK_RIDE": 0, "SC_OPT_BRICK_WALKERS": 8},  # by 16 views, few walkers
     {"SC_OPT_SAFE_KERNELS": 0},                                           # the list kernels with the general path compiled in
     {"SC_OPT_DENSE_EXTRA": 0},                                            # no third pair of dense views for thinned-out units
+    {"SC_OPT_SPEC_SHARE": 0},                                             # no fill ahead of the verdicts
+    {"SC_OPT_SPEC_SHARE": 16, "SC_OPT_SPEC_BLOCKS": 7},                   # ... all of it, by an odd number of blocks
+    {"SC_OPT_SPEC_SHARE": 9, "SC_OPT_FILL_BLOCKS": 0},
     {"SC_OPT_DEFER_SHARE": 5},                                            # the dense kernel fills most strips itself (and nobody rides)
     {"SC_OPT_DEFER_SHARE": 2, "SC_OPT_FILL_BLOCKS": 0},
     {"SC_OPT_FILL_BLOCKS": 64, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_STAGE1_STORE_SHARE": 3},  # few store blocks, odd shares
