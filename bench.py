@@ -54,7 +54,7 @@ VALU_PEAK_TLANEOPS = 78.6
 # (brick, view) pair is projected (random grey masks), re-measured in round 4 on the current kernels
 # (profiles/r04_avg_sq_counters.json, tools/r04_avg_counters.sh; round 2 read 52.7 before the certified-view path
 # shortened the projection; SURVEY 8d estimated ~50)
-LANE_OPS_PER_VOXEL_VIEW = {"u8": 47.7, "f32": 46.0}
+LANE_OPS_PER_VOXEL_VIEW = {"u8": 41.7, "f32": 40.0}  # re-measured after the one-correction division (47.7 / 46.0 before it)
 AVG_COUNTERS = "profiles/r04_avg_sq_counters.json"
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),

@@ -11,12 +11,19 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <thread>
 
 namespace schost {
 
+inline int wait_mode() {  // EXPERIMENT (SC_WAIT_MODE): 0 block, 1 spin then yield, 2 spin then sleep 20 us a turn
+    static const int mode = [] { const char *e = std::getenv("SC_WAIT_MODE"); return e ? std::atoi(e) : 1; }();
+    return mode;
+}
 template <typename Query, typename Block>
 inline hipError_t poll_then_block(Query query, Block block) {
+    const int mode = wait_mode();
+    if (mode == 0) return block();
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = query();
@@ -26,7 +33,8 @@ inline hipError_t poll_then_block(Query query, Block block) {
             __builtin_ia32_pause();
 #endif
         } else {
-            std::this_thread::yield();
+            if (mode == 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            else std::this_thread::yield();
             if ((spins & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return block();
         }
     }
