@@ -27,13 +27,7 @@ static_assert(sizeof(ViewDesc) == 128, "ViewDesc layout");
 struct FastDiv {
     uint32_t m, s;
 };
-__host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (__umulhi(n, f.m) + n) >> f.s;
-#else
-    return (uint32_t)((((uint64_t)n * f.m) >> 32) + n) >> f.s;
-#endif
-}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
 
 struct GridDesc {
     float ox, oy, oz, vs;
