@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
                 int sh[2][2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const ViewDesc d = ui.views[vbase + (q ? b : a)];
+                    const ViewDesc d = scalar_desc(ui.views, vbase + (q ? b : a));  // (`ui.views`: a pointer inside a struct)
                     asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
                     const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
 #pragma unroll
@@ -498,8 +498,8 @@ __device__ __forceinline__ void late_unit(int32_t *__restrict__ labels, const Gr
                 b = __builtin_ctzll(need);
                 need &= need - 1;
             }
-            const ViewDesc da = views[base + a];
-            const ViewDesc db = views[base + b];
+            const ViewDesc da = scalar_desc(views, (uint32_t)(base + a));
+            const ViewDesc db = scalar_desc(views, (uint32_t)(base + b));
             two_views(da, db, two, x, y, z, alive, kept);
         }
     }

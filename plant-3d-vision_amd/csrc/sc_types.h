@@ -21,6 +21,18 @@ struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave
     uint64_t reserved;
 };
 static_assert(sizeof(ViewDesc) == 128, "ViewDesc layout");
+// Descriptor `i` (wave-uniform) by SCALAR loads, whatever the compiler knows about the pointer: through the constant
+// address space.  A pointer that reaches a kernel inside a struct carries no no-alias promise, so its loads are kept
+// coherent with the kernel's own stores -- seven vector loads per lane for a descriptor (round 4: 9 M of them per
+// dispatch in the final stage of the dense scene, against 2.4 M mask gathers).  No voxel kernel writes a descriptor.
+__device__ __forceinline__ ViewDesc scalar_desc(const ViewDesc *views, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) ViewDesc *const_views_t;
+    return ((const_views_t)(uintptr_t)views)[__builtin_amdgcn_readfirstlane(i)];
+#else
+    return views[i];
+#endif
+}
 
 // n / d for n < 2^31 without a division (Granlund & Montgomery): t = mulhi(n, m); q = (t + n) >> s, exact for every
 // n below 2^31 (t + n cannot overflow there) with s = ceil(log2 d), m = floor(2^32 (2^s - d) / d) + 1 (host: fast_div).
