@@ -61,7 +61,7 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
                 uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
                                (uint32_t)((v & 7) * 16 + (u & 15));
                 uint32_t b = 0;
-                if (ok[e]) b = m[off];
+                if (ok[e]) b = load_mask_byte(m, off);
                 add[e] = lut_s[b];
             }
         } else if (d.pad == 2) {  // float32 in 8x4 tiles
@@ -71,7 +71,7 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
                 int u, v;
                 ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
                 add[e] = 0.0f;
-                if (ok[e]) add[e] = m[ftile_offset(u, v, d.tiles_x)];
+                if (ok[e]) add[e] = load_mask_float(m, (int64_t)ftile_offset(u, v, d.tiles_x));
             }
         } else {
             const float *m = static_cast<const float *>(d.mask);
@@ -80,7 +80,7 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
                 int u, v;
                 ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
                 add[e] = 0.0f;
-                if (ok[e]) add[e] = m[(int64_t)v * d.W + u];  // nearest texel
+                if (ok[e]) add[e] = load_mask_float(m, (int64_t)v * d.W + u);  // nearest texel
             }
         }
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
                     int u, v;
                     const bool ok = project(ax, ay, az, z[e], d, u, v);
                     float add = 0.0f;
-                    if (ok) add = mf[ftile_offset(u, v, d.tiles_x)];
+                    if (ok) add = load_mask_float(mf, (int64_t)ftile_offset(u, v, d.tiles_x));
                     if (ok) val[e] = val[e] + add;  // :54
                 }
                 continue;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
                 const uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
                                      (uint32_t)((v & 7) * 16 + (u & 15));
                 uint32_t b = 0;
-                if (ok) b = m[off];
+                if (ok) b = load_mask_byte(m, off);
                 const float add = lut_s[b];
                 if (ok) val[e] = val[e] + add;  // :54
             }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void avg_flags_multi_kernel(MultiArgs a, Gr
             for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const uint32_t o = a.views[l][vi].occ[ty * occ_tx + tx];
+                    const uint32_t o = load_occ(a.views[l][vi].occ, (uint32_t)(ty * occ_tx + tx));
                     any[l] |= o;
                     all[l] &= o;
                 }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void average_multi_kernel(MultiArgs a, Grid
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     uint32_t b = 0;
-                    if (ok[e]) b = m[off[e]];
+                    if (ok[e]) b = load_mask_byte(m, off[e]);
                     const float add = lut_s[l][b];
                     if (ok[e]) val[l][e] = val[l][e] + add;  // :54
                 }

@@ -150,6 +150,17 @@ __device__ __forceinline__ uint32_t load_mask_at(const void *mask, uint32_t byte
     return *(gmask_t)((gbytes_t)(uintptr_t)mask + byte_offset);
 }
 
+// The occupancy bytes and cell maps hang off a descriptor too (d.occ, d.cmask): the same cast, or every one of their
+// loads is a FLAT load -- the slow path that looks the address up in both apertures and holds up the scalar-memory
+// and LDS counter as well as the vector one (round 4: 228 of them in the special kernel, 57 in the dense kernel).
+typedef const __attribute__((address_space(1))) uint8_t *gbyte_t;
+__device__ __forceinline__ uint32_t load_occ(const uint8_t *occ, uint32_t i) { return ((gbyte_t)(uintptr_t)occ)[i]; }
+__device__ __forceinline__ uint32_t load_cells(const uint32_t *cmask, uint32_t i) { return ((gmask_t)(uintptr_t)cmask)[i]; }
+
+typedef const __attribute__((address_space(1))) float *gfloat_t;
+__device__ __forceinline__ uint32_t load_mask_byte(const void *mask, uint32_t i) { return ((gbyte_t)(uintptr_t)mask)[i]; }
+__device__ __forceinline__ float load_mask_float(const void *mask, int64_t i) { return ((gfloat_t)(uintptr_t)mask)[i]; }
+
 struct Vox4 {
     uint64_t elem;   // offset of the group's first voxel in the slab state
     uint32_t k0;     // z index of that voxel

@@ -131,7 +131,7 @@ __device__ __forceinline__ void window_cells(const ViewDesc &d, int cx0, int cx1
 #pragma unroll
         for (int b = 0; b < NX; ++b) {
             w[a][b] = 0u;
-            if (a < nyw && b < nxw) w[a][b] = d.cmask[(ty0 + a) * d.tiles_x + tx0 + b];
+            if (a < nyw && b < nxw) w[a][b] = load_cells(d.cmask, (uint32_t)((ty0 + a) * d.tiles_x + tx0 + b));
         }
     uint32_t cols[NX];
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     uint32_t any = 0, all = 3;
     for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
         for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
-            uint32_t o = d.occ[ty * occ_tx + tx];
+            uint32_t o = load_occ(d.occ, (uint32_t)(ty * occ_tx + tx));
             any |= o;
             all &= o;
         }
@@ -204,11 +204,11 @@ __device__ __forceinline__ uint32_t brick_flat_f32(const ViewDesc &d, const Grid
     if (!fpr.ok) return 0u;
     const int otx = (d.W + 31) >> 5, oty = (d.H + 31) >> 5;
     const uint32_t *val = reinterpret_cast<const uint32_t *>(d.occ + (((size_t)otx * oty + 3) & ~(size_t)3));
-    const uint32_t first = val[fpr.ty0 * otx + fpr.tx0];
+    const uint32_t first = load_cells(val, (uint32_t)(fpr.ty0 * otx + fpr.tx0));
     bool flat = true;
     for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
         for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx)
-            flat &= d.occ[ty * otx + tx] != 0 && val[ty * otx + tx] == first;
+            flat &= load_occ(d.occ, (uint32_t)(ty * otx + tx)) != 0 && load_cells(val, (uint32_t)(ty * otx + tx)) == first;
     bits = first;
     return flat ? 3u : 0u;
 }
