@@ -538,8 +538,13 @@ struct UnitJob {
                               // takes their voxels as they are (see carve_special_kernel, UnitSpill)
 };
 
+// (second: the verdicts of views 64 .. nall - 1 about this unit, asked beforehand for several units in one round --
+// see unit_second_word; bit k speaks of view 64 + k)
+struct SecondWord {
+    unsigned long long empty, full, need;
+};
 __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
-                                              uint32_t sub, uint32_t lane) {
+                                              uint32_t sub, uint32_t lane, const SecondWord &second) {
     const uint32_t lb = unit >> 2, w = unit & 3u;
     const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
     const uint32_t il = lb / per_plane;
@@ -564,10 +569,10 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     for (int e = 0; e < 4; ++e)
         if (lab[e] != -1) alive |= 1u << e;  // :67
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
-    unsigned long long need[2] = {0ull, 0ull};
-    bool seen = false, empty = false;
-    for (int h = 0; h < 2 && h * 64 < uj.nall; ++h) {
-        const int vi = h * 64 + (int)lane;
+    unsigned long long need[2] = {0ull, second.need};
+    bool seen = second.full != 0, empty = second.empty != 0;
+    {
+        const int vi = (int)lane;  // the first 64 views, one per lane
         uint32_t v = 8u;  // no such view, or one the dense stage has applied
         if (vi < uj.nall && vi >= uj.ndense) {
             const ViewDesc d = uj.views[vi];  // one descriptor per lane
@@ -575,7 +580,7 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
         }
         empty |= __ballot(v == 1u) != 0;
         seen |= __ballot(v == 2u) != 0;
-        need[h] = __ballot(v == 0u);
+        need[0] = __ballot(v == 0u);
     }
     unsigned long long b[4];
     uint32_t nalive = 0;
@@ -717,14 +722,44 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
                 if (tid < kSub) upref[tid + 1] = val + add;
                 __syncthreads();
             }
-            for (uint32_t i = blockIdx.x * kFlagWaves + wave; i < total; i += nworkers) {
-                uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (wave-uniform)
+            // A wavefront asks the first 64 views about a unit in one round, a view per lane; the views behind them -- 8 of
+            // a batch of 72 -- would fill an eighth of a second round, so that round is asked for G = 64 / (nall - 64)
+            // units at once (lane = unit slot * (nall - 64) + view - 64), ahead of the units' own rounds: 1 1/8 verdict
+            // rounds per unit instead of 2 (the rounds are latency chains, and what this kernel's time is made of).
+            const uint32_t per1 = sj.uj.nall > 64 ? (uint32_t)sj.uj.nall - 64u : 0u;
+            const uint32_t G = per1 ? 64u / per1 : 1u;  // (nall <= 128: per1 <= 64, G >= 1)
+            for (uint32_t i0 = (blockIdx.x * kFlagWaves + wave) * G; i0 < total; i0 += nworkers * G) {
+                const uint32_t slot = per1 ? lane / per1 : 0u;
+                const uint32_t i = i0 + min(slot, G - 1u);
+                const bool has = slot < G && i < total;
+                uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (per lane: the lanes of a slot agree)
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (upref[mid] <= i) lo = mid; else hi = mid;
+                    if (upref[mid] <= (has ? i : 0u)) lo = mid; else hi = mid;
                 }
-                const uint32_t unit = __builtin_amdgcn_readfirstlane(sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])]);
-                unit_verdicts(sj.uj, g, ctl, unit, lo, lane);
+                const uint32_t my_unit = has ? sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])] : 0u;
+                uint32_t v1 = 8u;  // no such view
+                if (has && per1) {
+                    const int vi = 64 + (int)(lane - slot * per1);
+                    const ViewDesc d = sj.uj.views[vi];  // one descriptor per lane
+                    const uint32_t lb = my_unit >> 2, w = my_unit & 3u;
+                    const uint32_t per_plane = sj.uj.bricks_y * sj.uj.bricks_z;
+                    const uint32_t il = lb / per_plane, rem = lb - il * per_plane;
+                    const uint32_t by = rem / sj.uj.bricks_z, bz = rem - by * sj.uj.bricks_z;
+                    const int j0 = (int)(by * kBrickY), kb = (int)(bz * kBrickZ + w * 16u);
+                    const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
+                    v1 = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
+                }
+                const unsigned long long e1 = __ballot(v1 == 1u), f1 = __ballot(v1 == 2u), n1 = __ballot(v1 == 0u);
+                const unsigned long long word = per1 >= 64u ? ~0ull : ((1ull << per1) - 1ull);
+                for (uint32_t u = 0; u < G && i0 + u < total; ++u) {  // wave-uniform
+                    const uint32_t src = u * per1;  // the first lane of the slot (lane 0 when there is no second word)
+                    const uint32_t unit = __builtin_amdgcn_readlane(my_unit, src);
+                    const uint32_t sub = __builtin_amdgcn_readlane(lo, src);
+                    const SecondWord second{(e1 >> src) & word & (per1 ? ~0ull : 0ull), (f1 >> src) & word & (per1 ? ~0ull : 0ull),
+                                            (n1 >> src) & word & (per1 ? ~0ull : 0ull)};
+                    unit_verdicts(sj.uj, g, ctl, unit, sub, lane, second);
+                }
             }
         }
     }
