@@ -556,18 +556,9 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     const int nvalid = inside ? (int)min(4u, g.nz - k0) : 0;
     const uint32_t elem = (il * g.ny + j) * g.nzp + k0;
     int32_t *p = uj.labels + elem;  // the pitch is a multiple of 64: 16-byte groups
-    int32_t lab[4] = {-1, -1, -1, -1};  // what a lane does not own counts as carved
-    if (inside) {
-        const int4 q = *reinterpret_cast<const int4 *>(p);
-        lab[0] = q.x; lab[1] = q.y; lab[2] = q.z; lab[3] = q.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
-    }
-    uint32_t alive = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (lab[e] != -1) alive |= 1u << e;  // :67
+    // (the labels are asked for here and looked at behind the verdict round: one memory round trip, not two in a row)
+    int4 q = make_int4(-1, -1, -1, -1);  // what a lane does not own counts as carved
+    if (inside) q = *reinterpret_cast<const int4 *>(p);
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // :71, global plane index
     unsigned long long need[2] = {0ull, second.need};
     bool seen = second.full != 0, empty = second.empty != 0;
@@ -582,6 +573,14 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
         seen |= __ballot(v == 2u) != 0;
         need[0] = __ballot(v == 0u);
     }
+    int32_t lab[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e >= nvalid) lab[e] = -1;  // row padding behind the last voxel
+    uint32_t alive = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (lab[e] != -1) alive |= 1u << e;  // :67
     unsigned long long b[4];
     uint32_t nalive = 0;
 #pragma unroll
