@@ -63,10 +63,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
     __shared__ uint32_t pref[kSub + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t bx = blockIdx.x, gdim = gridDim.x;
-    // A final stage with deferred stores has cs.nstrips STORE blocks behind its persistent list
-    // blocks: this stage is bound by projection arithmetic and the -1 fill of the bricks the flags
-    // kernel found empty by HBM writes, so the two run side by side instead of one after the
-    // other.  The list blocks leave wavefront slots free; short store blocks stream through them.
+    // A list stage with deferred stores has STORE blocks behind its persistent list blocks: the stage's
+    // own work is projection arithmetic, the -1 fill of the bricks the flags kernel found empty is HBM
+    // writes, so the two run side by side instead of one after the other.  (Since round 4 cut the
+    // arithmetic the final stage of a plant is bound by the fill beside it -- about 5.3 TB/s there,
+    // whatever the store pattern: DESIGN_APPENDIX.md 12.)
     const bool split = cs.flags != nullptr;
     const uint32_t nown = cs.nstrips - cs.first, nvirt = nown + cs.spec;  // the share proper, and the prefilled strips behind it
     const uint32_t nstore = split ? (cs.fill_blocks ? cs.fill_blocks : nvirt) : 0u;
