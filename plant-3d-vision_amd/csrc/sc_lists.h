@@ -49,10 +49,11 @@ struct UnitSpill {
 //     are many more items than wavefronts (no tail); groups of one chunk may run concurrently
 //     on different wavefronts, which is exact because a carve is a plain store of -1 (final,
 //     idempotent) and a 0 -> 1 promotion is a compare-and-swap on 0 (it can never undo a -1).
-// (at most 80 SGPRs: with 82-96 the CU admits 7 such blocks instead of 8, with 98+ only 6 --
-// MI355X_MICROARCH.md, "Residency" -- and the store blocks need the slots the list blocks leave)
+// (at most 96 SGPRs -- the eight lane masks of four views a turn need them: with 82-96 the CU admits 7 such blocks
+// instead of 8, with 98+ only 6 -- MI355X_MICROARCH.md, "Residency"; the list stages run 6 blocks per CU, store blocks
+// included, and the store blocks need the slots the list blocks leave)
 template <bool FINAL, int P, bool ALL_SAFE = false>  // P voxels per lane (an item is a chunk of 64 * P entries); ALL_SAFE: see project()
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void carve_list_kernel(int32_t *__restrict__ labels, GridDesc g,
                                                             const ViewDesc *__restrict__ views,
                                                             int nviews,
                                                             const uint32_t *__restrict__ lin,
@@ -235,9 +236,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void c
             y[p] = g.oy + (float)(int)j * g.vs;
             z[p] = g.oz + (float)(int)k * g.vs;
         }
-        // U views per iteration.  The final stage is bound by arithmetic (U = 2); the stages before
-        // it wait on memory and most of their voxels die within a few views (U = 4).
-        constexpr int U = P >= 4 ? 1 : (FINAL ? 2 : 4);
+        // U views per iteration: four (8 projection chains and 8 gathers in flight per lane at P = 2).  The final stage ran
+        // two until round 4's end -- it was bound by its arithmetic then; beside the fill that bounds it now, four took
+        // it from 67.2 to 63.3 us and the batch from 0.160 to 0.1545 ms (same box, four runs each).
+        constexpr int U = P >= 4 ? 1 : 4;
         for (;;) {  // (once; a second time over the views behind this stage's for a chunk whose survivors find no room)
         for (int vi = v0; vi < v1; vi += U) {
             unsigned long long any = 0;
