@@ -241,32 +241,51 @@ __device__ __forceinline__ void store_culled_bricks(int32_t *__restrict__ labels
 #ifdef SC_TRACE_DENSE  // diagnostic builds only (tools/probes/dense_trace.py): what every walker wavefront of the dense
 __device__ uint32_t g_dense_trace[8192 * 8];  // stage did (rows 0..4095)
 #endif
-// FULL candidates (flag 3: every view the flags kernel could see keeps the brick whole, but the masks
+// FULL candidates (flag 3 / 7: every view the flags kernel could see keeps the brick whole, but the masks
 // of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
-// views: same organisation as the flags kernel's own FULL rounds (64 bricks per block, one view per
-// wavefront and round, verdicts joined in LDS).  Kept by all: flag 2, filled like any FULL brick.
+// views.  The flags kernel's organisation for its own FULL rounds -- a brick per lane, a view per wavefront and
+// round, verdicts joined in LDS -- over the CANDIDATE LIST that kernel leaves (ListCtl::lc), 64 entries per block:
+// every lane has a question.  (Until round 4 a block took 64 bricks where they lie, candidates or not: five
+// candidates cost the 7 rounds of 8 views that 64 cost, and the kernel is bound by what it issues, not by the chain
+// of its rounds -- 65 us on a bulky object with 8 or with 16 wavefronts per block: DESIGN_APPENDIX 12.)
+// Kept by all: flag 2 (or 6, unseen), filled like any FULL brick.
 // Otherwise flag 5 and a place on the LATE list: the special kernel (carve_special_kernel) carves such a brick
-// over all the views of the batch, unit by unit.  A block without candidates leaves at once.
-__global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
+// over all the views of the batch, unit by unit.
+constexpr int kConfirmWaves = 8;  // (16: a solid object 0.219 -> 0.253 ms -- a round asks all its views about every brick still
+                                  // a candidate, so wider rounds ask more views about bricks an earlier one would have dropped)
+__global__ __launch_bounds__(64 * kConfirmWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
-    uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ late, ListCtl *ctl) {
-    if (v0 >= v1 || ctl->cand.n == 0) return;  // no view was packed late, or the flags kernel left no candidate open
-    __shared__ unsigned long long s_full[kFlagWaves], s_seen[kFlagWaves];
+    uint8_t *__restrict__ flags, const uint32_t *__restrict__ cands, uint32_t cand_per, uint32_t *__restrict__ late,
+    ListCtl *ctl, uint32_t parity) {
+    if (v0 >= v1) return;  // no view was packed late
+    // the sub-lists' groups of 64, one behind the other (a batch without open candidates: every block leaves here)
+    uint32_t ncand[kCandSub], gfirst[kCandSub + 1];
+    gfirst[0] = 0;
+#pragma unroll
+    for (int s = 0; s < kCandSub; ++s) {
+        ncand[s] = ctl->ncand[parity][s].n;
+        gfirst[s + 1] = gfirst[s] + ((ncand[s] + 63u) >> 6);
+    }
+    __shared__ unsigned long long s_full[kConfirmWaves], s_seen[kConfirmWaves];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t per_plane = bricks_y * bricks_z;
-    // a persistent grid over the groups of 64 bricks
-    for (uint32_t grp = blockIdx.x; grp * 64u < nbricks; grp += gridDim.x) {
-        const uint32_t lb = grp * 64u + lane;
-        const uint32_t fl = lb < nbricks ? flags[lb] : 0u;
-        const bool isc = fl == 3u || fl == 7u;  // candidates: some view so far saw the brick whole / none sees it
-        unsigned long long any_seen = __ballot(fl == 3u);
+    // a persistent grid over the groups of 64 candidates
+    for (uint32_t grp = blockIdx.x; grp < gfirst[kCandSub]; grp += gridDim.x) {
+        uint32_t sub = 0, first = 0, n = ncand[0];
+#pragma unroll
+        for (int s = 1; s < kCandSub; ++s)
+            if (grp >= gfirst[s]) { sub = (uint32_t)s; first = gfirst[s]; n = ncand[s]; }
+        const uint32_t idx = (grp - first) * 64u + lane;
+        const bool isc = idx < n;
+        const uint32_t lb = isc ? cands[(size_t)sub * cand_per * 64u + idx] : 0u;
+        const uint32_t fl = isc ? flags[lb] : 0u;
+        unsigned long long any_seen = __ballot(fl == 3u);  // some view so far saw the brick whole (7: none sees it)
         unsigned long long cand = __ballot(isc);
-        if (cand == 0) continue;  // block-uniform: every wavefront read the same 64 flags
         const uint32_t il = lb / per_plane;
         const uint32_t rem = lb - il * per_plane;
         const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
         const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
-        for (int base = v0; base < v1 && cand != 0; base += kFlagWaves) {  // block-uniform
+        for (int base = v0; base < v1 && cand != 0; base += kConfirmWaves) {  // block-uniform
             const int vi = base + (int)wave;
             bool keeps = true, sees = false;
             if (vi < v1 && ((cand >> lane) & 1ull)) {
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_confirm_kernel(
             if (lane == 0) { s_full[wave] = mf; s_seen[wave] = ms; }
             __syncthreads();
 #pragma unroll
-            for (int w = 0; w < kFlagWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
+            for (int w = 0; w < kConfirmWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
         }
         if (wave != 0) continue;
         if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;

@@ -59,6 +59,7 @@ constexpr int kSub = 256;        // sharded append counters = sub-lists of a sur
 constexpr int kStreamGroups = 2; // 16-byte groups per lane in the per-view streaming kernel
                                  // (measured with streaming loads: 2 -> 0.0803, 3 -> 0.0811, 4 -> 0.0860 ms)
 constexpr int kXcdRun = 16;      // consecutive logical blocks kept on one XCD
+constexpr int kCandSub = 8;      // sub-lists of the candidate list (see ListCtl::ncand)
 
 // Survivor lists of the fused carve (see carve_list_kernel).  Zeroed before every fused launch.
 // Every counter sits on a 128-byte line of its own: returning device-scope atomics on one
@@ -88,11 +89,13 @@ struct ListCtl {
     uint32_t pad[26];
     ListCounter xcd_next[64];    // dense stage: ticket counters for the live list, 8 per XCD (index xcd * 8 + c: the
                                  // wavefronts of XCD k whose number ends in c share one; see carve_brick_kernel)
-    ListCounter cand;            // .n non-zero: the flags kernel left FULL candidates open (the confirm kernel has work).
-                                 // A flag on a line of its own, read before it is written: as a count (an atomic per
-                                 // block, 11 ns each on one address) it cost 22 us when every brick is a candidate,
-                                 // and as a plain store on the line of the live-brick counter it doubled that
-                                 // kernel's time on a bulky object (the atomics on `nlive` waited behind the stores)
+    ListCounter ncand[2][kCandSub];  // FULL candidates the flags kernel left open for the confirm kernel: entries of the
+                                 // candidate list's sub-lists, same alternation as nlive.  Sub-list s takes the blocks
+                                 // [s per, (s + 1) per) of the flags kernel, one atomic per block with candidates --
+                                 // inside a solid object that is every block at about the same time, and returning
+                                 // atomics on one line serialise at 11 ns each: one counter for all of them (a 64-bit
+                                 // add that reserved the live list's places as well) made the flags kernel 25 -> 35 us
+                                 // there
 };
 
 // Bricks whose -1 fill is left to the final list stage (see carve_list_kernel).

@@ -181,12 +181,35 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
     if (fpr.outside) return 4u;  // OUTSIDE: the view does nothing to the brick
     if (!fpr.ok) return 0u;
     uint32_t any = 0, all = 3;
-    for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
-        for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
-            uint32_t o = load_occ(d.occ, (uint32_t)(ty * occ_tx + tx));
-            any |= o;
-            all &= o;
+    if (occ_tx >= 8) {
+        // A tile row's bytes lie side by side: EIGHT of them in one (unaligned) load, four tile rows per turn -- the
+        // footprint of a brick is 2-4 tiles wide and 4-7 tall, and asked for byte by byte its 12-18 loads are what
+        // the flags and confirm kernels spend their time on (each lane's byte in a cache line of its own).  The
+        // eight start at the footprint's first column, or further left when that would run past the row's end; the
+        // bytes outside the footprint are masked out.  A row looked at twice changes neither the OR nor the AND.
+        typedef const __attribute__((address_space(1), aligned(1))) unsigned long long *grow_t;
+        unsigned long long any8 = 0ull, all8 = ~0ull;
+        for (int cx = fpr.tx0; cx <= fpr.tx1; cx += 8) {
+            const int start = min(cx, occ_tx - 8), off = cx - start, ncols = min(fpr.tx1 - cx + 1, 8);
+            const unsigned long long m = (ncols >= 8 ? ~0ull : ((1ull << (8 * ncols)) - 1ull)) << (8 * off);
+            for (int ty = fpr.ty0; ty <= fpr.ty1; ty += 4) {
+                unsigned long long w[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) w[a] = *(grow_t)(uintptr_t)(d.occ + (uint32_t)(min(ty + a, fpr.ty1) * occ_tx + start));
+                any8 |= ((w[0] | w[1]) | (w[2] | w[3])) & m;
+                all8 &= ((w[0] & w[1]) & (w[2] & w[3])) | ~m;
+            }
         }
+        any = (any8 & 0x0101010101010101ull) != 0ull ? 1u : 0u;
+        all = (all8 & 0x0202020202020202ull) == 0x0202020202020202ull ? 2u : 0u;
+    } else {
+        for (int ty = fpr.ty0; ty <= fpr.ty1; ++ty)
+            for (int tx = fpr.tx0; tx <= fpr.tx1; ++tx) {
+                uint32_t o = load_occ(d.occ, (uint32_t)(ty * occ_tx + tx));
+                any |= o;
+                all &= o;
+            }
+    }
     // every voxel of the brick lands in-image on a pixel of these tiles: all of them background
     // (EMPTY: the view carves the whole brick) or all of them foreground (FULL: the view keeps it)
     return (any & 1u) == 0 ? 1u : ((all & 2u) != 0 ? 2u : 0u);
@@ -246,7 +269,8 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int nviews, uint32_t bricks_y, uint32_t bricks_z,
     uint32_t nbricks, uint8_t *__restrict__ flags, uint32_t *__restrict__ live, ListCtl *ctl,
     FlagViews own, DescCopy dc, const ViewDesc *__restrict__ allviews, int nall, int nbatch,
-    uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list, SpecFill sf) {
+    uint8_t *__restrict__ dead, int dead_stale, uint32_t parity, uint32_t *__restrict__ fill_list, SpecFill sf,
+    uint32_t *__restrict__ cands, uint32_t cand_per) {
     __shared__ unsigned long long s_empty[kFlagWaves], s_full[kFlagWaves], s_seen[kFlagWaves];
     if (blockIdx.x < sf.nblocks) {  // block-uniform
         typedef int v4i __attribute__((ext_vector_type(4)));
@@ -261,6 +285,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     if (bid == 0) {
         for (uint32_t i = threadIdx.x; i < dc.words; i += 64 * kFlagWaves) dc.dst[i] = dc.src[i];
         if (threadIdx.x == 0) ctl->nlive[parity ^ 1u] = ctl->nfill[parity ^ 1u] = 0u;  // the next launch's counters
+        if (threadIdx.x < (uint32_t)kCandSub) ctl->ncand[parity ^ 1u][threadIdx.x].n = 0u;
     }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t lb = bid * 64u + lane;
@@ -338,20 +363,28 @@ __global__ __launch_bounds__(64 * kFlagWaves) void brick_flags_kernel(
     // kept by every view of the batch: FULL (2: some view saw it, a 0 becomes 1) or UNTOUCHED (6: no view
     // sees any of it, the labels stay); by every view packed so far only: a candidate (3 seen / 7 unseen)
     if (inb) flags[lb] = isdead ? 4 : (gone ? 1 : (kept ? (nall >= nbatch ? (saw ? 2 : 6) : (saw ? 3 : 7)) : 0));
-    if (nall < nbatch) {  // grid-uniform: later views are not packed yet, kept bricks are candidates
-        const unsigned long long mc = __ballot(inb && !isdead && !gone && kept);
-        if (mc != 0 && lane == 0 && ctl->cand.n == 0u) ctl->cand.n = 1u;
-    }
     if (valid && dead != nullptr && (gone || dead_stale)) dead[lb] = gone ? 1 : 0;
     // the bricks left go on the live list, one atomic per block
     const bool alive = valid && !gone && !kept;
     const unsigned long long m = __ballot(alive);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (m != 0) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&ctl->nlive[parity], (uint32_t)__popcll(m));
         base = __shfl(base, 0);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         if (alive) live[base + (uint32_t)__popcll(m & below)] = lb;
+    }
+    // ... and, while later views are not packed yet (grid-uniform), the kept ones on the candidate list, whose 64-entry
+    // groups the confirm kernel asks those views about with every lane at work (asked where they lie, a block of 64
+    // bricks with five candidates cost what one with 64 costs); sub-list = this block's eighth of the grid
+    const bool open = cands != nullptr && nall < nbatch && inb && !isdead && !gone && kept;
+    const unsigned long long mc = __ballot(open);
+    if (mc != 0) {
+        const uint32_t sub = bid / cand_per;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->ncand[parity][sub].n, (uint32_t)__popcll(mc));
+        base = __shfl(base, 0);
+        if (open) cands[(size_t)sub * cand_per * 64u + base + (uint32_t)__popcll(mc & below)] = lb;
     }
     if (fill_list != nullptr) {  // launches whose dense kernel fills from a list (see carve_brick_light_kernel)
         const bool fillme = valid && (gone || kept);

@@ -1168,6 +1168,9 @@ int flush(sc_engine *e, size_t count = 0) {
             e->ctl_clean[e->ctl_idx] = false;
         }
         const uint32_t parity = (uint32_t)(e->flag_launches & 1u);
+        // blocks of the flags kernel per sub-list of the candidate list (ListCtl::ncand): sub-list s holds the candidates of
+        // blocks [s per, (s + 1) per) at cands + s per 64 -- at most the bricks of those blocks, so the lists fit in nbricks words
+        const uint32_t cand_per = std::max<uint32_t>(1u, (uint32_t)(((nbricks + 63u) / 64u + kCandSub - 1) / kCandSub));
         if (brick) ++e->flag_launches;
         if (compact) {
             rc = ensure_lists(e);
@@ -1247,7 +1250,8 @@ int flush(sc_engine *e, size_t count = 0) {
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
                                    flag_views, bys, bzs, nbricks, e->flags, e->live, e->ctl, own, dc,
                                    desc_by_flags ? vpin : vd, e->full_bricks ? packed_ahead : 0, (int)nv, e->dead,
-                                   dead_stale, parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list, sf);
+                                   dead_stale, parity, compact ? static_cast<uint32_t *>(nullptr) : e->fill_list, sf,
+                                   compact ? e->fill_list : static_cast<uint32_t *>(nullptr), cand_per);  // (the room of the fill list holds the candidate list when nothing fills from a list)
                 e->last_parity = parity;
                 rc = ltf.end();
                 if (rc) return rc;
@@ -1306,8 +1310,8 @@ int flush(sc_engine *e, size_t count = 0) {
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
                 // (one block per 64 bricks up to 4096 blocks; without candidates a block leaves after one scalar load)
                 const uint32_t nconfirm = std::min<uint32_t>((nbricks + 63u) / 64u, 4096u);
-                hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kFlagWaves), 0, e->stream, g, vd,
-                                   packed_ahead, (int)nv, bys, bzs, nbricks, e->flags, e->late, e->ctl);
+                hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kConfirmWaves), 0, e->stream, g, vd,
+                                   packed_ahead, (int)nv, bys, bzs, e->flags, e->fill_list, cand_per, e->late, e->ctl, parity);
             }
             // Too few bulk units for their verdicts are taken by the first survivor stage as they are (UnitSpill); a
             // batch with a single (final) list stage has no such stage: its units are always asked
