@@ -1308,7 +1308,8 @@ int flush(sc_engine *e, size_t count = 0) {
             CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0, 0u}, cs = none;
             if (ride_blocks) {
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
-                // (one block per 64 bricks up to 4096 blocks; without candidates a block leaves after one scalar load)
+                // (a block per 64 entries of the candidate list, a persistent grid of at most 4096; without candidates
+                // every block leaves after eight scalar loads)
                 const uint32_t nconfirm = std::min<uint32_t>((nbricks + 63u) / 64u, 4096u);
                 hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kConfirmWaves), 0, e->stream, g, vd,
                                    packed_ahead, (int)nv, bys, bzs, e->flags, e->fill_list, cand_per, e->late, e->ctl, parity);
