@@ -339,6 +339,37 @@ def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape
     e.close()
 
 
+@pytest.mark.parametrize("kind,shape,nv", [("dense", (40, 128, 256), 30), ("solid", (36, 100, 200), 24),
+                                           ("dense", (70, 64, 130), 40)])
+def test_full_candidates_on_their_list_over_many_flag_blocks(gpu_device, kind, shape, nv):
+    """FULL candidates (bricks every view packed ahead keeps whole) are listed by the flags kernel in eight sub-lists
+    by block range and asked about the late views by the confirm kernel, 64 list entries per block (ListCtl::ncand).
+    Grids of 16-35 flag blocks: several blocks per sub-list, sub-lists that end inside a group of 64, candidates that
+    fail (late bricks) and candidates that hold -- every label equal to the oracle's, on a fresh volume, on a second
+    batch over the stored one, and with the riders off (no candidate stays open)."""
+    sh, origin, vs, views = scene(shape, nv, kind)
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=8)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    V, H, W = stack.shape
+    late = {}
+    for ride in (1, 0):
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+        e.set_option(nat.SC_OPT_PACK_RIDE, ride)
+        ptr = e.dev_alloc(stack.nbytes)
+        e.dev_upload(ptr, stack)
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (kind, "fresh", ride, histogram3(want))
+        late[ride] = e.fused_counts_ex()["late_bricks"]
+        e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (kind, "stored state", ride)
+        e.dev_free(ptr)
+        e.close()
+    assert late[0] == 0  # every mask packed ahead: the flags kernel settles FULL bricks itself
+    if shape == (40, 128, 256):
+        assert late[1] > 0, "the scene is meant to leave candidates that a late view rejects"
+
+
 @pytest.mark.parametrize("shape", [(6, 32, 128), (5, 37, 131), (3, 16, 64)])
 @pytest.mark.parametrize("default_value", [0, 1, -1, 7])
 @pytest.mark.parametrize("defer", [1536, 0])
