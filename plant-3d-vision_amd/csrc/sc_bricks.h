@@ -388,11 +388,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
             // eight counters per XCD, each dealing every eighth run of the XCD's entries to the wavefronts whose
             // number ends in c: returning atomics on one address take 11 ns each, and with one counter per XCD the
             // 1 500 tickets of a plant's batch were 16 us of them in a row
-            const uint32_t c = t & 7u;
+            // (fewer than eight wavefronts per XCD -- 8 walker blocks, a test's setting -- share as many counters as
+            // there are of them: with eight, the runs of the counters nobody holds were dealt to nobody, and a live list
+            // of more than 512 bricks kept labels no view had been applied to -- found by the fuzz sweep's big grids)
+            const uint32_t nc = min(8u, per_xcd);
+            const uint32_t c = t % nc;
             uint32_t n = 0;
             if (lane == 0) n = atomicAdd(&ctl->xcd_next[xcd * 8u + c].n, 1u);
             n = __builtin_amdgcn_readfirstlane(n);
-            t = per_xcd + ((n / kXcdRun) * 8u + c) * kXcdRun + (n % kXcdRun);
+            t = per_xcd + ((n / kXcdRun) * nc + c) * kXcdRun + (n % kXcdRun);
         }
         first = false;
         t = __builtin_amdgcn_readfirstlane(t);

@@ -339,6 +339,30 @@ def test_fused_pipeline_knobs_never_change_a_label(gpu_device, opts, kind, shape
     e.close()
 
 
+@pytest.mark.parametrize("opts", [{"SC_OPT_BRICK_WALKERS": 8}, {"SC_OPT_LIST_BLOCKS": 8, "SC_OPT_PACK_RIDE": 0},
+                                  {"SC_OPT_BRICK_WALKERS": 24}, {}])
+def test_few_walker_blocks_on_a_long_live_list(gpu_device, opts):
+    """The dense stage's walkers draw their bricks from eight ticket counters per XCD, each dealing every eighth run of
+    16 live-list entries.  With 8 walker blocks an XCD has four wavefronts: they must share four counters -- with
+    eight, the runs of the counters nobody holds went to nobody, and a live list of more than 512 bricks kept labels no
+    view had been applied to (round 4, found by the fuzz sweep once it drew grids of this size)."""
+    sh, origin, vs, views = scene((36, 142, 208), 12, "noise")
+    want = oracle_c.carve(sh, origin, vs, views, nthreads=8)
+    e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE)
+    for k, v in opts.items():
+        e.set_option(getattr(nat, k), v)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = e.dev_alloc(stack.nbytes)
+    e.dev_upload(ptr, stack)
+    K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+    for state in ("fresh", "stored state"):
+        e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+        assert np.array_equal(e.get_values(), want), (opts, state)
+    assert e.fused_counts()[0] > 512, "the scene is meant to leave a long live list"
+    e.dev_free(ptr)
+    e.close()
+
+
 @pytest.mark.parametrize("kind,shape,nv", [("dense", (40, 128, 256), 30), ("solid", (36, 100, 200), 24),
                                            ("dense", (70, 64, 130), 40)])
 def test_full_candidates_on_their_list_over_many_flag_blocks(gpu_device, kind, shape, nv):

@@ -3,7 +3,11 @@
 principal points thousands of pixels off the picture, focal lengths up to 1e5, voxel sizes from 1e-3
 to 1e3), default values and pipeline knobs; every volume must equal the oracle's, fresh and on a
 second batch, through host masks or a device batch.
-Usage: timeout -k 10 900 python tools/fuzz_carve.py [cases] [seed] [summary.json]
+Usage: timeout -k 10 900 python tools/fuzz_carve.py [cases] [seed] [summary.json] [share of big cases, default 0]
+(big cases: grids of up to 48 x 160 x 320 voxels and up to 40 views -- tens of blocks in the flags kernel, several per
+sub-list of the candidate list, riders in most cases)
+FUZZ_ONLY="17,330": replay the same draws but run only those cases, print where their labels differ and which of
+their knobs the mismatch needs (each left out in turn).
 (diagnostic, not part of the test suite; prints each case before it runs so that a fault can be traced
 to its parameters; the summary of the round's run is kept under profiles/)."""
 import os, sys
@@ -28,12 +32,17 @@ KNOBS = {
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    big_share = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    only = {int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x.strip()}
     bad = 0
     certified_views = uncertified_views = averaged = 0
     for c in range(cases):
         shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
         kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
         nviews = int(rng.integers(1, 16))
+        if big_share > 0 and rng.random() < big_share:
+            shape = (int(rng.integers(16, 49)), int(rng.integers(48, 161)), int(rng.integers(100, 321)))
+            nviews = int(rng.integers(12, 41))
         kw = dict(radius_factor=float(rng.choice([0.3, 0.8, 1.5, 3.0])), tilt_deg=float(rng.choice([0.0, 0.0, 25.0, 50.0])),
                   voxel_size=float(rng.choice([1e-3, 0.5, 0.5, 0.5, 1.7, 1e3])))
         if rng.random() < 0.4:
@@ -51,28 +60,53 @@ def main():
         uncertified_views += len(views) - ncert
         dv = int(rng.choice([0, 0, 0, 1, -1, 5]))
         opts = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
-        print(f"case {c}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts}", flush=True)
-        want = oracle_c.carve(sh, origin, vs, views, dv, nthreads=4)
-        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=dv)
-        for k, v in opts.items():
-            e.set_option(getattr(nat, k), v)
+        run_it = not only or c in only
         device_masks = rng.random() < 0.5
-        stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
-        K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
-        ptr = e.dev_alloc(stack.nbytes); e.dev_upload(ptr, stack)
         ok = True
-        for rnd in range(2):
-            if device_masks:
-                e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
-            else:
-                for Kq, Rq, tq, m in views:
-                    e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
-            got = e.get_values()
-            if not np.array_equal(got, want):
-                ok = False
-                print(f"MISMATCH case {c} round {rnd}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts} "
-                      f"device {device_masks}: {int((got != want).sum())} voxels differ")
-        e.dev_free(ptr); e.close()
+        if run_it:
+            print(f"case {c}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts}", flush=True)
+            want = oracle_c.carve(sh, origin, vs, views, dv, nthreads=4)
+            stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+            K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
+
+            def carve_twice(o):
+                e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=dv)
+                for k, v in o.items():
+                    e.set_option(getattr(nat, k), v)
+                ptr = e.dev_alloc(stack.nbytes); e.dev_upload(ptr, stack)
+                gots = []
+                for rnd in range(2):
+                    if device_masks:
+                        e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+                    else:
+                        for Kq, Rq, tq, m in views:
+                            e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+                    gots.append(e.get_values().copy())
+                counts = e.fused_counts_ex()
+                e.dev_free(ptr); e.close()
+                return gots, counts
+
+            gots, counts = carve_twice(opts)
+            for rnd, got in enumerate(gots):
+                if not np.array_equal(got, want):
+                    ok = False
+                    print(f"MISMATCH case {c} round {rnd}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts} "
+                          f"device {device_masks}: {int((got != want).sum())} voxels differ")
+            if only and not ok:  # where, what, and which knobs it takes
+                got = gots[0]
+                badv = np.argwhere(got != want)
+                print("   counts", counts)
+                print("   planes", np.unique(badv[:, 0])[:24], "strips y", np.unique(badv[:, 1] // 16)[:24], "bricks z", np.unique(badv[:, 2] // 64))
+                pairs, n = np.unique(np.stack([got[got != want], want[got != want]], 1), axis=0, return_counts=True)
+                print("   (got, want):", [(tuple(int(x) for x in pq), int(q)) for pq, q in zip(pairs, n)])
+                for b in badv[:12]:
+                    print("    ", tuple(int(x) for x in b), "got", int(got[tuple(b)]), "want", int(want[tuple(b)]))
+                for k in list(opts):
+                    o = dict(opts); del o[k]
+                    g2, _ = carve_twice(o)
+                    print(f"   without {k}={opts[k]}: {int((g2[0] != want).sum())} / {int((g2[1] != want).sum())} differ", flush=True)
+                g3, _ = carve_twice({})
+                print(f"   no knobs: {int((g3[0] != want).sum())} / {int((g3[1] != want).sum())} differ", flush=True)
         # the average kernel on the same rig (every third case): uint8 masks through the table or float32
         # masks, binary or grey, fused / per view, brick and tile forms on or off -- bitwise against the oracle
         if c % 3 == 0 and int(np.prod(sh)) * nviews < 4e7:
@@ -88,10 +122,12 @@ def main():
                     ms.append(rng.integers(0, 256, m.shape, dtype=np.uint8) if grey else m)
                 else:
                     ms.append(rng.random(m.shape, dtype=np.float32) if grey else table[m])
-            fviews = [(Kq, Rq, tq, (table[m] if form == "u8" else m)) for (Kq, Rq, tq, _), m in zip(views, ms)]
-            wantf = oracle_c.average(sh, origin, vs, fviews, adv, nthreads=4)
             aopts = {"SC_OPT_VIEWS_PER_LAUNCH": int(rng.choice([0, 0, 1, 4])), "SC_OPT_AVG_BRICK": int(rng.choice([0, 1, 1])),
                      "SC_OPT_AVG_TILE_F32": int(rng.choice([0, 1, 1]))}
+            if not run_it:
+                continue
+            fviews = [(Kq, Rq, tq, (table[m] if form == "u8" else m)) for (Kq, Rq, tq, _), m in zip(views, ms)]
+            wantf = oracle_c.average(sh, origin, vs, fviews, adv, nthreads=4)
             print(f"   average: form {form} grey {grey} log {log} default {adv} opts {aopts}", flush=True)
             ea = nat.Engine(sh, origin, vs, nat.SC_MODE_AVERAGE, default_value=adv)
             ea.set_lut(table)
