@@ -41,7 +41,8 @@ def main():
         kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
         nviews = int(rng.integers(1, 16))
         if big_share > 0 and rng.random() < big_share:
-            shape = (int(rng.integers(16, 49)), int(rng.integers(48, 161)), int(rng.integers(100, 321)))
+            bx, by_, bz_ = (int(x) for x in os.environ.get("FUZZ_BIG_MAX", "48,160,320").split(","))  # (e.g. 128,320,640)
+            shape = (int(rng.integers(16, bx + 1)), int(rng.integers(48, by_ + 1)), int(rng.integers(100, bz_ + 1)))
             nviews = int(rng.integers(12, 41))
         kw = dict(radius_factor=float(rng.choice([0.3, 0.8, 1.5, 3.0])), tilt_deg=float(rng.choice([0.0, 0.0, 25.0, 50.0])),
                   voxel_size=float(rng.choice([1e-3, 0.5, 0.5, 0.5, 1.7, 1e3])))
