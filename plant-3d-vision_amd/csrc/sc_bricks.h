@@ -244,7 +244,7 @@ __device__ uint32_t g_dense_trace[8192 * 8];  // stage did (rows 0..4095)
 // FULL candidates (flag 3 / 7: every view the flags kernel could see keeps the brick whole, but the masks
 // of views [v0, v1) were packed only afterwards, beside the dense stage) put the question to those
 // views.  The flags kernel's organisation for its own FULL rounds -- a brick per lane, a view per wavefront and
-// round, verdicts joined in LDS -- over the CANDIDATE LIST that kernel leaves (ListCtl::lc), 64 entries per block:
+// round, verdicts joined in LDS -- over the CANDIDATE LIST that kernel leaves (ListCtl::ncand: eight sub-lists, one behind the other here), 64 entries per block:
 // every lane has a question.  (Until round 4 a block took 64 bricks where they lie, candidates or not: five
 // candidates cost the 7 rounds of 8 views that 64 cost, and the kernel is bound by what it issues, not by the chain
 // of its rounds -- 65 us on a bulky object with 8 or with 16 wavefronts per block: DESIGN_APPENDIX 12.)
