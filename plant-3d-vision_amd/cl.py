@@ -189,7 +189,8 @@ class Backprojection(object):
     dtype : numpy.int32 ("carving") or numpy.float32 ("averaging")   (cl.py:145-150)
     kernel : str, "carve" or "average" -- the HIP kernel that will run
     values_h : numpy.ndarray, host copy of the volume (refreshed by ``get_values``)
-    values_d : int, device address of the volume as ``device_values()`` last returned it (``None`` before that)
+    values_d : int, device address of the volume (``device_values()``; fetched on demand, dropped whenever the
+        state changes, so a read is never a stale snapshot)
     """
 
     def __init__(self, shape, origin, voxel_size, type="carving", default_value=0, labels=None,
@@ -269,6 +270,7 @@ class Backprojection(object):
 
     def _submit_view(self, intrinsics, rot, tvec, mask, invert):
         """``process_view`` plus the fileset loop's optional ``np.invert`` (cl.py:300-301)."""
+        self._values_d = None  # the state is about to change: a cached device address may be a stale snapshot
         self._lut = submit_view(self._engine, self.dtype, self.log, self._lut, intrinsics, rot, tvec,
                                 mask, invert)
         return
@@ -361,9 +363,15 @@ class Backprojection(object):
 
     @property
     def values_d(self):
-        """The reference's ``values_d`` (cl.py:175) is a device buffer; here: the device address ``device_values()``
-        last handed out (``None`` before the first such call).  Reading the attribute does nothing on the device."""
-        return getattr(self, "_values_d", None)
+        """The reference's ``values_d`` (cl.py:175) is a device buffer, valid from ``init_buffers`` on; here: the
+        device address of the volume.  It is fetched by ``device_values()`` when nothing is cached (which launches
+        pending views and, on a padded grid, makes the snapshot) and the cache is dropped by everything that changes
+        the state -- ``clear``, ``process_view`` & co., ``init_buffers`` -- so a read never yields a stale address
+        (ADVICE r04)."""
+        cached = getattr(self, "_values_d", None)
+        if cached is None and getattr(self, "_engine", None) is not None:
+            cached = self.device_values()
+        return cached
 
     def device_values(self):
         """Device address of the volume as ``nx * ny * nz`` contiguous elements in the reference's order: pending
@@ -469,6 +477,7 @@ class Backprojection(object):
         K = np.array([cam["camera_model"]['params'][0:4] for _, cam in selected], dtype=np.float32)  # :293
         R = np.array([sum(cam['rotmat'], []) for _, cam in selected], dtype=np.float32)  # :295
         t = np.array([cam['tvec'] for _, cam in selected], dtype=np.float32)  # :296
+        self._values_d = None
         try:
             self._engine.process_png_views(K, R, t, raws, invert=invert, threads=max(self.decode_workers, 16))
         except ValueError:  # some file is not a grey8 PNG: nothing was enqueued
@@ -481,6 +490,7 @@ class Backprojection(object):
         # may be held by the caller (get_values returned it) and keeps its contents: it is never
         # reused here unless the caller hands it back with ``recycle``.
         self._values_h = None
+        self._values_d = None
         if self._spare is None and self._prefault is None:
             self._start_prefault()
         self._engine.clear()

@@ -11,6 +11,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -196,9 +197,21 @@ struct Pool {
     }
 };
 
+// A fork()ed child inherits the pool object but none of its threads (`started` true, `workers` holding the parent's
+// thread objects, perhaps a locked mutex): work queued there would wait for nobody (ADVICE r04 -- multiprocessing's
+// fork start method, luigi workers).  The child gets a fresh pool, which starts its own threads at its first push;
+// the old object is leaked on purpose (its mutex may be held by a thread that does not exist here).
+std::atomic<Pool *> g_pool{nullptr};
+void pool_after_fork_child() { g_pool.store(new Pool(), std::memory_order_release); }
+
 Pool &pool() {
-    static Pool *p = new Pool();  // never destroyed: worker threads may outlive static destruction order otherwise
-    return *p;
+    static const bool once = [] {
+        g_pool.store(new Pool(), std::memory_order_release);  // never destroyed: worker threads may outlive static destruction order otherwise
+        pthread_atfork(nullptr, nullptr, pool_after_fork_child);
+        return true;
+    }();
+    (void)once;
+    return *g_pool.load(std::memory_order_acquire);
 }
 
 struct Latch {

@@ -40,9 +40,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,6 +54,34 @@
 #include "hostpack.h"
 #include "spacecarve.h"
 #include "spacecarve_tuning.h"
+
+// SC_TRACE_ALLOC=1 in the environment: every allocation of this file reports "sc_alloc <call>:<line> <bytes> <ms>"
+// on stderr (bench.py's cold-process leg reads them: what a first batch pays the driver for memory).  Off: a flag test.
+namespace sctrace {
+inline bool on() {
+    static const bool v = [] { const char *s = getenv("SC_TRACE_ALLOC"); return s && *s && *s != '0'; }();
+    return v;
+}
+template <class F>
+inline hipError_t timed(const char *what, int line, size_t bytes, F &&f) {
+    if (!on()) return f();
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t r = f();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "sc_alloc %s:%d %zu %.3f\n", what, line, bytes, ms);
+    return r;
+}
+template <class T>
+inline hipError_t dev(T **p, size_t bytes, int line) {
+    return timed("hipMalloc", line, bytes, [&] { return (hipMalloc)(reinterpret_cast<void **>(p), bytes); });
+}
+template <class T>
+inline hipError_t host(T **p, size_t bytes, unsigned flags, int line) {
+    return timed("hipHostMalloc", line, bytes, [&] { return (hipHostMalloc)(reinterpret_cast<void **>(p), bytes, flags); });
+}
+}  // namespace sctrace
+#define hipMalloc(p, n) sctrace::dev((p), (n), __LINE__)
+#define hipHostMalloc(p, n, f) sctrace::host((p), (n), (f), __LINE__)
 
 namespace {
 
@@ -1984,6 +2014,10 @@ int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, co
         if (!png[q]) return fail(SC_ERR_INVALID, "null file %d", q);
         if (sc_png_info(png[q], sizes[q], &Ws[(size_t)q], &Hs[(size_t)q]) != SC_OK)
             return fail(SC_ERR_INVALID, "file %d: %s", q, sc_png_last_error());
+        // the limits check_view_args puts on a mask, before a pixel buffer of that size is asked for
+        if (Ws[(size_t)q] <= 0 || Hs[(size_t)q] <= 0 || Ws[(size_t)q] > (1 << 24) || Hs[(size_t)q] > (1 << 24) ||
+            (int64_t)Ws[(size_t)q] * Hs[(size_t)q] > (int64_t)1 << 31)
+            return fail(SC_ERR_INVALID, "file %d: a %d x %d mask is beyond the limits of a view", q, Ws[(size_t)q], Hs[(size_t)q]);
         offs[(size_t)q] = total;
         total += ((size_t)Hs[(size_t)q] * (size_t)((Ws[(size_t)q] + kTile - 1) / kTile) * 4 + 255) & ~(size_t)255;
     }
@@ -2001,28 +2035,45 @@ int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, co
     int nth = threads > 0 ? threads : 16;
     nth = std::min(std::min(nth, V), 64);
     std::atomic<int> next{0}, bad{-1};
+    std::atomic<bool> nomem{false};
     const uint8_t flip = invert ? 255 : 0;
+    // (nothing may leave a thread function or this C entry point as an exception -- std::terminate: the pixel buffer's
+    // allocation and the threads' creation are caught and reported as SC_ERR_NOMEM)
     auto work = [&]() {
-        std::vector<uint8_t> pix;
-        for (;;) {
-            const int q = next.fetch_add(1, std::memory_order_relaxed);
-            if (q >= V || bad.load(std::memory_order_relaxed) >= 0) return;
-            const int W = Ws[(size_t)q], H = Hs[(size_t)q];
-            pix.resize((size_t)W * H);
-            if (sc_png_decode_gray8(png[q], sizes[q], pix.data(), W, H) != SC_OK) {
-                int expect = -1;
-                bad.compare_exchange_strong(expect, q);
-                return;
+        try {
+            std::vector<uint8_t> pix;
+            for (;;) {
+                const int q = next.fetch_add(1, std::memory_order_relaxed);
+                if (q >= V || bad.load(std::memory_order_relaxed) >= 0) return;
+                const int W = Ws[(size_t)q], H = Hs[(size_t)q];
+                pix.resize((size_t)W * H);
+                if (sc_png_decode_gray8(png[q], sizes[q], pix.data(), W, H) != SC_OK) {
+                    int expect = -1;
+                    bad.compare_exchange_strong(expect, q);
+                    return;
+                }
+                schost::pack_rows(pix.data(), W, W, 0, H, reinterpret_cast<uint32_t *>(base + offs[(size_t)q]), (W + kTile - 1) / kTile, 1, flip);
             }
-            schost::pack_rows(pix.data(), W, W, 0, H, reinterpret_cast<uint32_t *>(base + offs[(size_t)q]), (W + kTile - 1) / kTile, 1, flip);
+        } catch (...) {
+            nomem.store(true);
+            int expect = -1;
+            bad.compare_exchange_strong(expect, V);  // stops the others
         }
     };
     {
         std::vector<std::thread> pool;
-        pool.reserve((size_t)nth);
-        for (int i = 1; i < nth; ++i) pool.emplace_back(work);
+        try {
+            pool.reserve((size_t)nth);
+            for (int i = 1; i < nth; ++i) pool.emplace_back(work);
+        } catch (...) {
+            // (fewer threads than asked for: the ones that exist and this one do the work)
+        }
         work();
         for (auto &th : pool) th.join();
+    }
+    if (nomem.load()) {
+        arena.used -= total;
+        return fail(SC_ERR_NOMEM, "out of host memory while decoding the masks");
     }
     if (bad.load() >= 0) {
         arena.used -= total;  // nothing of this call stays

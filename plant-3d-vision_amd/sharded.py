@@ -120,6 +120,10 @@ class ShardedBackprojection:
         if views_per_launch:
             self._engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, int(views_per_launch))
         self._on_gpu = engine_factory is None
+        #: ``all_gather(overlap=True)``: the stream whose collective still reads the engine's packed labels; the
+        #: engine waits for it right before it packs again (``_settle``), not right behind the collective, so the
+        #: collective of batch k runs beside the carve of batch k + 1
+        self._lazy_wait = None
         #: host tensors only (CPU tests of the host logic over gloo): what stands in for ``sc_unpack_labels``
         self._unpack_fn = unpack_fn
 
@@ -148,11 +152,20 @@ class ShardedBackprojection:
     def flush(self):
         self._engine.flush()
 
+    def _settle(self):
+        """The engine's stream waits for a collective that ``all_gather(overlap=True)`` left reading the packed
+        labels (device-side order; the host does not wait).  Called before anything packs or reads back again."""
+        if self._lazy_wait is not None:
+            self._engine.order_after(self._lazy_wait)
+            self._lazy_wait = None
+
     def synchronize(self):
+        self._settle()
         self._engine.synchronize()
 
     def get_local(self):
         """This rank's planes as a host array ``[len(planes), ny, nz]`` (in ``self.planes`` order)."""
+        self._settle()
         return self._engine.get_values()
 
     # -- assembling the grid ----------------------------------------------------------------
@@ -205,10 +218,13 @@ class ShardedBackprojection:
         """Bytes one rank contributes to a packed all-gather (its planes padded to the largest plane count)."""
         return nat.packed_bytes(self._planes_max() * self.shape[1] * self.shape[2], bits)
 
-    def _all_gather_packed(self, bits, widen, recv, out, unpack=True):
+    def _all_gather_packed(self, bits, widen, recv, out, unpack=True, overlap=False):
         """Labels at 2 bits each (or 1: the occupancy ``label == 1`` the consumer binarises to, proc3d.py:515)
         over the wire -- 1/16 (1/32) of the int32 planes: 32 MiB per rank at 1024^3 / 8 -- and ONE kernel
-        (``sc_unpack_labels``) that unpacks and puts the planes in global order, as int8 or, ``widen``, int32."""
+        (``sc_unpack_labels``) that unpacks and puts the planes in global order, as int8 or, ``widen``, int32.
+        ``overlap`` (``unpack=False`` only): the engine's stream is NOT made to wait behind the collective -- it
+        waits right before its next pack instead (``_settle``), so the carve of the next batch runs beside this
+        batch's collective.  The caller hands alternating ``recv`` buffers if it still reads the previous grid."""
         import torch
         import torch.distributed as dist
         if self.dtype != np.int32:
@@ -217,6 +233,9 @@ class ShardedBackprojection:
         rank_bytes = self.packed_rank_bytes(bits)
         tstream = None
         if self._on_gpu:
+            # the batch's kernels first, THEN the wait for the previous collective, then the pack
+            self._engine.flush()
+            self._settle()
             ptr, nbytes = self._engine.values_packed(bits)
             # packed on the engine's stream; the collective and the unpack run on torch's: ordered on the device,
             # nothing waits on the host
@@ -253,7 +272,10 @@ class ShardedBackprojection:
             if single and recv.is_cuda:
                 recv = recv.clone()
             if tstream is not None:
-                self._engine.order_after(tstream)
+                if overlap:
+                    self._lazy_wait = tstream  # the engine waits before its next pack, not here
+                else:
+                    self._engine.order_after(tstream)
             return PackedGrid(recv, rank_bytes, W, self.partition, self.shape, bits, self.device)
         if recv.is_cuda:
             nat.unpack_labels(self.device, torch.cuda.current_stream(recv.device).cuda_stream, recv.data_ptr(), rank_bytes, W,
@@ -267,7 +289,7 @@ class ShardedBackprojection:
                                                             np.int32 if widen else np.int8).reshape(-1))
         return out[:n_out].view(self.shape)
 
-    def all_gather(self, compress=False, widen=True, recv=None, out=None, unpack=True):
+    def all_gather(self, compress=False, widen=True, recv=None, out=None, unpack=True, overlap=False):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
 
         compress=True sends carve labels as int8 (labels are in {-1, 0, 1} when default_value
@@ -282,13 +304,21 @@ class ShardedBackprojection:
         unpack=False (packed forms only): no grid is written at all -- the result is a ``PackedGrid`` (the ranks'
         packed planes on this device), which ``proc3d.vol2pcd`` consumes as it is and ``.unpack()`` turns into the
         grid on demand.
+        overlap=True (with unpack=False): a pipeline of batches -- the collective of this batch runs beside the
+        carve of the next one; the engine waits for it only before it packs again.
         """
         import torch
         import torch.distributed as dist
+        if overlap and (unpack or compress not in ("2bit", "1bit")):
+            raise ValueError("overlap=True is for the packed forms left packed (compress='2bit' / '1bit', unpack=False)")
         if compress in ("2bit", "1bit"):
-            return self._all_gather_packed(2 if compress == "2bit" else 1, widen, recv, out, unpack)
+            if not unpack and not self._on_gpu:
+                # (ADVICE r04: a PackedGrid is a device object -- unpack() and vol2pcd read it with HIP kernels)
+                raise ValueError("unpack=False needs the HIP engine: a PackedGrid lives on the device")
+            return self._all_gather_packed(2 if compress == "2bit" else 1, widen, recv, out, unpack, overlap)
         if not unpack:
             raise ValueError("unpack=False is for the packed forms (compress='2bit' / '1bit')")
+        self._settle()
         local = self._slab_tensor()
         if compress:
             if self.dtype != np.int32:
@@ -323,6 +353,7 @@ class ShardedBackprojection:
         star's wording).  Exact: every voxel is non-zero on exactly one rank."""
         import torch
         import torch.distributed as dist
+        self._settle()
         local = self._slab_tensor()
         full = torch.zeros((self.shape[0], self.shape[1], self.shape[2]), dtype=local.dtype,
                            device=local.device)
@@ -350,6 +381,7 @@ class ShardedBackprojection:
         takes 512^3 labels in ~4 ms, a fresh ``np.empty`` ~30 (first-touch page faults, not the transfer)."""
         import torch
         import torch.distributed as dist
+        self._settle()
         two_bit = (self.dtype == np.int32 and float(self.default_value) in (-1.0, 0.0, 1.0)
                    and compress in (None, "2bit") and hasattr(self._engine, "get_values_packed"))
         if compress == "2bit" and not two_bit:
@@ -423,5 +455,6 @@ class ShardedBackprojection:
 
     def close(self):
         if self._engine is not None:
+            self._settle()
             self._engine.close()
             self._engine = None

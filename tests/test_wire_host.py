@@ -99,3 +99,34 @@ def test_ranks_packed_planes_widen_into_one_grid_in_global_order(world, shape, p
         buf[r * rank_bytes // 4: r * rank_bytes // 4 + w.size] = w
     got = nat.widen_labels2_ranks(buf, rank_bytes, world, partition, shape)
     assert got.dtype == np.int32 and np.array_equal(got, grid)
+
+
+def test_host_pool_works_in_a_forked_child():
+    """A fork()ed child inherits the pool object without its threads (multiprocessing's fork start
+    method, luigi workers): the host-only entry points must still finish there -- a fresh pool after the fork."""
+    import os
+    import signal
+    n = 3 * 262144 * 16 + 7
+    rng = np.random.default_rng(11)
+    labels = rng.integers(-1, 2, size=n).astype(np.int32)
+    packed = pack_labels_np(labels, 2)
+    big = rng.integers(0, 256, (1080, 1440), dtype=np.uint8)
+    want_bits = nat.hostpack_bits(big, nat.SC_MASK_U8)          # the parent's pool has started its threads
+    assert np.array_equal(nat.widen_labels2(packed, n, threads=8), labels)
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # the child: no pytest machinery from here on
+        code = 1
+        try:
+            signal.alarm(60)  # a hang is a failure, not a stuck test run
+            ok = np.array_equal(nat.widen_labels2(packed, n, threads=8), labels)
+            ok = ok and np.array_equal(nat.hostpack_bits(big, nat.SC_MASK_U8), want_bits)
+            os.write(w, b"1" if ok else b"0")
+            code = 0 if ok else 2
+        finally:
+            os._exit(code)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    assert os.read(r, 1) == b"1" and os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    os.close(r)
+    assert np.array_equal(nat.widen_labels2(packed, n, threads=8), labels)  # the parent's pool is untouched
