@@ -3,9 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts
-``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` on itself as a
-fresh child BEFORE it makes any GPU call, relays rank 0's JSON line and exits with the child's code.  Under
+N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts its N ranks itself (this script
+again, with the environment ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would give them) as
+fresh children BEFORE it makes any GPU call, relays rank 0's JSON line and exits with their code.  Under
 torch.distributed.run (the driver's N > 1 command) it is a rank as before.
 
 A "step" is one pass of the hot path over one batch of synthetic input: clear the grid, take
@@ -306,7 +306,7 @@ def traffic_passes(a):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1",
                    "--cpu-seconds", "0", "--extra-steps", "0", "--e2e-reps", "0", "--skip-other-path", "--cold-reps", "0",
-                   "--traffic-passes", "off", "--n", str(a.n), "--views", str(a.views), "--scene", a.scene,
+                   "--traffic-passes", "off", "--parity-check", "off", "--cold-process", "off", "--n", str(a.n), "--views", str(a.views), "--scene", a.scene,
                    "--scene-cache", a.scene_cache]
             env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             r = subprocess.run(cmd, cwd=env["TMPDIR"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
@@ -678,29 +678,43 @@ def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, wor
 
 
 def self_launch(a):
-    """`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as fresh child processes --
-    `python -m torch.distributed.run` on this script -- BEFORE this process makes any GPU call (it never makes one),
-    relay rank 0's JSON line on stdout and return the child's exit code."""
+    """`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as fresh child processes of
+    this script -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would set -- BEFORE this process makes any GPU
+    call (it never makes one), relay rank 0's JSON line on stdout and return the first non-zero exit code."""
     import socket
     import subprocess
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)  # stderr goes straight through
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # rank 0's stdout carries the line; the other ranks print nothing there (their stdout joins stderr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120 if codes[0] == 0 else 10))
+        except subprocess.TimeoutExpired:
+            p.kill()  # (its own pid: a rank left behind by a failed rank 0)
+            codes.append(p.wait())
     line = None
-    for ln in r.stdout.decode(errors="replace").splitlines():
+    for ln in out0.decode(errors="replace").splitlines():
         ln = ln.strip()
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
     if line is not None:
         sys.stdout.write(line + "\n")
         sys.stdout.flush()
-    if r.returncode != 0:
-        return r.returncode
+    bad = [c for c in codes if c != 0]
+    if bad:
+        return bad[0] if bad[0] > 0 else 1
     return 0 if line is not None else 1
 
 
@@ -720,7 +734,15 @@ def cold_child(a):
     stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
     K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); tt = np.stack([v[2] for v in views])
     t.append(time.perf_counter())  # scene from the cache
-    eng = nat.Engine(list(gshape), origin, vs, nat.SC_MODE_CARVE, device=0)  # the process's first HIP calls are in here
+    # the process's first HIP calls: runtime and device initialisation, the context (what ANY use of the GPU pays once)
+    import ctypes
+    hip = nat.hip_runtime()
+    hip.hipInit(0)
+    hip.hipSetDevice(0)
+    hip.hipFree(ctypes.c_void_p(0))
+    hip.hipDeviceSynchronize()
+    t.append(time.perf_counter())
+    eng = nat.Engine(list(gshape), origin, vs, nat.SC_MODE_CARVE, device=0)
     t.append(time.perf_counter())
     masks_dev = eng.dev_alloc(stack.nbytes)
     eng.dev_upload(masks_dev, stack)
@@ -739,8 +761,8 @@ def cold_child(a):
     eng.dev_free(masks_dev)
     eng.close()
     ms = [(b - a_) * 1e3 for a_, b in zip(t[:-1], t[1:])]
-    out = {"import_ms": ms[0], "scene_ms": ms[1], "create_ms": ms[2], "mask_upload_ms": ms[3], "enqueue_ms": ms[4],
-           "wait_ms": ms[5], "second_batch_ms": ms[6], "first_batch_ms": ms[2] + ms[4] + ms[5]}
+    out = {"import_ms": ms[0], "scene_ms": ms[1], "hip_runtime_init_ms": ms[2], "create_ms": ms[3], "mask_upload_ms": ms[4],
+           "enqueue_ms": ms[5], "wait_ms": ms[6], "second_batch_ms": ms[7], "first_batch_ms": ms[3] + ms[5] + ms[6]}
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
 
@@ -774,10 +796,10 @@ def cold_process(a):
     out["allocations_over_1ms"] = [x for x in allocs if x["ms"] >= 1.0]
     out["allocations"] = len(allocs)
     out["note"] = ("a fresh process, started before the bench process touched the GPU, once (no best-of): import_ms = "
-                   "binding + libspacecarve.so; create_ms = sc_create, the process's FIRST HIP calls (runtime and device "
-                   "initialisation, the code object's load, the label volume, a stream); mask_upload_ms = 112 MB of "
+                   "binding + libspacecarve.so; hip_runtime_init_ms = hipInit + the device's context (any use of the GPU pays "
+                   "it once per process); create_ms = sc_create (the code object's load, the label volume, a stream); mask_upload_ms = 112 MB of "
                    "masks to HBM (the ingest stand-in, not the batch); enqueue_ms = the batch's launches with the engine's "
-                   "one-off allocations between them; wait_ms = what was left of the device work; first_batch_ms = create + "
+                   "one-off allocations between them and each kernel's first-launch set-up in the runtime; wait_ms = what was left of the device work; first_batch_ms = create + "
                    "enqueue + wait; allocations* = the library's own hipMalloc / hipHostMalloc calls (SC_TRACE_ALLOC)")
     return out
 

@@ -194,12 +194,28 @@ class _CffiBackend:
 _backend = None
 
 
+_hip_runtime = None
+
+
+def hip_runtime():
+    """The HIP runtime this process uses, as a ``ctypes.CDLL`` (the one ``_preload_hip_runtime`` chose, else the one
+    libspacecarve.so brought in): for diagnostics that time the runtime's own initialisation (bench.py's cold-process leg)."""
+    backend()
+    if _hip_runtime is not None:
+        return _hip_runtime
+    if "torch" in sys.modules:
+        import torch
+        return ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
+    return ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+
+
 def _preload_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm ships its own ``libamdhip64.so`` (same SONAME as
     /opt/rocm's); whichever is loaded first serves everybody, and torch fails if that is not its
     own.  So when torch is installed but not imported yet, load ITS runtime before our library:
     device pointers, streams and RCCL then work across torch and the engine in either import
     order.  Without torch the system ROCm runtime is used."""
+    global _hip_runtime
     if "torch" in sys.modules:
         return
     try:
@@ -211,7 +227,7 @@ def _preload_hip_runtime():
     lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.exists(lib):
         try:
-            ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
+            _hip_runtime = ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass
 
