@@ -346,6 +346,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
         else if (pack_rows == 2) pack16_block<2>(ride, b);
         else if (pack_rows == 8) pack16_block<8>(ride, b);
         else pack16_block<4>(ride, b);
+#ifdef SC_TRACE_DENSE
+        if (threadIdx.x == 0) {  // when the last rider ended (row 8191: min start, max end, count)
+            atomicMax(&g_dense_trace[8191 * 8 + 1], (uint32_t)wall_clock64());
+            atomicAdd(&g_dense_trace[8191 * 8 + 2], 1u);
+        }
+#endif
         return;
     }
     if (blockIdx.x >= nwalkers) {

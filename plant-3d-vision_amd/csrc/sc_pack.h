@@ -182,6 +182,22 @@ __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
 
 __global__ __launch_bounds__(kBlock) void pack_band_kernel(PackJob pj) { pack_band_block(pj, blockIdx.x); }
 
+// The same with `nfill` persistent fill blocks in front that set the first `bytes` of a FRESH label volume to -1 (see
+// SpecFill in sc_verdicts.h: labels that are written again by a later kernel of the batch wherever their brick is not
+// EMPTY).  The kernel that packs the first ten masks of a batch reads 15 MB and leaves HBM idle: round 5 gives it a
+// share of the fill that waits for nobody.
+__global__ __launch_bounds__(kBlock) void pack_band_fill_kernel(PackJob pj, int32_t *labels, uint64_t bytes, uint32_t nfill) {
+    if (blockIdx.x < nfill) {  // block-uniform
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i minus = {-1, -1, -1, -1};
+        char *base = reinterpret_cast<char *>(labels);
+        for (uint64_t off = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u; off < bytes; off += (uint64_t)nfill * (kBlock * 16))
+            __builtin_nontemporal_store(minus, reinterpret_cast<v4i *>(base + off));
+        return;
+    }
+    pack_band_block(pj, blockIdx.x - nfill);
+}
+
 // Masks that arrive from the HOST cross PCIe as bits already (hostpack.h: `pixel != 0` after the optional invert, on
 // host threads, row-major, one word per 32 pixels, 0 beyond the picture).  What is left for the device is a pass over
 // those bits: the words into the 32x32-tile order the carve kernels gather from, and per tile its occupancy byte and

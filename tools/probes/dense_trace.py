@@ -52,7 +52,9 @@ def main():
     order = np.argsort(t1)[-5:]
     out["last_finishers"] = [{"bricks": int(w[i, 2]), "units": int(w[i, 3]), "start": round((t0[i] - base) * 0.01, 2),
                               "end": round((t1[i] - base) * 0.01, 2)} for i in order]
-    u = tr_all[4096:8192]
+    if tr_all[8191, 2]:
+        out["riders"] = {"blocks": int(tr_all[8191, 2]), "last_end_us": round((int(tr_all[8191, 1]) - int(base)) * 0.01, 2)}
+    u = tr_all[4096:8191]
     u = u[u[:, 1] != 0]
     if len(u):
         t0 = u[:, 0].astype(np.int64); t1 = u[:, 1].astype(np.int64)
