@@ -97,9 +97,6 @@
                                      persistent fill blocks in front of the flags kernel's own (fresh volumes only: every
                                      brick that is not EMPTY is written again by a later kernel of the batch); 0: none  */
 #define SC_OPT_SPEC_BLOCKS 46     /* ... that many blocks of 512 threads (64)                                             */
-#define SC_OPT_SPEC_PACK_SHARE 47 /* 64ths of the strips (5), IN FRONT of the share above, set to -1 even earlier: by fill
-                                     blocks inside the kernel that packs the first masks of a device batch (band form),
-                                     which leaves HBM idle -- 42 MB at 512^3 ride along for a microsecond; 0: none    */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

@@ -346,12 +346,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
         else if (pack_rows == 2) pack16_block<2>(ride, b);
         else if (pack_rows == 8) pack16_block<8>(ride, b);
         else pack16_block<4>(ride, b);
-#ifdef SC_TRACE_DENSE
-        if (threadIdx.x == 0) {  // when the last rider ended (row 8191: min start, max end, count)
-            atomicMax(&g_dense_trace[8191 * 8 + 1], (uint32_t)wall_clock64());
-            atomicAdd(&g_dense_trace[8191 * 8 + 2], 1u);
-        }
-#endif
         return;
     }
     if (blockIdx.x >= nwalkers) {
@@ -366,23 +360,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
     // the brick is live because a 32x32 tile under it touches the plant, the unit lies beside it -- and projects the
     // others.  (A block of four wavefronts per brick, one unit each, left three in four idle once units are culled;
     // tickets keep every wavefront busy whatever the bricks hold.)
-    //
-    // Round 5: the units a verdict round leaves are SHARED by the block's wavefronts through a pool in LDS.  A ticket
-    // is a brick, and a brick was a verdict round plus 0 to 4 units of ~3.6 us each in ONE wavefront: 4 096 walker
-    // wavefronts were busy 17.8 us on average on a plant and the last one ended at 30.6 -- the wavefronts that drew a
-    // brick with four surviving units last defined the kernel.  Now the wavefront that asked keeps the first surviving
-    // unit and puts the others into the pool; a wavefront looks into the pool before it draws a ticket, and one that
-    // finds neither stays while a wavefront of its block is still inside a verdict round (s_busy).  Every unit is
-    // projected by exactly one wavefront, as before; which one changes nothing (one owner per voxel, appends are
-    // atomic reservations).  Nothing waits on another block, and a wavefront that pushes goes back to the pool itself,
-    // so the pool drains whatever the others do: the exit condition (no ticket, empty pool, nobody asking) is reached
-    // by every wavefront.
-    constexpr uint32_t kPoolSlots = 32;  // (at most 12 entries are ever pending: a wavefront pushes <= 3, and only after it found the pool empty)
-    __shared__ uint32_t s_pool[3][kPoolSlots];  // [0]: brick * 4 + unit, ~0 = empty slot; [1]: plane; [2]: by << 8 | bz
-    __shared__ uint32_t s_head, s_tail, s_busy;
-    if (threadIdx.x < kPoolSlots) s_pool[0][threadIdx.x] = 0xffffffffu;
-    if (threadIdx.x == 0) { s_head = 0u; s_tail = 0u; s_busy = 0u; }
-    __syncthreads();
     const uint32_t nlive = ctl->nlive[parity];
     // masks whose tiles settled less than half of the bricks (noise: none) have no structure for the cells to find
     const int nverd = nlive <= verd_max_live ? nverd_arg : 0;
@@ -396,67 +373,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
     // (the first ticket of a wavefront is its own number among the XCD's: a thousand atomics on one address at the
     // kernel's start would take longer than the first bricks)
     const uint32_t per_xcd = (nwalkers >> 3) * (kBlock / 64);
-    bool first = true, tickets = true;
+    bool first = true;
     uint32_t misses = 0, turn = 0;
 #ifdef SC_TRACE_DENSE
     const uint64_t tr0 = wall_clock64();
     uint32_t tr_bricks = 0, tr_units = 0, tr_verd = 0, tr_unit = 0, tr_tick = 0;
 #endif
-    // one unit: lane = column * 4 + group of 4 voxels -- a square patch of the plane, the UNIT the bulk list speaks of (see Append)
-    auto project_unit = [&](uint32_t lb, uint32_t u, uint32_t il, uint32_t by, uint32_t bz) {
-        const uint32_t j = by * kBrickY + (lane >> 2);
-        const uint32_t k0 = bz * kBrickZ + u * 16u + (lane & 3u) * 4u;
-        brick_voxels<FRESH, ALL_SAFE>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u, nextra);
-#ifdef SC_TRACE_DENSE
-        ++tr_units;
-#endif
-    };
     for (;;) {
-        // (a) a unit another wavefront of this block left in the pool?
-        uint32_t ent = 0xffffffffu, pil = 0u, pyz = 0u;
-        if (lane == 0) {
-            for (;;) {
-                const uint32_t h = __hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t t = __hip_atomic_load(&s_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (h == t) break;
-                if (atomicCAS(&s_head, h, h + 1u) != h) continue;
-                const uint32_t slot = h & (kPoolSlots - 1u);
-                // (the place is reserved before it is written: wait for the entry itself)
-                while ((ent = __hip_atomic_load(&s_pool[0][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0xffffffffu)
-                    __builtin_amdgcn_s_sleep(1);
-                pil = __hip_atomic_load(&s_pool[1][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pyz = __hip_atomic_load(&s_pool[2][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_pool[0][slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-            }
-        }
-        ent = __builtin_amdgcn_readfirstlane(ent);
-        if (ent != 0xffffffffu) {
-            pil = __builtin_amdgcn_readfirstlane(pil);
-            pyz = __builtin_amdgcn_readfirstlane(pyz);
-#ifdef SC_TRACE_DENSE
-            const uint64_t trc = wall_clock64();
-#endif
-            project_unit(ent >> 2, ent & 3u, pil, pyz >> 8, pyz & 0xffu);
-#ifdef SC_TRACE_DENSE
-            tr_unit += (uint32_t)(wall_clock64() - trc);
-#endif
-            continue;
-        }
-        if (!tickets) {
-            // (c) no ticket left for this wavefront and nothing in the pool: gone, unless a wavefront of the block is
-            // inside a verdict round and may still push (it drains the pool itself if everybody else has left)
-            uint32_t busy = 0u;
-            if (lane == 0) busy = __hip_atomic_load(&s_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane(busy) == 0u) break;
-            __builtin_amdgcn_s_sleep(8);
-            continue;
-        }
-        // (b) the next brick
 #ifdef SC_TRACE_DENSE
         const uint64_t tra = wall_clock64();
 #endif
-        if (lane == 0) atomicAdd(&s_busy, 1u);
         uint32_t t = (blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
         if (!first) {
             // eight counters per XCD, each dealing every eighth run of the XCD's entries to the wavefronts whose
@@ -475,15 +401,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
         first = false;
         t = __builtin_amdgcn_readfirstlane(t);
         const uint32_t entry = ((t / kXcdRun) * 8u + xcd) * kXcdRun + (t % kXcdRun);
-        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) {  // past the last run for every XCD
-            tickets = false;
-            if (lane == 0) atomicSub(&s_busy, 1u);
-            continue;
-        }
-        if (entry >= nlive) {
-            if (lane == 0) atomicSub(&s_busy, 1u);
-            continue;
-        }
+        if ((t / kXcdRun) * 8u * kXcdRun >= nlive) break;  // past the last run for every XCD
+        if (entry >= nlive) continue;
         const uint32_t lb = __builtin_amdgcn_readfirstlane(live[entry]);
         const uint32_t il = lb / per_plane;
         const uint32_t rem = lb - il * per_plane;
@@ -516,35 +435,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(102))) void 
         const uint64_t trc = wall_clock64();
         tr_verd += (uint32_t)(trc - trb);
 #endif
-        // the units left: the first is this wavefront's, the others go into the pool
-        const uint32_t left = ~culled & 0xfu;
-        const uint32_t mine = left ? (uint32_t)__builtin_ctz(left) : 4u;
-        const uint32_t others = left & (left - 1u);
-        if (lane == 0) {
-            if (others != 0u) {
-                const uint32_t n = (uint32_t)__builtin_popcount(others);
-                uint32_t pos = atomicAdd(&s_tail, n);
-                for (uint32_t m = others; m != 0u; m &= m - 1u, ++pos) {
-                    const uint32_t slot = pos & (kPoolSlots - 1u);
-                    __hip_atomic_store(&s_pool[1][slot], il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&s_pool[2][slot], (by << 8) | bz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    // (LDS operations of one wavefront are performed in order: the entry word last)
-                    __hip_atomic_store(&s_pool[0][slot], lb * 4u + (uint32_t)__builtin_ctz(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            atomicSub(&s_busy, 1u);
-        }
-        // the units some view carves whole: no projection, one store per lane
-        {
-            const uint32_t j = by * kBrickY + (lane >> 2);
-            for (uint32_t u = 0; u < 4u; ++u) {
-                if (!((culled >> u) & 1u)) continue;
-                const uint32_t k0 = bz * kBrickZ + u * 16u + (lane & 3u) * 4u;
+        // lane = column * 4 + group of 4 voxels: a square patch of the plane, the UNIT the bulk list speaks of (see Append)
+        const uint32_t j = by * kBrickY + (lane >> 2);
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t k0 = bz * kBrickZ + u * 16u + (lane & 3u) * 4u;
+            if ((culled >> u) & 1u) {
                 if (j < g.ny && k0 < g.nz)
                     *reinterpret_cast<int4 *>(labels + ((uint64_t)il * g.ny + j) * g.nzp + k0) = make_int4(-1, -1, -1, -1);
+                continue;
             }
+            brick_voxels<FRESH, ALL_SAFE>(labels, g, views, nviews, init, ap, il, j, k0, lb, lane, u, nextra);
+#ifdef SC_TRACE_DENSE
+            ++tr_units;
+#endif
         }
-        if (mine < 4u) project_unit(lb, mine, il, by, bz);
 #ifdef SC_TRACE_DENSE
         tr_unit += (uint32_t)(wall_clock64() - trc);
 #endif

@@ -12,6 +12,23 @@ __device__ __forceinline__ uint32_t nonzero_nibble(uint32_t w) {
     return (t * 0x00204081u) >> 28;  // gathers bits 7,15,23,31 into a nibble (no carries collide)
 }
 
+// 16 pixels (bytes) -> 16 bits, bit j = (pixel j != 0).  Round 5: bit 7 of every non-zero byte by the carry trick as
+// above (and, add, one three-input v_bitop3), then the four flags of a dword are gathered -- and put at their place
+// in the 16 bits -- by ONE v_dot4_u32_u8 with the weights 1 2 4 8 (or 16 .. 128), accumulating: 0x80 w = 128 w per
+// flag, so the sum of a pair of dwords is 128 x their byte.  18 vector instructions for 16 pixels; the form above is
+// 27, four of them v_mul_lo_u32, which issue at a quarter of the rate (tools/probes/valu_probe.hip).  The packers are
+// half of the dense stage's vector instructions (the riders: 62 views of a batch of 72), and that stage is bound by
+// what it issues.
+__device__ __forceinline__ uint32_t nonzero_bits16(uint4 q) {
+    const uint32_t t0 = (q.x | ((q.x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    const uint32_t t1 = (q.y | ((q.y & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    const uint32_t t2 = (q.z | ((q.z & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    const uint32_t t3 = (q.w | ((q.w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    const uint32_t lo = __builtin_amdgcn_udot4(t1, 0x80402010u, __builtin_amdgcn_udot4(t0, 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(t3, 0x80402010u, __builtin_amdgcn_udot4(t2, 0x08040201u, 0u, false), false);
+    return ((hi << 8) + lo) >> 7;  // lo, hi: 128 x a byte
+}
+
 // (Measured: 44-50 us for 72 masks of 1440x1080 whatever ROWS is, and the same for a band form
 // reading whole rows contiguously.  tools/probes/read_probe.hip: a plain read of those 112 MB
 // takes 41 us when they come from HBM -- every step writes 0.5 GB of labels in between, so they
@@ -68,8 +85,7 @@ __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         int ty = by * ROWS + k;
-        uint32_t half = nonzero_nibble(q[k].x ^ flip) | (nonzero_nibble(q[k].y ^ flip) << 4) |
-                        (nonzero_nibble(q[k].z ^ flip) << 8) | (nonzero_nibble(q[k].w ^ flip) << 12);
+        uint32_t half = nonzero_bits16(make_uint4(q[k].x ^ flip, q[k].y ^ flip, q[k].z ^ flip, q[k].w ^ flip));
         uint32_t other = __shfl_xor(half, 1);
         uint32_t word = half | (other << 16);
         if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
@@ -120,7 +136,6 @@ constexpr int kBandPhase = 6;    // 16-byte loads in flight per lane (3, 4, 6, 1
 
 __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
     __shared__ alignas(16) uint32_t band_s[kBandTiles * 32];  // the band's tile words, as they lie in the packed arena
-    __shared__ uint32_t cmb_s[kBandTiles];        // per tile: cells with some foreground | with some background << 16
     const int W = pj.W, H = pj.H, tiles_x = pj.tiles_x, tiles_y = pj.tiles_y;
     const uint32_t flip = pj.flip;
     const uint32_t tid = threadIdx.x;
@@ -129,74 +144,74 @@ __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
     if (slot >= pj.nslots) return;  // block-uniform
     slot += pj.slot0;
     const int64_t view = pj.use_order ? (int64_t)pj.order[slot] : (int64_t)slot;
-    const uint8_t *raw = pj.raw + view * pj.view_stride + (int64_t)ty * 32 * pj.row_stride;
-    const int cpr = W >> 4;                    // 16-pixel chunks per row (W % 16 == 0)
+    // the band's first byte (block-uniform: a scalar base) and 32-bit offsets from it: 32 rows of a picture are below
+    // 2^31 bytes (check_pack_job: row_stride < 2^26)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(1))) uint4 *gq_t;  // (global loads: scalar base + 32-bit lane offset)
+#else
+    typedef const uint4 *gq_t;
+#endif
+    const char *raw = reinterpret_cast<const char *>(pj.raw) + view * pj.view_stride + (int64_t)ty * 32 * pj.row_stride;
+    const uint32_t stride = (uint32_t)pj.row_stride;
+    const uint32_t cpr = (uint32_t)(W >> 4);       // 16-pixel chunks per row (W % 16 == 0)
     const uint32_t cprp = 2u * (uint32_t)tiles_x;  // ... rounded up to an even number
     const uint32_t ntasks = 32u * cprp;
-    const int rows_here = min(32, H - ty * 32);
-    if (tid < (uint32_t)tiles_x) cmb_s[tid] = 0u;
+    const uint32_t rows_here = (uint32_t)min(32, H - ty * 32);
     // task q = tid + 256 i: row q / cprp, chunk q % cprp, stepped without a division
     uint32_t row = tid / cprp, c = tid - row * cprp;
     const uint32_t drow = (uint32_t)kBlock / cprp, dc = (uint32_t)kBlock - drow * cprp;
-    bool synced = false;
     for (uint32_t base = 0; base < ntasks; base += (uint32_t)kBlock * kBandPhase) {
         uint4 q[kBandPhase];
-        uint32_t rr[kBandPhase], cc[kBandPhase];
+        uint32_t dst[kBandPhase];  // where the task's word goes in band_s (0xffffffff: nowhere)
 #pragma unroll
         for (int i = 0; i < kBandPhase; ++i) {
-            rr[i] = row; cc[i] = c;
+            // (tasks past the band's end belong to nobody; the odd chunk of a pair hands its half to the even one)
+            dst[i] = (row < 32u && (c & 1u) == 0u) ? (c >> 1) * 32u + row : 0xffffffffu;
             q[i] = make_uint4(flip, flip, flip, flip);  // padding stays background after the flip
-            if ((int)row < rows_here && (int)c < cpr)
-                q[i] = *reinterpret_cast<const uint4 *>(raw + (int64_t)row * pj.row_stride + (int64_t)c * 16);
+            if (row < rows_here && c < cpr) q[i] = *(gq_t)(uintptr_t)(raw + (row * stride + c * 16u));
             row += drow; c += dc;
             if (c >= cprp) { c -= cprp; ++row; }
         }
-        if (!synced) { __syncthreads(); synced = true; }  // cmb_s is zero for everybody (block-uniform branch)
 #pragma unroll
         for (int i = 0; i < kBandPhase; ++i) {
-            const uint32_t half = nonzero_nibble(q[i].x ^ flip) | (nonzero_nibble(q[i].y ^ flip) << 4) |
-                                  (nonzero_nibble(q[i].z ^ flip) << 8) | (nonzero_nibble(q[i].w ^ flip) << 12);
+            if (flip) q[i] = make_uint4(q[i].x ^ flip, q[i].y ^ flip, q[i].z ^ flip, q[i].w ^ flip);  // (block-uniform)
+            const uint32_t half = nonzero_bits16(q[i]);
             const uint32_t other = __shfl_xor(half, 1);  // the task next door: same row, the tile's other half
-            if (rr[i] < 32u) {                           // (tasks past the band's end belong to nobody)
-                if ((cc[i] & 1u) == 0u) band_s[(cc[i] >> 1) * 32u + rr[i]] = half | (other << 16);
-                // the task's 16 pixels are two 8-pixel cells of cell row rr >> 3
-                const uint32_t fa = (half & 0xffu) != 0u, fb = (half >> 8) != 0u;
-                const uint32_t ha = (half & 0xffu) != 0xffu, hb = (half >> 8) != 0xffu;  // padding: background
-                const uint32_t bit = (rr[i] >> 3) * 4u + (cc[i] & 1u) * 2u;
-                atomicOr(&cmb_s[cc[i] >> 1], ((fa | (fb << 1)) << bit) | ((ha | (hb << 1)) << (16u + bit)));
-            }
+            if (dst[i] != 0xffffffffu) band_s[dst[i]] = half | (other << 16);
         }
     }
     __syncthreads();
     // the band's tiles: tiles_x * 32 words in a row in the packed arena
-    uint4 *dst = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * tiles_x * 32);
+    uint4 *out = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * tiles_x * 32);
     const uint4 *src = reinterpret_cast<const uint4 *>(band_s);
-    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) dst[i] = src[i];
-    if (tid < (uint32_t)tiles_x) {
-        const uint32_t cm = cmb_s[tid];
-        const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + tid;
-        pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
-        if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) out[i] = src[i];
+    // The 8x8-pixel cells from the finished words (round 5; until then every task worked out its two cells' flags and
+    // sent them to LDS atomics: a third of the packer's instructions): thread 4 t + cy takes cell row cy of tile t --
+    // the OR and the AND of its eight words, a byte of them per cell -- and the four threads of a tile join their
+    // nibbles.  Padding is background (zero bits): a tile over the picture's edge is never FULL.
+    for (uint32_t t4 = tid; t4 < (uint32_t)tiles_x * 4u; t4 += kBlock) {  // (kBandTiles * 4 == kBlock: one turn)
+        const uint32_t t = t4 >> 2, cy = t4 & 3u;
+        const uint4 a = src[t * 8u + cy * 2u], bq = src[t * 8u + cy * 2u + 1u];
+        const uint32_t any = (a.x | a.y) | (a.z | a.w) | (bq.x | bq.y) | (bq.z | bq.w);
+        const uint32_t all = (a.x & a.y) & (a.z & a.w) & (bq.x & bq.y) & (bq.z & bq.w);
+        uint32_t f = 0u, g = 0u;
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) {
+            f |= (((any >> (8 * cx)) & 0xffu) != 0u ? 1u : 0u) << cx;
+            g |= (((all >> (8 * cx)) & 0xffu) != 0xffu ? 1u : 0u) << cx;
+        }
+        uint32_t cm = (f << (4u * cy)) | (g << (16u + 4u * cy));
+        cm |= __shfl_xor(cm, 1);
+        cm |= __shfl_xor(cm, 2);
+        if (cy == 0u) {
+            const int64_t tile = (int64_t)slot * tiles_x * tiles_y + (int64_t)ty * tiles_x + t;
+            pj.occ[tile] = ((cm & 0xffffu) ? 1 : 0) | ((cm >> 16) ? 0 : 2);
+            if (pj.cmask != nullptr) pj.cmask[tile] = cm;
+        }
     }
 }
 
 __global__ __launch_bounds__(kBlock) void pack_band_kernel(PackJob pj) { pack_band_block(pj, blockIdx.x); }
-
-// The same with `nfill` persistent fill blocks in front that set the first `bytes` of a FRESH label volume to -1 (see
-// SpecFill in sc_verdicts.h: labels that are written again by a later kernel of the batch wherever their brick is not
-// EMPTY).  The kernel that packs the first ten masks of a batch reads 15 MB and leaves HBM idle: round 5 gives it a
-// share of the fill that waits for nobody.
-__global__ __launch_bounds__(kBlock) void pack_band_fill_kernel(PackJob pj, int32_t *labels, uint64_t bytes, uint32_t nfill) {
-    if (blockIdx.x < nfill) {  // block-uniform
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i minus = {-1, -1, -1, -1};
-        char *base = reinterpret_cast<char *>(labels);
-        for (uint64_t off = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u; off < bytes; off += (uint64_t)nfill * (kBlock * 16))
-            __builtin_nontemporal_store(minus, reinterpret_cast<v4i *>(base + off));
-        return;
-    }
-    pack_band_block(pj, blockIdx.x - nfill);
-}
 
 // Masks that arrive from the HOST cross PCIe as bits already (hostpack.h: `pixel != 0` after the optional invert, on
 // host threads, row-major, one word per 32 pixels, 0 beyond the picture).  What is left for the device is a pass over

@@ -231,7 +231,6 @@ struct sc_engine {
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
     int64_t spec_share = 3;    // sixteenths of the strips set to -1 by fill blocks in front of the flags kernel (fresh volumes)
-    int64_t spec_pack_share = 5;  // 64ths of the strips, in front of those, filled inside the kernel that packs a device batch's first masks
     int64_t spec_blocks = 64;  // ... that many persistent blocks of 512 threads (64: a fill that does not saturate HBM leaves the verdicts their memory round trips; 128 measured 2 % slower per batch, 48 too)
     int64_t dense_extra = 1;   // a unit the dense views thinned out to 32 .. 128 voxels takes one more pair of views there
     int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
@@ -548,8 +547,10 @@ PackJob make_pack_job(const void *raw_dev, int64_t row_stride, int64_t view_stri
 int pack_form(const sc_engine *e, const PackJob &pj) {
     // (narrow pictures make bands of a few hundred tasks, less than a block's worth: 128-pixel pictures took 61 us
     // in bands against 24 in panels)
-    if (e->pack_rows == 0 && pj.tiles_x >= 16 && pj.tiles_x <= kBandTiles) return 0;
-    if (e->pack_rows == 3 && pj.tiles_x <= kBandTiles) return 0;  // bands whatever the width (tests)
+    // (the band form addresses a band's bytes by 32-bit offsets from its first one: 32 rows below 2^31 bytes)
+    const bool band_ok = pj.tiles_x <= kBandTiles && pj.row_stride < ((int64_t)1 << 26);
+    if (e->pack_rows == 0 && pj.tiles_x >= 16 && band_ok) return 0;
+    if (e->pack_rows == 3 && band_ok) return 0;  // bands whatever the width (tests)
     return (e->pack_rows == 0 || e->pack_rows == 3) ? 4 : (int)e->pack_rows;
 }
 
@@ -559,20 +560,12 @@ int64_t pack16_blocks(const sc_engine *e, const PackJob &pj) {
     return (int64_t)pj.nslots * ((pj.tiles_y + rows - 1) / rows) * ((pj.tiles_x + 3) / 4);
 }
 
-// slots [pj.slot0, pj.slot0 + pj.nslots) as a launch of their own; fill_bytes > 0 (band form only): the first that many
-// bytes of the label volume are set to -1 by fill blocks in front (pack_band_fill_kernel)
-int launch_pack16(sc_engine *e, const PackJob &pj, uint64_t fill_bytes = 0) {
+// slots [pj.slot0, pj.slot0 + pj.nslots) as a launch of their own
+int launch_pack16(sc_engine *e, const PackJob &pj) {
     if (pj.nslots <= 0) return SC_OK;
     const int rows = pack_form(e, pj);
     int64_t blocks = pack16_blocks(e, pj);
     if (blocks > 0x7fffffffLL) return fail(SC_ERR_INVALID, "mask batch too large");
-    if (fill_bytes > 0 && rows == 0) {
-        const uint32_t nfill = (uint32_t)std::min<int64_t>(2 * e->spec_blocks, 1024);  // (256-thread blocks here, 512 in the flags kernel)
-        hipLaunchKernelGGL(pack_band_fill_kernel, dim3((uint32_t)blocks + nfill), dim3(kBlock), 0, e->stream, pj,
-                           static_cast<int32_t *>(e->state), fill_bytes, nfill);
-        HIP_TRY(hipGetLastError());
-        return SC_OK;
-    }
 #define LAUNCH_PACK16(ROWS) \
     hipLaunchKernelGGL(pack16_kernel<ROWS>, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, pj)
     if (rows == 0) hipLaunchKernelGGL(pack_band_kernel, dim3((uint32_t)blocks), dim3(kBlock), 0, e->stream, pj);
@@ -1056,26 +1049,6 @@ FusedPlan fused_plan(const sc_engine *e, size_t nv, bool has_occ) {
     return p;
 }
 
-// Strips of a FRESH volume set to -1 ahead of the brick verdicts (SpecFill): `total` of them, the first `by_pack` by
-// fill blocks inside the kernel that packs the batch's first masks, the others in front of the flags kernel's blocks.
-// Everything behind the flags kernel that writes labels comes later on the stream, and the fill of the strips is all
-// the list stages' (no dense-stage store blocks), or nothing is filled ahead.
-struct SpecPlan { uint32_t total, by_pack; };
-SpecPlan spec_plan(const sc_engine *e, const FusedPlan &fp, bool pack_launch_band) {
-    SpecPlan sp{0u, 0u};
-    if (!(fp.brick && fp.compact && fp.defer_stores && fp.dense_store_strips == 0 && e->fresh)) return sp;
-    const uint32_t by_flags = (uint32_t)((uint64_t)fp.nstrips * (uint64_t)e->spec_share / 16u);
-    if (pack_launch_band && e->spec_pack_share > 0)
-        sp.by_pack = (uint32_t)std::min<uint64_t>((uint64_t)fp.nstrips * (uint64_t)e->spec_pack_share / 64u, fp.nstrips - by_flags);
-    sp.total = sp.by_pack + by_flags;
-    return sp;
-}
-uint64_t strips_bytes(const sc_engine *e, uint32_t strips, uint32_t bys) {
-    // strip s starts at column (s / bys) * ny + (s % bys) * 16; the columns are contiguous rows of nzp labels
-    const uint64_t cols = (uint64_t)(strips / bys) * (uint64_t)e->ny + (uint64_t)(strips % bys) * kBrickY;
-    return cols * (uint64_t)e->nzp * 4u;
-}
-
 // Launch the first `count` pending views (count == 0: all of them).
 int flush(sc_engine *e, size_t count = 0) {
     if (e->pending.empty()) return SC_OK;
@@ -1093,7 +1066,6 @@ int flush(sc_engine *e, size_t count = 0) {
     memset(&ride, 0, sizeof ride);
     uint32_t ride_blocks = 0;
     int packed_ahead = (int)nv;
-    uint32_t spec_by_pack = 0;  // strips the pack launch below has set to -1 (SpecPlan)
     if (e->deferred.on) {
         const bool whole = nv == e->pending.size() && nv == (size_t)e->deferred.V && e->mode == SC_MODE_CARVE && nv > 1;
         if (!whole) {
@@ -1125,11 +1097,7 @@ int flush(sc_engine *e, size_t count = 0) {
             LaunchTimer ltp{e, SC_KERNEL_PACK};
             rcd = ltp.begin();
             if (rcd) return rcd;
-            // (the labels this launch may fill ahead are exactly those the flags kernel's own fill blocks would: the
-            // plan below is the one the carve branch makes from the same engine state a few lines further down)
-            if (e->mode == SC_MODE_CARVE && pack_form(e, pj) == 0)
-                spec_by_pack = spec_plan(e, fp, true).by_pack;
-            rcd = launch_pack16(e, pj, spec_by_pack ? strips_bytes(e, spec_by_pack, fp.bys) : 0);
+            rcd = launch_pack16(e, pj);
             if (rcd) return rcd;
             rcd = ltp.end();
             if (rcd) return rcd;
@@ -1210,8 +1178,9 @@ int flush(sc_engine *e, size_t count = 0) {
         // strips set to -1 ahead of the verdicts, by fill blocks in front of the flags kernel's own (SpecFill): a fresh
         // volume whose fill is all the list stages' (so that everything behind the flags kernel that writes labels
         // comes later on the stream)
-        // (the pack launch above has taken the first spec_by_pack of them already)
-        const uint32_t spec_strips = spec_plan(e, fp, spec_by_pack > 0).total;
+        uint32_t spec_strips = 0;
+        if (fp.brick && fp.compact && fp.defer_stores && dense_store_strips == 0 && e->fresh && e->spec_share > 0)
+            spec_strips = (uint32_t)((uint64_t)fp.nstrips * (uint64_t)e->spec_share / 16u);
         const bool desc_by_flags = brick && flag_views <= kFlagWaves;
         if (!desc_by_flags) {
             rc = upload_desc();
@@ -1304,10 +1273,10 @@ int flush(sc_engine *e, size_t count = 0) {
                     desc_uploaded = true;
                 }
                 SpecFill sf{nullptr, 0u, 0u};
-                if (spec_strips > spec_by_pack) {
-                    const uint64_t done = strips_bytes(e, spec_by_pack, bys);
-                    sf = SpecFill{reinterpret_cast<int32_t *>(reinterpret_cast<char *>(st) + done),
-                                  strips_bytes(e, spec_strips, bys) - done, (uint32_t)e->spec_blocks};
+                if (spec_strips > 0) {
+                    // strip s starts at column (s / bys) * ny + (s % bys) * 16; the columns are contiguous rows of nzp labels
+                    const uint64_t cols = (uint64_t)(spec_strips / bys) * (uint64_t)e->ny + (uint64_t)(spec_strips % bys) * kBrickY;
+                    sf = SpecFill{st, cols * (uint64_t)e->nzp * 4u, (uint32_t)e->spec_blocks};
                 }
                 hipLaunchKernelGGL(brick_flags_kernel, dim3(sf.nblocks + (nbricks + 63u) / 64u), dim3(64 * kFlagWaves), 0,
                                    e->stream, g, desc_by_flags ? static_cast<const ViewDesc *>(nullptr) : vd,
@@ -1860,10 +1829,6 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_SPEC_BLOCKS:
             if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "spec_blocks must be in [1, 4096]");
             e->spec_blocks = value;
-            return SC_OK;
-        case SC_OPT_SPEC_PACK_SHARE:
-            if (value < 0 || value > 64) return fail(SC_ERR_INVALID, "spec_pack_share must be in [0, 64]");
-            e->spec_pack_share = value;
             return SC_OK;
         case SC_OPT_DENSE_EXTRA:
             e->dense_extra = value ? 1 : 0;

@@ -184,7 +184,7 @@ def cameras_for_label(files, label, camera_metadata="colmap_camera"):
 
 
 def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging", log=True,
-                      invert=False, device=None, overlap=True):
+                      invert=False, device=None, overlap=True, timing=None):
     """``Voxels`` on device-resident masks: one volume per label.
 
     masks   : ``{label: uint8 cuda tensor [n_img, Sy, Sx]}`` (``masks_from_predictions``)
@@ -193,6 +193,7 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
         label's volume crosses PCIe and gets its ``exp`` / clip on a helper thread, the device already
         works on the next label.  ``False`` = one engine, one label after the other (cl.py:248-255).
         Same volumes either way.
+    timing  : a dict to receive the phases' host-clock milliseconds (shared-launch path; diagnostics).
     Returns ``{label: ndarray}`` -- float32 for "averaging" (after ``exp`` / clip when ``log``,
     tasks/cl.py:172-174), int32 for "carving".
     """
@@ -231,7 +232,22 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
 
     narrow = mode == nat.SC_MODE_CARVE and int(np.prod(vol_shape)) >= (1 << 24)
 
+    def exp_clip_piece(piece):
+        # np.exp, then vol[vol > 1] = 1 (tasks/cl.py:172-174) as np.minimum: same values, elementwise -- a piece at a time
+        np.exp(piece, out=piece)
+        np.minimum(piece, piece.dtype.type(1.0), out=piece)
+
+    def exp_clip_from(src_piece, dst_piece):
+        # the same from a piece that has landed in the page-locked ring to its place in the volume: one pass
+        np.exp(src_piece, out=dst_piece)
+        np.minimum(dst_piece, dst_piece.dtype.type(1.0), out=dst_piece)
+
     def finish(eng, dest, dest8, src):
+        if dest8 is None and mode == nat.SC_MODE_AVERAGE and log and int(np.prod(vol_shape)) >= (1 << 24):
+            # round 5: the exp / clip of a piece runs on host threads while the next pieces cross PCIe
+            vol = eng.get_values_staged(dest.result(), exp_clip_from)
+            del src
+            return vol
         if dest8 is not None:
             # labels cross PCIe as bytes and are widened on host threads (as Backprojection.get_values)
             small = eng.get_values_i8(dest8.result())
@@ -254,21 +270,59 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
         # cross PCIe one after the other, the ``exp`` / clip of one on a helper thread beside the next copy.
         # (Up to 4 labels: with 6 the shared launch lost to six of their own, 16.5 against 14.3 ms on the device.)
         try:
+            import threading
+            import time
+            tm = [("start", time.perf_counter())]
             srcs = []
-            dests = []
+            nlab = len(masks)
+            dests = [None] * nlab
+            ready = [threading.Event() for _ in range(nlab)]
+
+            def touch_in_turn():
+                # the labels' host arrays, pages touched in the order the copies need them (all at once they fight
+                # over the same page-fault path: the first label's pages are what the first copy waits for)
+                for i in range(nlab):
+                    dests[i] = nat.TouchedEmpty(vol_shape, vol_dtype, threads=nat.host_workers()).result()
+                    ready[i].set()
+
+            toucher = threading.Thread(target=touch_in_turn, daemon=True)
+            toucher.start()
             for label, m in masks.items():
                 eng = nat.Engine(shape, origin, voxel_size, mode, device=dev)
                 engines.append(eng)
                 eng.set_lut(lut)
                 eng.order_after(producer)  # the masks are complete before the engines read them
                 srcs.append((255 - m) if invert else m)
-                dests.append(nat.TouchedEmpty(vol_shape, vol_dtype))
+            tm.append(("engines", time.perf_counter()))
             nat.average_labels(engines, K, R, t, [x.data_ptr() for x in srcs], n_img, H, W)
-            with ThreadPoolExecutor(max_workers=2) as helper:
-                futs = [helper.submit(finish, eng, dest, None, src)
-                        for eng, dest, src in zip(engines, dests, srcs)]
-                for label, fut in zip(masks, futs):
-                    out[label] = fut.result()
+            tm.append(("enqueue", time.perf_counter()))
+            # ONE pipeline over all the labels (round 5): the volumes cross the one PCIe link back to back, in pieces,
+            # and every piece's exp / clip (tasks/cl.py:172-174) runs on host threads beside the copies that follow
+            pipelined = log and int(np.prod(vol_shape)) >= (1 << 24)
+            with ThreadPoolExecutor(max_workers=nat.host_workers()) as pool:
+                futs = []
+                for i, (label, eng) in enumerate(zip(masks, engines)):
+                    ready[i].wait()
+                    tm.append((f"pages{i}", time.perf_counter()))
+                    if pipelined:
+                        # (the ring is shared by the labels: a slot is written again only when its piece has left it)
+                        futs += eng.get_values_staged(dests[i], exp_clip_from, pool=pool)
+                        out[label] = dests[i]
+                    else:
+                        out[label] = finish(eng, _Ready(dests[i]), None, None)
+                    tm.append((f"copied{i}", time.perf_counter()))
+                for f in futs:
+                    f.result()
+                tm.append(("exp_tail", time.perf_counter()))
+            toucher.join()
+            # the device volumes go back to the driver on a thread of their own: three hipFree of 512 MiB are
+            # milliseconds the caller need not wait for (joined at interpreter exit; a failure there cannot be reported
+            # to anybody, and there is nothing the caller could do about one)
+            closing, engines = engines, []
+            _close_later(closing)
+            tm.append(("handed_back", time.perf_counter()))
+            if timing is not None:
+                timing.update({name: (b - a) * 1e3 for (_, a), (name, b) in zip(tm[:-1], tm[1:])})
             del srcs
         finally:
             for eng in engines:
@@ -314,6 +368,39 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
         for eng in engines:
             eng.close()
     return out
+
+
+_closers = []
+
+
+def _close_later(engines):
+    """``close()`` of engines whose results have been read back, off the caller's path."""
+    import atexit
+    import threading
+
+    def work():
+        for eng in engines:
+            try:
+                eng.close()
+            except Exception:  # noqa: BLE001
+                pass
+
+    th = threading.Thread(target=work, daemon=True)
+    if not _closers:
+        atexit.register(lambda: [t.join() for t in list(_closers)])
+    _closers[:] = [t for t in _closers if t.is_alive()]
+    _closers.append(th)
+    th.start()
+
+
+class _Ready:
+    """An array that is there already, with ``TouchedEmpty``'s ``result()``."""
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def result(self):
+        return self._arr
 
 
 class StandInSegmenter:

@@ -297,9 +297,6 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_SPEC_SHARE": 0},                                             # no fill ahead of the verdicts
     {"SC_OPT_SPEC_SHARE": 16, "SC_OPT_SPEC_BLOCKS": 7},                   # ... all of it, by an odd number of blocks
     {"SC_OPT_SPEC_SHARE": 9, "SC_OPT_FILL_BLOCKS": 0},
-    {"SC_OPT_SPEC_PACK_SHARE": 0},                                        # no fill inside the pack launch
-    {"SC_OPT_SPEC_PACK_SHARE": 64, "SC_OPT_SPEC_SHARE": 0},               # ... all of it there
-    {"SC_OPT_SPEC_PACK_SHARE": 23, "SC_OPT_SPEC_SHARE": 9, "SC_OPT_SPEC_BLOCKS": 3},
     {"SC_OPT_DEFER_SHARE": 5},                                            # the dense kernel fills most strips itself (and nobody rides)
     {"SC_OPT_DEFER_SHARE": 2, "SC_OPT_FILL_BLOCKS": 0},
     {"SC_OPT_FILL_BLOCKS": 64, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_STAGE1_STORE_SHARE": 3},  # few store blocks, odd shares

@@ -40,5 +40,13 @@ for mode, code in ((nat.SC_MODE_AVERAGE, nat.SC_MASK_U8_LUT), (nat.SC_MODE_CARVE
             o1 = np.exp(vol[:64])
             t6 = T()
             msg = f"  exp/clip {1e3*(t5-t4):.1f} (one thread would take {1e3*(t6-t5)*8:.0f})  min/max {float(out.min()):.3g}/{float(out.max()):.3g}"
+        if mode == nat.SC_MODE_AVERAGE:
+            # the same label again with the pieces' exp / clip beside the copy (Engine.get_values_pipelined)
+            def piece(v):
+                np.exp(v, out=v); np.minimum(v, np.float32(1.0), out=v)
+            for pb in (8 << 20, 32 << 20, 128 << 20):
+                t7 = T()
+                eng.get_values_pipelined(dest, piece, piece_bytes=pb)
+                msg += f"  pipelined({pb >> 20} MiB pieces) {1e3*(T()-t7):.1f}"
         print(f"{'average' if mode == nat.SC_MODE_AVERAGE else 'carve'}: enqueue {1e3*(t1-t0):.1f}  device {1e3*(t2-t1):.1f}  wait pages {1e3*(t3-t2):.1f}  read-back {1e3*(t4-t3):.1f}{msg} ms", flush=True)
     eng.close()

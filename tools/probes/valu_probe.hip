@@ -68,6 +68,13 @@
 #define LSHL(i) "v_lshlrev_b32 %" S(i) ", 2, %" S(i) "\n"
 #define OR3(i) "v_or3_b32 %" S(i) ", %" S(i) ", %8, %9\n"
 #define CMPSDWA(i) "v_cmp_ne_u16_sdwa s[20:21], %" S(i) ", %8 src0_sel:BYTE_0 src1_sel:DWORD\n"
+#define DOT4(i) "v_dot4_u32_u8 %" S(i) ", %" S(i) ", %8, %9\n"
+#define XORB(i) "v_xor_b32 %" S(i) ", %" S(i) ", %8\n"
+#define ORB(i) "v_or_b32 %" S(i) ", %" S(i) ", %8\n"
+#define DPPMOV(i) "v_mov_b32_dpp %" S(i) ", %" S(i) " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define SUBREV(i) "v_subrev_u32 %" S(i) ", %" S(i) ", %8\n"
+#define MINU(i) "v_min_u32 %" S(i) ", %" S(i) ", %8\n"
+#define ALIGNBIT(i) "v_alignbit_b32 %" S(i) ", %" S(i) ", %8, 7\n"
 #define SNOP(i) "s_nop 0\n"
 #define SAND(i) "s_and_b32 s20, s20, s21\n"
 
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
         CASE(22, ANDOR) CASE(23, RCP) CASE(24, MAXF) CASE(25, MED3) CASE(26, LDEXP) CASE(27, DIVFIX) CASE(28, MOV)
         CASE(29, TRUNC) CASE(30, FLOOR) CASE(31, CVTU) CASE(32, PERM) CASE(33, XAD) CASE(34, LSHLOR) CASE(35, SNOP) CASE(36, SAND)
         CASE(37, CNDE64V) CASE(38, CMPU) CASE(39, CMPUV) CASE(40, MINABS) CASE(41, MAX3) CASE(42, BFI) CASE(43, FRACT) CASE(44, SUBF)
-        CASE(45, MADU64X) CASE(46, LSHLADD64X) CASE(47, PKFMA) CASE(48, PKMUL) CASE(49, PKADD) CASE(50, FMAX) CASE(51, MULX) CASE(52, LSHL) CASE(53, OR3) CASE(54, CMPSDWA)
+        CASE(45, MADU64X) CASE(46, LSHLADD64X) CASE(47, PKFMA) CASE(48, PKMUL) CASE(49, PKADD) CASE(50, FMAX) CASE(51, MULX) CASE(52, LSHL) CASE(53, OR3) CASE(54, CMPSDWA) CASE(55, DOT4) CASE(56, XORB) CASE(57, ORB) CASE(58, DPPMOV) CASE(59, SUBREV) CASE(60, MINU) CASE(61, ALIGNBIT)
     }
     float s = 0;
     for (int i = 0; i < 8; ++i) s += r[i];
@@ -134,6 +141,6 @@ int main() {
     ROW(26, "v_ldexp_f32") ROW(27, "v_div_fixup_f32") ROW(28, "v_mov_b32") ROW(29, "v_trunc_f32") ROW(30, "v_floor_f32") ROW(31, "v_cvt_u32_f32")
     ROW(32, "v_perm_b32") ROW(33, "v_xad_u32") ROW(34, "v_lshl_or_b32") ROW(35, "s_nop 0") ROW(36, "s_and_b32")
     ROW(37, "v_cndmask_e64 vcc") ROW(38, "v_cmp_lt_u32 sgpr") ROW(39, "v_cmp_lt_u32 vcc") ROW(40, "v_min_f32 |a|,|b|") ROW(41, "v_max3_f32 abs") ROW(42, "v_bfi_b32") ROW(43, "v_fract_f32") ROW(44, "v_sub_f32")
-    ROW(45, "v_mad_u64_u32") ROW(46, "v_lshl_add_u64") ROW(47, "v_pk_fma_f32 (same regs)") ROW(48, "v_pk_mul_f32 (same regs)") ROW(49, "v_pk_add_f32 (same regs)") ROW(50, "v_fma_f32 (same regs)") ROW(51, "v_mul_f32 (same regs)") ROW(52, "v_lshlrev_b32") ROW(53, "v_or3_b32") ROW(54, "v_cmp_ne_u16_sdwa")
+    ROW(45, "v_mad_u64_u32") ROW(46, "v_lshl_add_u64") ROW(47, "v_pk_fma_f32 (same regs)") ROW(48, "v_pk_mul_f32 (same regs)") ROW(49, "v_pk_add_f32 (same regs)") ROW(50, "v_fma_f32 (same regs)") ROW(51, "v_mul_f32 (same regs)") ROW(52, "v_lshlrev_b32") ROW(53, "v_or3_b32") ROW(54, "v_cmp_ne_u16_sdwa") ROW(55, "v_dot4_u32_u8") ROW(56, "v_xor_b32") ROW(57, "v_or_b32") ROW(58, "v_mov_b32_dpp quad_perm") ROW(59, "v_subrev_u32") ROW(60, "v_min_u32") ROW(61, "v_alignbit_b32")
     return 0;
 }
