@@ -11,8 +11,22 @@
 constexpr int kATileW = 16, kATileH = 8;
 //   2  float32 in 8x4-pixel tiles (32 floats = one 128-byte line per tile; tilef_kernel)
 constexpr int kFTileW = 8, kFTileH = 4;
-__device__ __forceinline__ uint32_t ftile_offset(int u, int v, int tiles_x) {
-    return (__umul24((uint32_t)(v >> 2), (uint32_t)tiles_x) + (uint32_t)(u >> 3)) * 32u + (uint32_t)((v & 3) * 8 + (u & 7));
+// (round 5: strips as for the bytes below -- 8 pixels wide, a strip's rows one after the other, 32 bytes a row, so a
+// 128-byte line is still an 8x4 tile; `strip` = the floats of a strip = 8 x its rows, ViewDesc::tiles_x holds it)
+__device__ __forceinline__ uint32_t ftile_offset(int u, int v, int strip) {
+    return __umul24((uint32_t)u >> 3, (uint32_t)strip) + (((uint32_t)v << 3) | ((uint32_t)u & 7u));
+}
+
+// Where pixel (u, v) of a uint8 averaging mask lies.  The picture is cut into STRIPS 16 pixels wide and as tall as
+// the picture (rounded up to 8 rows); a strip is stored row after row, 16 bytes a row, so that a 128-byte line is
+// still a 16x8-pixel tile -- what a wavefront's gather touches a handful of -- and the offset is
+//     (u >> 4) * strip + v * 16 + (u & 15)          (strip = 16 bytes x the strip's rows; ViewDesc::tiles_x holds it)
+// four vector instructions where the row-major order of the tiles ((v >> 3) * tiles_x + (u >> 4)) * 128 + (v & 7) * 16
+// + (u & 15) took nine (round 5: the averaging kernel is bound by what it issues, 37 instructions per voxel.view).
+// Both factors of the product are below 2^24 and the offset below 2^31: enqueue_tile8 refuses pictures beyond that
+// (a million rows, or 2 GiB of pixels).
+__device__ __forceinline__ uint32_t u8strip_offset(int u, int v, uint32_t strip) {
+    return __umul24((uint32_t)u >> 4, strip) + (((uint32_t)v << 4) | ((uint32_t)u & 15u));
 }
 
 template <bool FRESH, bool VEC>
@@ -58,8 +72,7 @@ __device__ __forceinline__ void average_body(float *__restrict__ values, const G
             for (int e = 0; e < 4; ++e) {
                 int u, v;
                 ok[e] = project(ax, ay, az, z[e], d, u, v) & (e < (int)vx.nvalid);
-                uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
-                               (uint32_t)((v & 7) * 16 + (u & 15));
+                uint32_t off = u8strip_offset(u, v, (uint32_t)d.tiles_x);
                 uint32_t b = 0;
                 if (ok[e]) b = load_mask_byte(m, off);
                 add[e] = lut_s[b];
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void average_kernel_1(float *__restrict__ v
     average_body<FRESH, VEC>(values, g, &view, 1, init, lut);
 }
 
-// uint8 [V][H][W] row-major -> 16x8-pixel tiles (128 B each) for the averaging gather.
+// uint8 [V][H][W] row-major -> strips of 16x8-pixel tiles (128 B each; u8strip_offset) for the averaging gather.
 // Fast form: W % 16 == 0 and 16-byte aligned rows -- every lane moves one 16-byte run.
 __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict__ raw,
                                                        int64_t row_stride, int64_t view_stride, int W,
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void tile8_kernel(const uint8_t *__restrict
     int v = (int)(r % H);
     int view = (int)(r / H);
     const uint8_t *src = raw + view * view_stride + (int64_t)v * row_stride + c * 16;
-    uint8_t *dst = out + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
+    uint8_t *dst = out + (int64_t)view * tiles_y * tiles_x * 128 + ((int64_t)c * tiles_y * 8 + v) * 16;  // strip c, row v
     if (fast) {
         *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
     } else {
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void uniform_tiles_kernel(const uint8_t *__
     const int v = ty * 32 + (lane >> 1), c = tx * 2 + (lane & 1);
     bool nz = false, hole = false;
     if (v < H && c * 16 < W) {
-        const uint8_t *src = tiled + ((int64_t)view * tiles_y * tiles_x + (int64_t)(v >> 3) * tiles_x + c) * 128 + (v & 7) * 16;
+        const uint8_t *src = tiled + (int64_t)view * tiles_y * tiles_x * 128 + ((int64_t)c * tiles_y * 8 + v) * 16;  // strip c, row v
         const uint4 q = *reinterpret_cast<const uint4 *>(src);
         nz = (q.x | q.y | q.z | q.w) != 0u;
         hole = (q.x & q.y & q.z & q.w) != 0xffffffffu;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void tilef_kernel(const float *__restrict__
     int view = (int)(r / H);
     const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(raw) + view * view_stride +
                                                        (int64_t)v * row_stride) + c * 4;
-    float *dst = out + (int64_t)view * tiles_y * tiles_x * 32 + ftile_offset(c * 4, v, tiles_x);
+    float *dst = out + (int64_t)view * tiles_y * tiles_x * 32 + ftile_offset(c * 4, v, tiles_y * 32);
     if (fast) {
         *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
     } else {
@@ -197,14 +210,14 @@ __global__ __launch_bounds__(kBlock) void uniform_f32_kernel(const float *__rest
     const int lane = threadIdx.x & 63;
     const int rx = (int)(reg % otx), ry = (int)((reg / otx) % oty), view = (int)(reg / ((int64_t)otx * oty));
     const uint32_t *base = reinterpret_cast<const uint32_t *>(tiled) + (int64_t)view * tiles_y * tiles_x * 32;
-    const uint32_t first = base[ftile_offset(rx * 32, ry * 32, tiles_x)];
+    const uint32_t first = base[ftile_offset(rx * 32, ry * 32, tiles_y * 32)];
     bool same = true;
     // lane l: row ry*32 + l/2, half l & 1 of the 32 columns
     const int v = ry * 32 + (lane >> 1);
     if (v < H) {
         for (int q = 0; q < 16; ++q) {
             const int u = rx * 32 + (lane & 1) * 16 + q;
-            if (u < W) same &= base[ftile_offset(u, v, tiles_x)] == first;
+            if (u < W) same &= base[ftile_offset(u, v, tiles_y * 32)] == first;
         }
     }
     const unsigned long long differ = __ballot(!same);
@@ -236,15 +249,33 @@ __global__ __launch_bounds__(kBlock) void avg_flags_kernel(GridDesc g, const Vie
     const uint32_t by = rem / bricks_z, bz = rem - by * bricks_z;
     const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;
     const ViewDesc d = views[vi];
+    // Verdict 5 (round 5): the footprint is MIXED -- the voxels have to be projected -- but lies wholly inside the picture
+    // (rect_box: every voxel of the brick in front of the camera, its pixel inside the picture, rounding included):
+    // the averaging kernel then projects without the picture test (backprojection.c:13, :23-31 hold for every voxel).
+    bool all_inside = false;
     if (d.pad == 2) {  // tiled float32 mask: flat when every region under the brick holds one value
         uint32_t bits;
-        const uint32_t v = brick_flat_f32(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), bits);
+        uint32_t v = brick_flat_f32(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), bits, &all_inside);
+        if (v == 0u && all_inside && d.safe != 0) v = 5u;
         verd[(size_t)lb * (uint32_t)nviews + vi] = (uint8_t)v;
         if (verdf != nullptr) verdf[(size_t)lb * (uint32_t)nviews + vi] = bits;
         return;
     }
-    verd[(size_t)lb * (uint32_t)nviews + vi] =
-        (uint8_t)brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), (d.W + 31) >> 5);
+    uint32_t v = brick_verdict(d, g, x, (int)(by * kBrickY), (int)(bz * kBrickZ), (d.W + 31) >> 5, &all_inside);
+    if (v == 0u && all_inside && d.safe != 0) v = 5u;  // (d.safe: the short division needs no operand test, project())
+    verd[(size_t)lb * (uint32_t)nviews + vi] = (uint8_t)v;
+}
+
+// The pixel of a voxel that is KNOWN to lie in front of a certified camera and inside the picture (verdict 5): the
+// arithmetic of project()'s short path (backprojection.c:11-21, the correctly rounded shared-reciprocal division) without
+// the tests of :13 and :23-31, which hold.
+__device__ __forceinline__ void project_inside(float ax, float ay, float az, float z, const ViewDesc &d, int &u, int &v) {
+    const float pz = (az + d.R[8] * z) + d.t[2];  // :11
+    const float px = (ax + d.R[2] * z) + d.t[0];  // :17
+    const float py = (ay + d.R[5] * z) + d.t[1];  // :18
+    const float r = refined_rcp(pz);
+    u = (int)(div_by_rcp(px, pz, r) * d.K[0] + d.K[2]);  // :20
+    v = (int)(div_by_rcp(py, pz, r) * d.K[1] + d.K[3]);  // :21
 }
 
 template <bool FRESH>
@@ -298,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
         for (int q = 0; q < nv; ++q) {
             const uint32_t c = __builtin_amdgcn_readlane(mine, q);  // wave-uniform (brick-uniform)
             if (c == 4u) continue;  // OUTSIDE: no voxel of the brick is in the picture, the view adds nothing (:50-52)
-            if (c != 0u) {
+            if (c != 0u && c != 5u) {
                 const float add = c == 1u ? add0 : (c == 2u ? add255 : __uint_as_float(__builtin_amdgcn_readlane(minef, q)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = val[e] + add;  // :54, every voxel is in-image
@@ -306,6 +337,25 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
             }
             const ViewDesc d = views[v0 + q];
             const float ax = d.R[0] * x + d.R[1] * y, ay = d.R[3] * x + d.R[4] * y, az = d.R[6] * x + d.R[7] * y;
+            if (c == 5u) {  // mixed, and every voxel of the brick inside the picture: no test, no branch around the gather
+                if (d.pad == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int u, v;
+                        project_inside(ax, ay, az, z[e], d, u, v);
+                        val[e] = val[e] + load_mask_float(d.mask, (int64_t)ftile_offset(u, v, d.tiles_x));  // :54
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int u, v;
+                        project_inside(ax, ay, az, z[e], d, u, v);
+                        const uint32_t off = u8strip_offset(u, v, (uint32_t)d.tiles_x);
+                        val[e] = val[e] + lut_s[load_mask_byte(d.mask, off)];  // :54
+                    }
+                }
+                continue;
+            }
             if (d.pad == 2) {  // tiled float32 mask (wave-uniform)
                 const float *mf = static_cast<const float *>(d.mask);
 #pragma unroll
@@ -323,8 +373,7 @@ __global__ __launch_bounds__(kBlock) void average_brick_kernel(float *__restrict
             for (int e = 0; e < 4; ++e) {
                 int u, v;
                 const bool ok = project(ax, ay, az, z[e], d, u, v);
-                const uint32_t off = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
-                                     (uint32_t)((v & 7) * 16 + (u & 15));
+                const uint32_t off = u8strip_offset(u, v, (uint32_t)d.tiles_x);
                 uint32_t b = 0;
                 if (ok) b = load_mask_byte(m, off);
                 const float add = lut_s[b];
@@ -391,8 +440,10 @@ __global__ __launch_bounds__(kBlock) void avg_flags_multi_kernel(MultiArgs a, Gr
                     all[l] &= o;
                 }
             }
+        // (5: mixed, but every voxel of the brick inside the picture -- see avg_flags_kernel)
+        const uint32_t mixed = (fpr.inside && d.safe != 0) ? 5u : 0u;
 #pragma unroll
-        for (int l = 0; l < L; ++l) v[l] = (any[l] & 1u) == 0 ? 1u : ((all[l] & 2u) != 0 ? 2u : 0u);
+        for (int l = 0; l < L; ++l) v[l] = (any[l] & 1u) == 0 ? 1u : ((all[l] & 2u) != 0 ? 2u : mixed);
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) const_cast<uint8_t *>(a.verd[l])[(size_t)lb * (uint32_t)nviews + vi] = (uint8_t)v[l];
@@ -438,11 +489,12 @@ __global__ __launch_bounds__(kBlock) void average_multi_kernel(MultiArgs a, Grid
         for (int l = 0; l < L; ++l) mine[l] = ((int)lane < nv) ? a.verd[l][(size_t)lb * (uint32_t)nviews + v0 + (int)lane] : 0u;
         for (int q = 0; q < nv; ++q) {
             uint32_t c[L];
-            bool mixed = false;
+            bool mixed = false, inside5 = false;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 c[l] = __builtin_amdgcn_readlane(mine[l], q);  // wave-uniform (brick-uniform)
-                mixed |= c[l] == 0u;
+                mixed |= c[l] == 0u || c[l] == 5u;
+                inside5 |= c[l] == 5u;  // (a matter of the pose: the same for every label whose footprint is mixed)
             }
             if (c[0] == 4u) continue;  // OUTSIDE is a matter of the pose: no label's picture holds a voxel of the brick (:50-52)
             if (!mixed) {  // every label's footprint is flat: the labels' table values, nothing projected
@@ -461,13 +513,17 @@ __global__ __launch_bounds__(kBlock) void average_multi_kernel(MultiArgs a, Grid
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int u, v;
-                ok[e] = project(ax, ay, az, z[e], d, u, v);
-                off[e] = (__umul24((uint32_t)(v >> 3), (uint32_t)d.tiles_x) + (uint32_t)(u >> 4)) * 128u +
-                         (uint32_t)((v & 7) * 16 + (u & 15));
+                if (inside5) {  // wave-uniform: no picture test
+                    project_inside(ax, ay, az, z[e], d, u, v);
+                    ok[e] = true;
+                } else {
+                    ok[e] = project(ax, ay, az, z[e], d, u, v);
+                }
+                off[e] = u8strip_offset(u, v, (uint32_t)d.tiles_x);
             }
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                if (c[l] != 0u) {  // flat for this label: every voxel is in-image and adds the one value
+                if (c[l] != 0u && c[l] != 5u) {  // flat for this label: every voxel is in-image and adds the one value
                     const float add = c[l] == 1u ? lut_s[l][0] : lut_s[l][255];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[l][e] = val[l][e] + add;

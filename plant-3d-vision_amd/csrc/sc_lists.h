@@ -729,7 +729,13 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
             // units at once (lane = unit slot * (nall - 64) + view - 64), ahead of the units' own rounds: 1 1/8 verdict
             // rounds per unit instead of 2 (the rounds are latency chains, and what this kernel's time is made of).
             const uint32_t per1 = sj.uj.nall > 64 ? (uint32_t)sj.uj.nall - 64u : 0u;
-            const uint32_t G = per1 ? 64u / per1 : 1u;  // (nall <= 128: per1 <= 64, G >= 1)
+            // (round 5: no more units per round than an even deal over the wavefronts asks for -- a round is a chain of
+            // its units' verdicts in ONE wavefront, and with 8 per round the reference's own configuration, 18 480 units
+            // on 4 096 wavefronts, kept 2 310 of them busy with eight units each while the others had none; and a bulky
+            // object's 56 500 went round twice with eight where twice seven is an even deal)
+            const uint32_t gmax = per1 ? 64u / per1 : 1u;  // (nall <= 128: per1 <= 64, gmax >= 1)
+            const uint32_t rounds = (total + nworkers * gmax - 1u) / (nworkers * gmax);
+            const uint32_t G = min(gmax, max(1u, (total + nworkers * rounds - 1u) / (nworkers * rounds)));
             for (uint32_t i0 = (blockIdx.x * kFlagWaves + wave) * G; i0 < total; i0 += nworkers * G) {
                 const uint32_t slot = per1 ? lane / per1 : 0u;
                 const uint32_t i = i0 + min(slot, G - 1u);

@@ -100,12 +100,14 @@ struct Footprint {  // 32x32-pixel tiles the brick's image may touch; ok == fals
     int tx0, tx1, ty0, ty1;
     bool ok;
     bool outside;  // see PixelBox
+    bool inside;   // see PixelBox: every voxel in front of the camera and inside the picture (whatever the tiles hold)
 };
 
 __device__ __forceinline__ Footprint brick_footprint(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0) {
-    Footprint fpr{0, 0, 0, 0, false, false};
+    Footprint fpr{0, 0, 0, 0, false, false, false};
     const PixelBox bx = rect_box(d, g, x, j0, j0 + kBrickY - 1, k0, k0 + kBrickZ - 1);
     fpr.outside = bx.outside;
+    fpr.inside = bx.inside;
     if (!bx.inside) return fpr;
     fpr.tx0 = (int)bx.umin >> 5; fpr.tx1 = (int)bx.umax >> 5; fpr.ty0 = (int)bx.vmin >> 5; fpr.ty1 = (int)bx.vmax >> 5;
     fpr.ok = (fpr.tx1 - fpr.tx0 + 1) * (fpr.ty1 - fpr.ty0 + 1) <= 64;
@@ -176,8 +178,9 @@ __device__ __forceinline__ uint32_t rect_verdict_cells(const ViewDesc &d, const 
 }
 
 __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridDesc &g, float x, int j0,
-                                                  int k0, int occ_tx) {
+                                                  int k0, int occ_tx, bool *all_inside = nullptr) {
     const Footprint fpr = brick_footprint(d, g, x, j0, k0);
+    if (all_inside != nullptr) *all_inside = fpr.inside;  // (for the averaging kernel: no voxel needs its picture test)
     if (fpr.outside) return 4u;  // OUTSIDE: the view does nothing to the brick
     if (!fpr.ok) return 0u;
     uint32_t any = 0, all = 3;
@@ -220,8 +223,9 @@ __device__ __forceinline__ uint32_t brick_verdict(const ViewDesc &d, const GridD
 // values.  A footprint over regions that all hold ONE value adds that value to every voxel of the brick
 // (backprojection.c:54) without projecting any: returns 3 and the value's bits, else 0.
 __device__ __forceinline__ uint32_t brick_flat_f32(const ViewDesc &d, const GridDesc &g, float x, int j0, int k0,
-                                                   uint32_t &bits) {
+                                                   uint32_t &bits, bool *all_inside = nullptr) {
     const Footprint fpr = brick_footprint(d, g, x, j0, k0);
+    if (all_inside != nullptr) *all_inside = fpr.inside;
     bits = 0u;
     if (fpr.outside) return 4u;  // the view adds nothing to the brick
     if (!fpr.ok) return 0u;

@@ -664,6 +664,9 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
                   const void *raw_dev, int H, int W, int64_t row_stride, int64_t view_stride) {
     int tiles_x = (W + kATileW - 1) / kATileW, tiles_y = (H + kATileH - 1) / kATileH;
     size_t per_view = (size_t)tiles_x * tiles_y * 128;
+    // (u8strip_offset: a 24-bit product of the strip's number and its bytes, offsets below 2^31)
+    if (per_view >= ((size_t)1 << 31) || (size_t)tiles_y * 128 >= ((size_t)1 << 24))
+        return fail(SC_ERR_INVALID, "mask too large for the byte gather (%d x %d)", W, H);
     void *tiled = nullptr;
     int rc = arena_alloc(e, per_view * (size_t)V, &tiled);
     if (rc) return rc;
@@ -700,7 +703,7 @@ int enqueue_tile8(sc_engine *e, int V, const float *K, const float *R, const flo
         ViewDesc d;
         fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<uint8_t *>(tiled) + (size_t)q * per_view, H, W,
                   uni ? uni + (size_t)q * uni_per_view : nullptr);
-        d.tiles_x = tiles_x;
+        d.tiles_x = tiles_y * 128;  // uint8 + table form: the bytes of a 16-pixel strip (u8strip_offset), not a tile count
         d.pad = 1;
         e->pending.push_back(d);
     }
@@ -713,6 +716,9 @@ int enqueue_tilef32(sc_engine *e, int V, const float *K, const float *R, const f
                     int H, int W, int64_t row_stride, int64_t view_stride) {
     const int tiles_x = (W + kFTileW - 1) / kFTileW, tiles_y = (H + kFTileH - 1) / kFTileH;
     const size_t per_view = (size_t)tiles_x * tiles_y * 128;
+    // (ftile_offset: a 24-bit product of the strip's number and its floats, element indices below 2^32)
+    if (per_view >= ((size_t)1 << 33) || (size_t)tiles_y * 32 >= ((size_t)1 << 24))
+        return fail(SC_ERR_INVALID, "mask too large for the float gather (%d x %d)", W, H);
     void *tiled = nullptr;
     int rc = arena_alloc(e, per_view * (size_t)V, &tiled);
     if (rc) return rc;
@@ -742,7 +748,7 @@ int enqueue_tilef32(sc_engine *e, int V, const float *K, const float *R, const f
         ViewDesc d;
         fill_desc(e, d, K + 4 * q, R + 9 * q, t + 3 * q, static_cast<char *>(tiled) + (size_t)q * per_view, H, W,
                   uni + (size_t)q * uni_view);
-        d.tiles_x = tiles_x;
+        d.tiles_x = tiles_y * 32;  // float32 tiles: the floats of an 8-pixel strip (ftile_offset), not a tile count
         d.pad = 2;
         e->pending.push_back(d);
     }
