@@ -30,7 +30,7 @@ Beside the headline, in the same line (N = 1):
   scenes   the fused carve on S2 "solid", S3 "noise" and "dense" (a 20 % solid object, ~30 %
            foreground: no all-empty / all-white shortcut applies to most of it);
   average  the `average` kernel (backprojection.c:36-55) on uint8 binary, uint8 grey and float32
-           masks, against the VALU issue roofline;
+           masks, against the ceiling its own instruction mix sets at the measured per-instruction costs;
   e2e      the reference's real interface (cl.py:190-232): 72 uint8 masks in HOST memory through
            ``process_view`` to int32 labels in HOST memory (PCIe both ways; never ``value``);
   cpu_baseline  the oracle on this box's host cores, on a bounded sample of the same workload (S1, and
@@ -52,17 +52,40 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# f32 VALU issue.  Spec: 157.3 TFLOP/s FP32 vector = 78.6 T FMA lane-ops/s (guide: a wave64 v_fma_f32 issues in 2
-# cycles when at least two wavefronts share the SIMD; one wavefront alone issues every 4 cycles = 39.3 T).  The
-# averaging kernel has been measured ABOVE the 4-cycle figure on this chip (44 T lane-ops/s, 3.5 cycles per VALU
-# instruction per SIMD, profiles/r02_avg_sq_counters.json), so the 2-cycle figure is the ceiling used here.
-VALU_PEAK_TLANEOPS = 78.6
-# VALU lane-ops the `average` kernel executes per voxel.view: SQ_INSTS_VALU x 64 / (N x V) of a run in which every
-# (brick, view) pair is projected (random grey masks), re-measured in round 4 on the current kernels
-# (profiles/r04_avg_sq_counters.json, tools/r04_avg_counters.sh; round 2 read 52.7 before the certified-view path
-# shortened the projection; SURVEY 8d estimated ~50)
-LANE_OPS_PER_VOXEL_VIEW = {"u8": 41.7, "f32": 40.0}  # re-measured after the one-correction division (47.7 / 46.0 before it)
-AVG_COUNTERS = "profiles/r04_avg_sq_counters.json"
+# The `average` kernel's ceiling (round 5): it is bound by what it ISSUES -- waves wait for the
+# vector ALU, not for memory (SQ_WAIT_INST_ANY 46 % of the wave-cycles, vector ALU active 85 % of the SIMD time:
+# profiles/r05_avg_*_counters.json) -- and a vector instruction does not cost "2 cycles": tools/probes/valu_probe.hip
+# measures, per wavefront instruction and SIMD with 8 wavefronts resident, 2.5-2.7 cycles for v_mul_f32 / v_add_f32 /
+# and / or / shifts right / moves, 4.1-4.7 for v_fma_f32, comparisons, conversions and every three-operand form, 8.3
+# for v_rcp_f32 (profiles/r05_valu_probe.txt, cycles at the 2.4 GHz the probe assumes).  The ceiling prices the
+# kernel's own instruction mix (the SQ_INSTS_VALU_* counters of a run on random grey masks, every (brick, view) pair
+# projected) at those costs; instructions no class counter names are priced as the cheapest class, so the ceiling is
+# a LOWER bound of the time the mix needs and `frac` = ceiling / measured a lower bound of the issue utilisation.
+VALU_COST_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.64, "SQ_INSTS_VALU_MUL_F32": 2.52, "SQ_INSTS_VALU_FMA_F32": 4.09,
+                    "SQ_INSTS_VALU_TRANS_F32": 8.34, "SQ_INSTS_VALU_CVT": 4.67, "SQ_INSTS_VALU_INT32": 2.70,
+                    "SQ_INSTS_VALU_INT64": 4.40, "other": 2.64}
+VALU_PROBE = "profiles/r05_valu_probe.txt"
+AVG_COUNTERS = {"u8": "profiles/r05_avg_u8_grey_counters.json", "f32": "profiles/r05_avg_f32_grey_counters.json"}
+AVG_COUNTERS_NVV = 512 ** 3 * 72  # the voxel.views of the run the counters were taken on
+SIMDS, PROBE_CLOCK_HZ = 1024, 2.4e9
+
+
+def valu_ceiling(form, nvv):
+    """(ceiling_ms, lane_ops_per_voxel_view, cycles_per_wave_voxel_view, mix) of the averaging kernel for `nvv`
+    voxel.views, from the committed counters of its `form` ("u8" / "f32") priced at VALU_COST_CYCLES; None without them."""
+    try:
+        d = json.load(open(os.path.join(ROOT, AVG_COUNTERS[form])))
+        k = [v for n, v in d["kernels"].items() if n.startswith("average_brick_kernel")][0]
+    except Exception:
+        return None
+    total = k["SQ_INSTS_VALU"]
+    named = {c: k.get(c, 0.0) for c in VALU_COST_CYCLES if c != "other"}
+    mix = dict(named, other=max(0.0, total - sum(named.values())))
+    cycles = sum(mix[c] * VALU_COST_CYCLES[c] for c in mix)  # per dispatch of AVG_COUNTERS_NVV voxel.views
+    scale = nvv / AVG_COUNTERS_NVV
+    return (cycles * scale / SIMDS / PROBE_CLOCK_HZ * 1e3, total * 64.0 / AVG_COUNTERS_NVV,
+            cycles / (AVG_COUNTERS_NVV / 64.0), {c: v * 64.0 / AVG_COUNTERS_NVV for c, v in mix.items()})
+
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
 # x-planes dealt round-robin over the ranks.  Shapes for n = 512: nx divisible by N, ny by 16 and
@@ -378,15 +401,16 @@ def cold_first_batch(a, nat, shape, origin, vs, call, device, reps):
         eng.close()
         runs.append({"total_ms": (t3 - t0) * 1e3, "create_ms": (t1 - t0) * 1e3, "enqueue_ms": (t2 - t1) * 1e3,
                      "wait_ms": (t3 - t2) * 1e3, "second_batch_ms": (t4 - t3) * 1e3, "kernels_ms": ksum})
-    best = min(runs, key=lambda r: r["total_ms"])
-    return {"cold_first_batch_ms": best["total_ms"], "breakdown": best, "all_total_ms": [r["total_ms"] for r in runs],
-            "note": "fresh sc_create -> 72 resident masks enqueued -> flush -> synchronize, host clock, best of %d; "
-                    "create_ms = the 512 MiB label volume and a stream; enqueue_ms = the engine's one-off allocations "
-                    "(survivor lists, control block, packed-mask arena) interleaved with its launches; wait_ms = what "
-                    "was left of the device work when the host was through; second_batch_ms = clear + the same batch "
-                    "+ synchronize on that engine; kernels_ms = HIP events around every kernel of a batch (the bulk "
-                    "decision is taken on the device inside each batch: a first batch runs the kernels of every "
-                    "later one)" % reps}
+    first = runs[0]
+    return {"cold_first_batch_ms": first["total_ms"], "breakdown": first, "all_total_ms": [r["total_ms"] for r in runs],
+            "note": "fresh sc_create -> 72 resident masks enqueued -> flush -> synchronize, host clock: the FIRST such engine "
+                    "of %d (round 5: no best-of -- the later ones reuse what the first one's hipFree left in the runtime's "
+                    "pools and read 3 x lower; the first engine of a PROCESS is `cold_process`); create_ms = the 512 MiB "
+                    "label volume and a stream; enqueue_ms = the engine's one-off allocations (survivor lists, control "
+                    "block, packed-mask arena) interleaved with its launches; wait_ms = what was left of the device work "
+                    "when the host was through; second_batch_ms = clear + the same batch + synchronize on that engine; "
+                    "kernels_ms = HIP events around every kernel of a batch (the bulk decision is taken on the device "
+                    "inside each batch: a first batch runs the kernels of every later one)" % reps}
 
 
 def host_timed(engine, torch, fn, steps, warmup=1, runs=3):
@@ -497,23 +521,27 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
             eng.flush()
 
         ms = host_timed(eng, torch, step, steps, warmup=1)
-        per_vv = LANE_OPS_PER_VOXEL_VIEW["u8" if name.startswith("u8") else "f32"]
-        lane_ops = per_vv * n * V
-        ach = lane_ops / (ms * 1e-3) / 1e12
         ent = {"ms_per_step": ms, "value": n * V / ms / 1e3, "unit": "Mvoxel*views/s", "steps": steps,
-               "timing": "best of 3 runs of that many steps",
-               "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
-                            "frac": ach / VALU_PEAK_TLANEOPS,
-                            "lane_ops_per_step": lane_ops,
-                            "model": "%.1f VALU lane-ops per voxel.view (SQ_INSTS_VALU x 64 / (N x V), %s) x N x V"
-                                     % (per_vv, AVG_COUNTERS)}}
-        if name in ("u8_binary", "f32"):
-            # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
-            # projecting: the model above counts work the kernel did not do
-            ent["roofline"]["frac"] = None
-            ent["roofline"]["equivalent_frac"] = ach / VALU_PEAK_TLANEOPS
-            ent["roofline"]["note"] = ("brick form skips the projection of (brick, view) pairs with a flat footprint: "
-                                       "an equivalent rate, not VALU utilisation")
+               "timing": "best of 3 runs of that many steps"}
+        ceil = valu_ceiling("u8" if name.startswith("u8") else "f32", float(n) * V)
+        if ceil is not None:
+            ceiling_ms, lane_ops, cyc, mix = ceil
+            roof = {"bound": "valu-issue", "ceiling_ms": ceiling_ms, "frac": ceiling_ms / ms,
+                    "lane_ops_per_voxel_view": lane_ops, "simd_cycles_per_wavefront_voxel_view": cyc,
+                    "mix_lane_ops_per_voxel_view": mix, "cost_cycles": VALU_COST_CYCLES,
+                    "model": "the kernel's vector instructions (SQ_INSTS_VALU_* of %s: random grey masks, every (brick, view) "
+                             "pair projected) priced at the cycles per wavefront instruction and SIMD that %s measures for "
+                             "each class (instructions no class counter names priced as the cheapest class), over %d SIMDs at "
+                             "the probe's 2.4 GHz: a lower bound of the time this mix needs"
+                             % (AVG_COUNTERS["u8" if name.startswith("u8") else "f32"], VALU_PROBE, SIMDS)}
+            if name in ("u8_binary", "f32"):
+                # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
+                # projecting: the model above counts work the kernel did not do
+                roof["equivalent_frac"] = roof.pop("frac")
+                roof["frac"] = None
+                roof["note"] = ("brick form skips the projection of (brick, view) pairs with a flat footprint: "
+                                "an equivalent rate, not issue utilisation")
+            ent["roofline"] = roof
         out[name] = ent
     eng.dev_free(buf)
     eng.close()
