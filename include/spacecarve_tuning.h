@@ -97,6 +97,10 @@
                                      persistent fill blocks in front of the flags kernel's own (fresh volumes only: every
                                      brick that is not EMPTY is written again by a later kernel of the batch); 0: none  */
 #define SC_OPT_SPEC_BLOCKS 46     /* ... that many blocks of 512 threads (64)                                             */
+#define SC_OPT_LATE_ROAD 47       /* 1 (default): a brick every view packed ahead keeps whole and a later one does not (a
+                                     "late" brick) gets its labels from the confirm kernel and its four units join the bulk
+                                     units -- verdicts per unit, work items for the undecided views -- when the batch has a
+                                     bulk list; 0: the late list (one wavefront takes a unit through every view), always  */
 #define SC_OPT_UNIT_CULL 37       /* 1 (default): inside the dense stage the four units (16 columns x 16 voxels) of every
                                      live brick are asked about as a whole, over 8x8-pixel cells, by the views packed
                                      ahead; a unit some view finds empty is carved whole, not projected -- unless

@@ -43,7 +43,7 @@ SC_OPT_BULK_MIN, SC_OPT_ITEM_BIAS, SC_OPT_UNIT_BLOCKS, SC_OPT_BULK_FLOOR = 32, 3
 SC_OPT_BULK_ADAPT = SC_OPT_BULK_FLOOR  # deprecated name of key 35 (0 still means: the units are always asked)
 SC_OPT_UNIT_CULL, SC_OPT_LIST_CAP, SC_OPT_HOST_PACK, SC_OPT_HOST_THREADS, SC_OPT_LDS_TILES, SC_OPT_BULK_LIVE, SC_OPT_SAFE_KERNELS = 37, 38, 39, 40, 41, 42, 43
 SC_OPT_DENSE_EXTRA = 44
-SC_OPT_SPEC_SHARE, SC_OPT_SPEC_BLOCKS = 45, 46
+SC_OPT_SPEC_SHARE, SC_OPT_SPEC_BLOCKS, SC_OPT_LATE_ROAD = 45, 46, 47
 
 # name -> (restype, [argtypes]); 'p' pointer, 'i' int, 'q' int64, 'f' float, 's' const char*
 _SIGNATURES = {

@@ -253,10 +253,26 @@ __device__ uint32_t g_dense_trace[8192 * 8];  // stage did (rows 0..4095)
 // over all the views of the batch, unit by unit.
 constexpr int kConfirmWaves = 8;  // (16: a solid object 0.219 -> 0.253 ms -- a round asks all its views about every brick still
                                   // a candidate, so wider rounds ask more views about bricks an earlier one would have dropped)
+// Round 5 -- the road of a candidate that fails.  Until then it went on the late list and the special kernel took it
+// through EVERY view of the batch, unit by unit, one wavefront per unit: a verdict round and a chain of two-view turns
+// each, 1 374 bricks = 5 496 such chains on the reference's own configuration and the longest part of that kernel.
+// Now (UnitRoad::on, when the batch has a bulk list and the dense stage's lists did not overflow) the brick's labels are
+// written HERE -- every view the flags kernel could see keeps the brick whole, so they are what the dense stage would
+// have left: `init`, or 1 over 0 where some view saw it -- and its four units join the bulk units: the special kernel
+// asks the remaining views about each as a whole (unit_verdicts) and only the undecided ones project its voxels, as
+// work items of the final stage, which has the wavefronts to hide their latency.  The other road stays for batches
+// without a bulk list (SC_OPT_BULK_MIN 0, more than 128 views, masks without cell maps) and for a dense stage that
+// overflowed.
+struct UnitRoad {
+    int32_t *labels;   // null: every failed candidate takes the late list
+    int32_t init, fresh;
+    uint32_t nbricks;  // the late list's room: unit-road bricks are entered from its far end
+};
+
 __global__ __launch_bounds__(64 * kConfirmWaves) void brick_confirm_kernel(
     GridDesc g, const ViewDesc *__restrict__ views, int v0, int v1, uint32_t bricks_y, uint32_t bricks_z,
     uint8_t *__restrict__ flags, const uint32_t *__restrict__ cands, uint32_t cand_per, uint32_t *__restrict__ late,
-    ListCtl *ctl, uint32_t parity) {
+    ListCtl *ctl, uint32_t parity, UnitRoad ur) {
     if (v0 >= v1) return;  // no view was packed late
     // the sub-lists' groups of 64, one behind the other (a batch without open candidates: every block leaves here)
     uint32_t ncand[kCandSub], gfirst[kCandSub + 1];
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(64 * kConfirmWaves) void brick_confirm_kernel(
         gfirst[s + 1] = gfirst[s] + ((ncand[s] + 63u) >> 6);
     }
     __shared__ unsigned long long s_full[kConfirmWaves], s_seen[kConfirmWaves];
+    __shared__ unsigned long long s_road, s_rseen;  // the group's failed candidates that take the units' road, and who saw them
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t per_plane = bricks_y * bricks_z;
     // a persistent grid over the groups of 64 candidates
@@ -301,17 +318,53 @@ __global__ __launch_bounds__(64 * kConfirmWaves) void brick_confirm_kernel(
 #pragma unroll
             for (int w = 0; w < kConfirmWaves; ++w) { cand &= s_full[w]; any_seen |= s_seen[w]; }
         }
-        if (wave != 0) continue;
-        if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
-        const bool failed = isc && !((cand >> lane) & 1ull);
-        const unsigned long long m = __ballot(failed);
-        if (m != 0) {
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&ctl->nlate, (uint32_t)__popcll(m));
-            pos = __shfl(pos, 0);
-            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if (failed) late[pos + (uint32_t)__popcll(m & below)] = lb;
+        const bool road = ur.labels != nullptr && ctl->overflow == 0u;  // block-uniform (the dense stage set the flag)
+        if (wave == 0) {
+            if (isc) flags[lb] = ((cand >> lane) & 1ull) ? (((any_seen >> lane) & 1ull) ? 2 : 6) : 5;
+            const bool failed = isc && !((cand >> lane) & 1ull);
+            const unsigned long long m = __ballot(failed);
+            if (m != 0) {
+                uint32_t pos = 0;
+                if (lane == 0) pos = atomicAdd(road ? &ctl->nlate_units : &ctl->nlate, (uint32_t)__popcll(m));
+                pos = __shfl(pos, 0);
+                const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                const uint32_t at = pos + (uint32_t)__popcll(m & below);
+                if (failed) late[road ? ur.nbricks - 1u - at : at] = lb;  // (failed candidates are bricks: both ends fit)
+            }
+            if (lane == 0) { s_road = road ? m : 0ull; s_rseen = any_seen; }  // (words of their own: a wavefront may still be reading the last round's)
         }
+        __syncthreads();
+        if (road) {
+            // the labels of the bricks that take the units' road, a brick per wavefront and turn: 16 columns x 64 voxels =
+            // four 16-byte stores per lane (lane = (column & 3) * 16 + group of 4 voxels)
+            const unsigned long long mr = s_road, ms = s_rseen;
+            uint32_t nth = 0;
+            for (unsigned long long mm = mr; mm != 0; mm &= mm - 1, ++nth) {
+                if ((nth & (uint32_t)(kConfirmWaves - 1)) != wave) continue;
+                const uint32_t src = (uint32_t)__builtin_ctzll(mm);
+                const uint32_t b = __builtin_amdgcn_readlane(lb, src);
+                const bool seen = (ms >> src) & 1ull;
+                const uint32_t bil = b / per_plane, brem = b - bil * per_plane;
+                const uint32_t bby = brem / bricks_z, bbz = brem - bby * bricks_z;
+                const uint32_t k0 = bbz * kBrickZ + (lane & 15u) * 4u;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t j = bby * kBrickY + i * 4u + (lane >> 4);
+                    if (j >= g.ny || k0 >= g.nz) continue;
+                    int32_t *p = ur.labels + ((uint64_t)bil * g.ny + j) * g.nzp + k0;  // the pitch is a multiple of 64: 16-byte groups
+                    if (ur.fresh) {
+                        const int32_t val = (seen && ur.init == 0) ? 1 : ur.init;  // backprojection.c:81 by a view that keeps the brick whole
+                        *reinterpret_cast<int4 *>(p) = make_int4(val, val, val, val);
+                    } else if (seen) {
+                        int4 q = *reinterpret_cast<const int4 *>(p);
+                        const bool changed = q.x == 0 || q.y == 0 || q.z == 0 || q.w == 0;
+                        q.x = q.x == 0 ? 1 : q.x; q.y = q.y == 0 ? 1 : q.y; q.z = q.z == 0 ? 1 : q.z; q.w = q.w == 0 ? 1 : q.w;
+                        if (changed) *reinterpret_cast<int4 *>(p) = q;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // everybody has read s_road / s_rseen before the next group's wave 0 writes them
     }
 }
 

@@ -424,6 +424,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void c
 
 struct LateBricks {           // FULL candidates that turned out not to be (see brick_confirm_kernel)
     const uint32_t *late;     // null: the batch had no open candidates
+    uint32_t nbricks;         // the list's room: the bricks that take the units' road are entered from its far end
     const ViewDesc *allviews; // every view of the batch
     const uint8_t *flags;
     int32_t nall, init, fresh;
@@ -707,10 +708,13 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
         for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
         if (lane == 0 && wsum != 0u) atomicAdd(&s_total, wsum);
         __syncthreads();
-        const uint32_t total = s_total;
-        // Fewer units than the floor: nobody asks, the first survivor stage takes their voxels as they are
-        // (UnitSpill -- it applies the same rule to the same counts).  Grid-uniform.
-        if (total >= sj.uj.floor && total != 0u) {
+        // Fewer bulk units than the floor: nobody asks about THEM, the first survivor stage takes their voxels as they
+        // are (UnitSpill -- it applies the same rule to the same counts).  The units of the candidates that failed
+        // (round 5: brick_confirm_kernel, UnitRoad) are always asked -- they are on no other list.  Grid-uniform.
+        const uint32_t nb = (s_total >= sj.uj.floor) ? s_total : 0u;
+        const uint32_t nl = sj.lb.late != nullptr ? 4u * ctl->nlate_units : 0u;
+        const uint32_t total = nb + nl;
+        if (total != 0u) {
             if (tid < kSub) upref[tid + 1] = mine;
             if (tid == 0) upref[0] = 0;
             __syncthreads();
@@ -736,16 +740,25 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
             const uint32_t gmax = per1 ? 64u / per1 : 1u;  // (nall <= 128: per1 <= 64, gmax >= 1)
             const uint32_t rounds = (total + nworkers * gmax - 1u) / (nworkers * gmax);
             const uint32_t G = min(gmax, max(1u, (total + nworkers * rounds - 1u) / (nworkers * rounds)));
+            const uint32_t nbricks_all = sj.lb.nbricks;
             for (uint32_t i0 = (blockIdx.x * kFlagWaves + wave) * G; i0 < total; i0 += nworkers * G) {
                 const uint32_t slot = per1 ? lane / per1 : 0u;
                 const uint32_t i = i0 + min(slot, G - 1u);
                 const bool has = slot < G && i < total;
-                uint32_t lo = 0, hi = kSub;  // largest s with upref[s] <= i (per lane: the lanes of a slot agree)
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (upref[mid] <= (has ? i : 0u)) lo = mid; else hi = mid;
+                // unit i: one of the bulk list's (the first nb), or unit (i - nb) & 3 of a failed candidate
+                uint32_t my_unit = 0u, lo = 0u;
+                if (has && i < nb) {
+                    uint32_t hi = kSub;  // largest s with upref[s] <= i (per lane: the lanes of a slot agree)
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (upref[mid] <= i) lo = mid; else hi = mid;
+                    }
+                    my_unit = sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])];
+                } else if (has) {
+                    const uint32_t lbq = sj.lb.late[nbricks_all - 1u - ((i - nb) >> 2)];
+                    my_unit = lbq * 4u + ((i - nb) & 3u);
+                    lo = (lbq * 0x9E3779B1u) >> 24;  // the sub-list its items and survivors go to (as brick_voxels picks it)
                 }
-                const uint32_t my_unit = has ? sj.uj.units[(size_t)lo * sj.uj.cap + (i - upref[lo])] : 0u;
                 uint32_t v1 = 8u;  // no such view
                 if (has && per1) {
                     const int vi = 64 + (int)(lane - slot * per1);

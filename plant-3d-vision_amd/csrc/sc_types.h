@@ -86,7 +86,9 @@ struct ListCtl {
                                  // that keep the same block (fewer than 6 views: no survivor stages) need no memset
     uint32_t nlate;              // FULL candidates a later view did not keep whole (entries of the late list)
     uint32_t nfill[2];           // settled bricks that need a fill (entries of the fill list), same alternation
-    uint32_t pad[26];
+    uint32_t nlate_units;        // ... of them, those whose four units take the bulk units' road (round 5): entries at the
+                                 // late list's far end, last one first (brick_confirm_kernel, carve_special_kernel)
+    uint32_t pad[25];
     ListCounter xcd_next[64];    // dense stage: ticket counters for the live list, 8 per XCD (index xcd * 8 + c: the
                                  // wavefronts of XCD k whose number ends in c share one; see carve_brick_kernel)
     ListCounter ncand[2][kCandSub];  // FULL candidates the flags kernel left open for the confirm kernel: entries of the

@@ -231,6 +231,7 @@ struct sc_engine {
     // carve masks from the host: packed to bits by host threads into a page-locked arena (two, alternating between
     // flushes), which one copy per flush brings to its device mirror together with the table of the views' records
     int64_t spec_share = 3;    // sixteenths of the strips set to -1 by fill blocks in front of the flags kernel (fresh volumes)
+    int64_t late_road = 1;     // 1: a FULL candidate a late view rejects joins the bulk units (UnitRoad); 0: the late list, always
     int64_t spec_blocks = 64;  // ... that many persistent blocks of 512 threads (64: a fill that does not saturate HBM leaves the verdicts their memory round trips; 128 measured 2 % slower per batch, 48 too)
     int64_t dense_extra = 1;   // a unit the dense views thinned out to 32 .. 128 voxels takes one more pair of views there
     int64_t safe_kernels = 1;  // batches whose views are all certified take the list kernels compiled without the general path
@@ -1349,8 +1350,10 @@ int flush(sc_engine *e, size_t count = 0) {
                 // (a block per 64 entries of the candidate list, a persistent grid of at most 4096; without candidates
                 // every block leaves after eight scalar loads)
                 const uint32_t nconfirm = std::min<uint32_t>((nbricks + 63u) / 64u, 4096u);
+                // (a candidate that fails takes the bulk units' road when the batch has a bulk list: UnitRoad)
+                const UnitRoad road{(bulk_on && e->late_road) ? st : nullptr, init, e->fresh ? 1 : 0, nbricks};
                 hipLaunchKernelGGL(brick_confirm_kernel, dim3(nconfirm), dim3(64 * kConfirmWaves), 0, e->stream, g, vd,
-                                   packed_ahead, (int)nv, bys, bzs, e->flags, e->fill_list, cand_per, e->late, e->ctl, parity);
+                                   packed_ahead, (int)nv, bys, bzs, e->flags, e->fill_list, cand_per, e->late, e->ctl, parity, road);
             }
             // Too few bulk units for their verdicts are taken by the first survivor stage as they are (UnitSpill); a
             // batch with a single (final) list stage has no such stage: its units are always asked
@@ -1363,7 +1366,7 @@ int flush(sc_engine *e, size_t count = 0) {
                 if (bulk_on)
                     sj.uj = UnitJob{e->bulk, e->bulkcap, e->items, e->itemcap, vd, (int32_t)nv, ndense, bys, bzs, st,
                                     e->lists, e->subcap, (uint32_t)e->item_bias, unit_floor};
-                sj.lb = LateBricks{ride_blocks ? e->late : nullptr, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
+                sj.lb = LateBricks{ride_blocks ? e->late : nullptr, nbricks, vd, e->flags, (int32_t)nv, init, e->fresh ? 1 : 0, bys, bzs};
                 sj.next = e->ctl2[e->ctl_idx ^ 1];
                 sj.rest = vd + ndense;
                 sj.nrest = (int32_t)nv - ndense;
@@ -1835,6 +1838,9 @@ int sc_set_option(sc_engine *e, int key, int64_t value) {
         case SC_OPT_SPEC_BLOCKS:
             if (value < 1 || value > 4096) return fail(SC_ERR_INVALID, "spec_blocks must be in [1, 4096]");
             e->spec_blocks = value;
+            return SC_OK;
+        case SC_OPT_LATE_ROAD:
+            e->late_road = value ? 1 : 0;
             return SC_OK;
         case SC_OPT_DENSE_EXTRA:
             e->dense_extra = value ? 1 : 0;
@@ -2664,7 +2670,7 @@ int sc_fused_counts_ex(sc_engine *e, int64_t out[8]) {
     if (rc || !e->ctl) return rc;
     ListCtl host;
     HIP_TRY(hipMemcpy(&host, e->ctl, sizeof(ListCtl), hipMemcpyDeviceToHost));
-    out[4] = host.nlate;
+    out[4] = (int64_t)host.nlate + (int64_t)host.nlate_units;  // failed candidates, whichever road they took
     if (e->last_bulk)
         for (int q = 0; q < kSub; ++q) {
             out[5] += std::min<uint32_t>(host.count[3][q].n, e->bulkcap);

@@ -297,6 +297,9 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_SPEC_SHARE": 0},                                             # no fill ahead of the verdicts
     {"SC_OPT_SPEC_SHARE": 16, "SC_OPT_SPEC_BLOCKS": 7},                   # ... all of it, by an odd number of blocks
     {"SC_OPT_SPEC_SHARE": 9, "SC_OPT_FILL_BLOCKS": 0},
+    {"SC_OPT_LATE_ROAD": 0},                                              # failed candidates on the late list, always
+    {"SC_OPT_LATE_ROAD": 1, "SC_OPT_BULK_MIN": 1, "SC_OPT_BULK_FLOOR": 0, "SC_OPT_BULK_LIVE": 0},  # ... among many bulk units
+    {"SC_OPT_LATE_ROAD": 1, "SC_OPT_BULK_FLOOR": 1 << 30},               # ... alone: the bulk units spill, the late ones are asked
     {"SC_OPT_DEFER_SHARE": 5},                                            # the dense kernel fills most strips itself (and nobody rides)
     {"SC_OPT_DEFER_SHARE": 2, "SC_OPT_FILL_BLOCKS": 0},
     {"SC_OPT_FILL_BLOCKS": 64, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_STAGE1_STORE_SHARE": 3},  # few store blocks, odd shares

@@ -26,7 +26,7 @@ KNOBS = {
     "SC_OPT_FINAL_VOXELS": [1, 2, 4], "SC_OPT_STAGE1_VOXELS": [1, 2, 4], "SC_OPT_VIEW_BRICK": [0, 1], "SC_OPT_STAGE1_STORE_SHARE": [0, 4, 16], "SC_OPT_STAGE1_LIST_BLOCKS": [8, 1280],
     "SC_OPT_BULK_MIN": [0, 1, 64, 128, 256], "SC_OPT_BULK_FLOOR": [0, 1, 16, 2048, 1 << 30], "SC_OPT_ITEM_BIAS": [0, 8, 12, 64],
     "SC_OPT_UNIT_BLOCKS": [1, 64, 512], "SC_OPT_UNIT_CULL": [0, 1, 2, 2],
-    "SC_OPT_HOST_PACK": [0, 1, 1], "SC_OPT_BULK_LIVE": [0, 0, 2, 16], "SC_OPT_SAFE_KERNELS": [0, 1, 1], "SC_OPT_DENSE_EXTRA": [0, 1, 1], "SC_OPT_SPEC_SHARE": [0, 3, 9, 16], "SC_OPT_SPEC_BLOCKS": [1, 128], "SC_OPT_LIST_CAP": [0, 0, 0, 2, 16, 300],
+    "SC_OPT_HOST_PACK": [0, 1, 1], "SC_OPT_BULK_LIVE": [0, 0, 2, 16], "SC_OPT_SAFE_KERNELS": [0, 1, 1], "SC_OPT_DENSE_EXTRA": [0, 1, 1], "SC_OPT_SPEC_SHARE": [0, 3, 9, 16], "SC_OPT_SPEC_BLOCKS": [1, 128], "SC_OPT_LATE_ROAD": [0, 1, 1], "SC_OPT_LIST_CAP": [0, 0, 0, 2, 16, 300],
 }
 
 def main():
