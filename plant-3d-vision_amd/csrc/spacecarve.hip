@@ -46,6 +46,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -1541,6 +1542,39 @@ int check_view_args(const sc_engine *e, const float *K, const float *R, const fl
     return SC_OK;
 }
 
+// Engine streams are kept between engines (round 5).  Creating a non-blocking stream is a hardware queue's worth of
+// set-up in the runtime: 84-139 ms for the first one of a process and, now and then, 6-40 ms for a later one -- the
+// "37 ms first batch" of a fresh engine that round 4's bench line showed on the driver's box (SC_TRACE_ALLOC=1 names the
+// call).  A destroyed engine's stream (idle: sc_destroy has waited for it) goes on a short per-device list and the next
+// engine on that device takes it from there; a process's first engine still pays the first creation, once.
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;  // (device, idle stream)
+constexpr size_t kStreamPoolMax = 16;
+
+hipError_t take_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (ptrdiff_t)i);
+                return hipSuccess;
+            }
+    }
+    return sctrace::timed("hipStreamCreate", __LINE__, 0, [&] { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); });
+}
+
+void give_stream_back(int device, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (g_stream_pool.size() < kStreamPoolMax) {
+            g_stream_pool.emplace_back(device, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 // The engine owns the x-planes  i0, i0 + istride, ...  (`planes` of them) of the global grid.
 int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t istride,
            int64_t planes, const float *origin, float vs, int mode, float default_value, int device) {
@@ -1564,7 +1598,7 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
         return fail(SC_ERR_DEVICE, "device %d not available (%d HIP device(s) visible)", device, ndev);
     {
         hipDeviceProp_t prop;
-        hq = hipGetDeviceProperties(&prop, device);
+        hq = sctrace::timed("hipGetDeviceProperties", __LINE__, 0, [&] { return hipGetDeviceProperties(&prop, device); });
         if (hq != hipSuccess) return fail(SC_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(hq));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(SC_ERR_DEVICE, "device %d is %s; this engine is built for gfx950 only", device,
@@ -1581,8 +1615,8 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
     memcpy(e->origin, origin, sizeof e->origin);
     e->vs = vs;
     e->default_value = default_value;
-    hipError_t he = hipSetDevice(device);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    hipError_t he = sctrace::timed("hipSetDevice", __LINE__, 0, [&] { return hipSetDevice(device); });
+    if (he == hipSuccess) he = take_stream(device, &e->own_stream);
     if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->npitch * 4);
     if (he != hipSuccess) {
         int code = he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE;
@@ -1682,7 +1716,10 @@ void sc_destroy(sc_engine *e) {
     if (e->ctl2[0]) (void)hipFree(e->ctl2[0]);
     if (e->items) (void)hipFree(e->items);
     if (e->state) (void)hipFree(e->state);
-    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->own_stream) {
+        (void)schost::wait_stream(e->own_stream);  // (the engine may have worked on a caller's stream: its own is idle now)
+        give_stream_back(e->device, e->own_stream);
+    }
     delete e;
 }
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Collects the round's fuzz runs (gpurun_out/r04/fuzz_*.log) into profiles/r04_fuzz_summary.json."""
+"""Collects the round's fuzz runs (gpurun_out/<round>/fuzz_*.log) into profiles/<round>_fuzz_summary.json: python tools/fuzz_summary.py r05 [notes...]."""
 import glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 runs = []
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r04", "fuzz_*.log"))):
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", ROUND, "fuzz_*.log"))):
     txt = open(f).read()
     cases = len(re.findall(r"^case \d+:", txt, re.M))
     mism = len(re.findall(r"MISMATCH", txt))
@@ -15,6 +16,6 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r04", "fuzz_*.log"))
     runs.append(ent)
 out = {"tool": "tools/fuzz_carve.py <cases> <seed> on one MI355X (random grids, scenes, rigs, default values, knob sets; "
                "host masks or a device batch; fresh volume + a second batch; every third case also the average kernel)",
-       "runs": runs, "notes": sys.argv[1:] }
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_fuzz_summary.json"), "w"), indent=1)
+       "runs": runs, "notes": sys.argv[2:]}
+json.dump(out, open(os.path.join(ROOT, "profiles", ROUND + "_fuzz_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
