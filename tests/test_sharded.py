@@ -179,6 +179,20 @@ def _gpu_worker(rank, world, port, shape, partition, q):
             assert np.array_equal(pg.unpack().cpu().numpy(), p1.cpu().numpy() if comp == "1bit" else p2.cpu().numpy())
             pc = proc3d.vol2pcd(pg, origin, vs, 0.0, as_open3d=False)
             clouds[comp] = (np.asarray(pc.points), np.asarray(pc.normals))
+        # the pipeline bench.py times at N > 1: batches back to back, the collective of one beside the carve of the
+        # next (overlap=True: the engine waits for it only before it packs again), alternating receive buffers
+        recv = [torch.empty(sb.packed_rank_bytes(2) * world, dtype=torch.uint8, device=full.device) for _ in range(2)]
+        grids = []
+        for i in range(3):
+            sb.clear()
+            for K, R, t, m in (views if i != 1 else views[:5]):  # the middle batch is a different volume
+                sb.process_view(K, R, t, m)
+            grids.append(sb.all_gather(compress="2bit", recv=recv[i & 1], unpack=False, overlap=True))
+        sb.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(grids[2].unpack().cpu().numpy(), p2.cpu().numpy())          # the last batch: all the views again
+        assert np.array_equal(grids[0].unpack().cpu().numpy(), p2.cpu().numpy())          # recv[0] was rewritten by batch 2: same grid
+        assert not np.array_equal(grids[1].unpack().cpu().numpy(), p2.cpu().numpy())      # recv[1] holds the 5-view volume
         ref = proc3d.vol2pcd((full.cpu().numpy() == 1).astype(np.uint8), origin, vs, 0.0, as_open3d=False)
         for comp, (pts, nrm) in clouds.items():
             assert np.array_equal(pts, np.asarray(ref.points)) and np.array_equal(nrm, np.asarray(ref.normals)), comp
