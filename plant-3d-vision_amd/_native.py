@@ -781,16 +781,17 @@ class Engine:
         are returned instead of waited for, so the next volume's copy follows this one's at once (the ring remembers
         which of its slots still hold pieces in flight, across calls; one staged read-back at a time per process)."""
         from concurrent.futures import ThreadPoolExecutor
-        if out.dtype != self.dtype or out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
-            raise ValueError("output buffer has the wrong dtype/size/layout")
+        # (`out` may be of another dtype than the volume -- the reference's float64 label array: `fn` converts)
+        if out.size != int(np.prod(self.slab_shape)) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("output buffer has the wrong size/layout")
         flat = out.reshape(-1)
-        item = flat.itemsize
+        item = np.dtype(self.dtype).itemsize
         self.flush()
         src = self.values_device_ptr()  # (a snapshot without the row padding when the grid has some)
         self.synchronize()
         step = max(1, int(piece_bytes) // item)
         ring, state = staging_ring(step * item, slots, self.device)
-        ring = ring.view(flat.dtype)  # [slots][step]
+        ring = ring.view(self.dtype)  # [slots][step]
         nw = int(workers or host_workers())
         sub = max(1, step // nw)
         own = pool is None

@@ -387,6 +387,8 @@ class Backprojection(object):
         float64 array ``[len(labels), *shape]``; the first label is not cleared."""
         if self.labels is not None:
             result = np.zeros((len(self.labels), *self.shape))
+            if self._can_stage_labels():
+                return self._process_labels_staged(fs, camera_metadata, invert, result)
             # result[i, :] = volume (cl.py:254) is a 1 GiB float64 write per label at 512^3 and costs more
             # than the label's whole carve: it runs on a helper thread while the next label is decoded,
             # carved and read back into another buffer
@@ -409,8 +411,67 @@ class Backprojection(object):
         else:
             return self.process_label(fs, camera_metadata, None, invert=invert)
 
+    #: set by ``tasks.cl.voxels_run`` (ours, not the reference's) before ``process_fileset`` when the task will apply
+    #: ``np.exp`` + clip to the labelled result anyway (tasks/cl.py:172-174): the staged read-back below then applies
+    #: them piece by piece on its way into the float64 array, and ``_label_post_applied`` tells the task so
+    _label_post = None
+    _label_post_applied = False
+    _label_single_valued = None
+
+    def _can_stage_labels(self):
+        """One HIP engine (not a group of devices), a volume worth the pieces (``SC_LABELS_STAGED=0`` in the environment:
+        never -- the two-pass route of rounds 3-4, for A/B measurements)."""
+        return (isinstance(self._engine, nat.Engine) and hasattr(self._engine, "get_values_staged")
+                and int(np.prod(self.shape)) >= (1 << 24) and os.environ.get("SC_LABELS_STAGED", "1") != "0")
+
+    def _process_labels_staged(self, fs, camera_metadata, invert, result):
+        """The label loop of cl.py:248-255 with ONE pass over host memory per label (round 5): the label's volume
+        crosses PCIe in pieces into a page-locked ring, and host threads take each piece from there to its place in
+        the float64 ``result[i]`` -- the widening of ``result[i, :] = volume`` (cl.py:254) and, when the task has
+        announced them (``_label_post``), its ``np.exp`` + clip (tasks/cl.py:172-174: float64, on the widened values,
+        as the reference computes them) -- while the next pieces cross and, behind the last piece, while the next
+        label's masks are decoded and carved.  Same values as the two-pass route; the float32 host copy of a label
+        (``values_h``) is not made."""
+        post = self._label_post == "exp_clip"
+        state = {"first": None, "single": True}
+
+        def land(src, dst):
+            # (the reference looks at the result BEFORE the exponential for its "one value only" warning, tasks/cl.py:168)
+            if state["single"]:
+                if state["first"] is None:
+                    state["first"] = src[0]
+                f = state["first"]
+                same = bool(np.isnan(src[:4096]).all() and np.isnan(src).all()) if f != f else \
+                    bool((src[:4096] == f).all() and (src == f).all())
+                if not same:
+                    state["single"] = False
+            np.copyto(dst, src)  # float32 / int32 -> float64, exact
+            if post:
+                np.exp(dst, out=dst)
+                np.minimum(dst, 1.0, out=dst)  # vol[vol > 1] = 1 (NaN stays NaN)
+
+        futs = []
+        with ThreadPoolExecutor(max_workers=nat.host_workers()) as pool:
+            for i, label in enumerate(self.labels):
+                logger.info(f"Processing label '{label}'...")
+                if i != 0:
+                    self.clear()
+                self._submit_label(fs, camera_metadata, label, invert)
+                futs += self._engine.get_values_staged(result[i], land, pool=pool)
+                self._values_h = None
+            for f in futs:
+                f.result()
+        self._label_post_applied = post
+        self._label_single_valued = state["single"]
+        return result
+
     def process_label(self, fs, camera_metadata, label=None, invert=False):
         """Processes a whole fileset for a given label (cl.py:259-305)."""
+        self._submit_label(fs, camera_metadata, label, invert)
+        return self.get_values()
+
+    def _submit_label(self, fs, camera_metadata, label=None, invert=False):
+        """The file loop of ``process_label`` (cl.py:279-303): every selected view handed to the engine, nothing read back."""
         if hasattr(fs, "get_files") and not isinstance(fs, (list, tuple)):
             fs = fs.get_files()  # cl.py:279-280
 
@@ -433,7 +494,7 @@ class Backprojection(object):
             self._submit_view(intrinsics, rot, tvec, mask, invert)  # :300-303
 
         if self._submit_encoded(selected, invert):
-            return self.get_values()
+            return
         if self.decode_workers <= 1 or len(selected) <= 1:
             for fi, cam in selected:
                 submit(cam, read_image(fi))  # :298
@@ -455,8 +516,6 @@ class Backprojection(object):
                     if nxt is not None:
                         pending.append((nxt[1], pool.submit(read_image, nxt[0])))
                     submit(cam, mask)
-
-        return self.get_values()
 
     def _submit_encoded(self, selected, invert):
         """The file loop (cl.py:282-303) handed to the library in one call when it can take it: a carve volume on one

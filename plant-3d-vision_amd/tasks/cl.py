@@ -127,11 +127,20 @@ def voxels_run(masks_files, bounding_box, voxel_size=1.0, type="carving", log=Tr
 
     sc = backprojection_cls(shape=shape, origin=origin_list, voxel_size=float(voxel_size),
                             type=str(type), labels=use_labels, log=bool(log), device=device)
+    want_exp = bool(log) and type == "averaging"
+    if want_exp and use_labels is not None and hasattr(sc, "_label_post"):
+        # our own class: the labelled read-back applies np.exp + clip piece by piece on its way into the float64 array
+        # (Backprojection._process_labels_staged) -- announced here, confirmed by `_label_post_applied`
+        sc._label_post = "exp_clip"
     vol = sc.process_fileset(masks_files, str(camera_metadata), bool(invert))
-    if _single_valued(vol):  # tasks/cl.py:168, `len(np.unique(vol)) == 1`
+    staged = bool(getattr(sc, "_label_post_applied", False))
+    single = getattr(sc, "_label_single_valued", None)  # (the staged read-back has looked, before its exponential)
+    if single is None:
+        single = _single_valued(vol)
+    if single:  # tasks/cl.py:168, `len(np.unique(vol)) == 1` (looked at before the exponential, as there)
         logger.warning("There is something WRONG with the volume!")
 
-    if log and type == "averaging":  # tasks/cl.py:172-174
+    if want_exp and not staged:  # tasks/cl.py:172-174
         vol = _exp_clip(vol)
 
     if use_labels is not None:

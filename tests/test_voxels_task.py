@@ -297,3 +297,19 @@ def test_voxels_task_over_the_hip_engine_from_png_files(gpu_device, task_env_hip
         want = np.exp(oracle_c.average(shape, origin, 1.0, views_of("stem", lambda m: np.log(EPS + img_as_float32(m)))).astype(np.float64))
     want[want > 1] = 1.0
     assert kind == "npz" and np.array_equal(vol["stem"], want)
+    # ... and at a size where the labels come back through the staged pipeline (>= 2^24 voxels: Backprojection.
+    # _process_labels_staged -- pieces through a page-locked ring, widened to float64 and exponentiated on their way
+    # into the result): the same values as np.exp over the widened oracle sums, for both labels
+    from plant3dvision_amd.tasks.cl import grid_from_bounding_box
+    vs = 0.125
+    mod.Voxels(voxel_size=vs, camera_metadata="camera", type="averaging", labels=["stem", "background"]).run()
+    kind, vol = scan.fileset("Voxels")._files[-1].written
+    big_shape, big_origin = grid_from_bounding_box(bbox, vs)
+    assert kind == "npz" and int(np.prod(big_shape)) >= 1 << 24 and list(vol) == ["stem", "background"]
+    for ch in ("stem", "background"):
+        with np.errstate(divide="ignore"):
+            want = np.exp(oracle_c.average(list(big_shape), big_origin, vs, views_of(ch, lambda m: np.log(EPS + img_as_float32(m))),
+                                           nthreads=8).astype(np.float64))
+        want[want > 1] = 1.0
+        assert vol[ch].dtype == np.float64 and np.array_equal(vol[ch], want), ch
+        del want
