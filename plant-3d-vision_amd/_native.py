@@ -11,6 +11,7 @@ import importlib.util
 import os
 import subprocess
 import sys
+import threading
 
 import numpy as np
 
@@ -297,18 +298,19 @@ def pinned_empty(shape, dtype, device=0):
 
 
 _staging = {}
+_staging_lock = threading.Lock()
 
 
 def staging_ring(piece_bytes, slots=4, device=0):
     """(ring, state) -- ``slots`` page-locked pieces (one allocation per process and size, kept for its life): the
     landing place of ``Engine.get_values_staged``, and which slots still hold pieces in flight.  ~0.03 s for
     128 MiB the first time."""
-    import threading
     key = (int(piece_bytes), int(slots), int(device))
-    ent = _staging.get(key)
-    if ent is None:
-        ring = pinned_empty((int(slots), int(piece_bytes)), np.uint8, device=device)
-        ent = _staging[key] = (ring, {"next": 0, "busy": [[] for _ in range(int(slots))], "lock": threading.Lock()})
+    with _staging_lock:
+        ent = _staging.get(key)
+        if ent is None:
+            ring = pinned_empty((int(slots), int(piece_bytes)), np.uint8, device=device)
+            ent = _staging[key] = (ring, {"next": 0, "busy": [[] for _ in range(int(slots))], "lock": threading.Lock()})
     return ent
 
 
