@@ -1568,6 +1568,51 @@ def test_read_back_over_the_two_bit_wire(gpu_device):
         bp.close()
 
 
+def test_read_back_in_pieces_with_a_host_function_beside_the_copies(gpu_device):
+    """Engine.get_values_staged / get_values_pipelined (round 5): the volume crosses PCIe in pieces -- through a
+    page-locked ring, or straight into the destination -- and a host function takes every piece on host threads while
+    the next ones cross.  Same values as get_values + the function afterwards: float32 sums and int32 labels, a padded
+    grid (nz % 64 != 0: the device snapshot without the padding), pieces smaller and larger than the volume, a
+    destination of another dtype (the reference's float64 label array, cl.py:254), several volumes on one pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    shape, origin, vs, views = scene((37, 48, 70), 6, "plant")  # nz = 70: rows padded on the device
+    fviews = [(K, R, t, img_as_float32(m)) for K, R, t, m in views]
+    want_f = oracle_c.average(list(shape), origin, vs, fviews)
+    want_i = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    ea = nat.Engine(shape, origin, vs, nat.SC_MODE_AVERAGE)
+    for K, R, t, m in fviews:
+        ea.process_view(K, R, t, m, nat.SC_MASK_F32)
+    ec = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
+    for K, R, t, m in views:
+        ec.process_view(K, R, t, m, nat.SC_MASK_U8)
+
+    def exp_from(src, dst):
+        np.exp(src, out=dst)
+
+    def exp_in_place(piece):
+        np.exp(piece, out=piece)
+
+    for piece_bytes in (4096, 1 << 16, 1 << 26):
+        out = np.full(shape, 7, dtype=np.float32)
+        assert ea.get_values_staged(out, exp_from, piece_bytes=piece_bytes) is out
+        assert np.array_equal(out, np.exp(want_f)), piece_bytes
+        out = np.full(shape, 7, dtype=np.float32)
+        ea.get_values_pipelined(out, exp_in_place, piece_bytes=piece_bytes)
+        assert np.array_equal(out, np.exp(want_f)), piece_bytes
+    # another dtype at the destination: float64 <- float32 and float64 <- int32, widened by the function
+    out64 = np.zeros((2, *shape))  # float64, like result = np.zeros((len(labels), *shape)) (cl.py:250)
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        futs = ea.get_values_staged(out64[0], lambda src, dst: np.copyto(dst, src), piece_bytes=1 << 15, pool=pool)
+        futs += ec.get_values_staged(out64[1], lambda src, dst: np.copyto(dst, src), piece_bytes=1 << 15, pool=pool)
+        for f in futs:
+            f.result()
+    assert np.array_equal(out64[0], want_f.astype(np.float64)) and np.array_equal(out64[1], want_i.astype(np.float64))
+    with pytest.raises(ValueError):
+        ea.get_values_staged(np.zeros(5, dtype=np.float32), exp_from)
+    ea.close()
+    ec.close()
+
+
 @pytest.mark.parametrize("default_value", [0, 1, -1, 5])
 @pytest.mark.parametrize("kind", ["plant", "solid", "dense"])
 def test_bricks_no_view_sees_keep_their_labels(gpu_device, kind, default_value):
