@@ -1055,8 +1055,12 @@ def main():
     # N > 1: `value` = carve + assembly (t_device + collective), W warm-up and exactly K timed steps
     asm = None
     dt_asm = None
+    asm_error = None
     if collective and a.path == "fused":
-        dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, bits=2, overlap=True)
+        try:
+            dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, bits=2, overlap=True)
+        except Exception as ex:  # noqa: BLE001  (the line must still come out: `value` falls back to the carve alone, and says so)
+            asm_error = repr(ex)
     if collective and a.assembly_steps > 0:
         try:
             asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
@@ -1217,6 +1221,8 @@ def main():
                                "all-gather into alternating receive buffers, the collective of step k beside the carve of "
                                "step k + 1, everything waited for inside the timed region; the roofline object describes the "
                                "carve-only span")
+        if asm_error is not None:
+            out["value_is"] = "CARVE ONLY: the carve + assembly steps failed (%s)" % asm_error
         if asm is not None:
             out["assembly"] = asm
         if parity is not None:
