@@ -13,7 +13,7 @@
                                      compacted lists; 0: every view is applied densely           */
 
 #define SC_OPT_DENSE_VIEWS 6      /* views applied to every voxel before compaction (2)       */
-#define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (8)             */
+#define SC_OPT_STAGE1_VIEWS 7     /* views applied to the first survivor list (6; 8 until round 5) */
 #define SC_OPT_LIST_BLOCKS 8      /* persistent grid of list stages without store blocks (2048)              */
 #define SC_OPT_VIEW_GROUP 9       /* the spans of the final survivor stage are a multiple of this many views (2) */
 #define SC_OPT_BRICK 10           /* 1 (default): for grids with nz <= 4096 and < 2^31 voxels the dense stage
@@ -24,7 +24,7 @@
                                      view, whole picture rows read in a piece (pictures up to 2048 pixels wide, wider
                                      ones take the panel form) --; 1, 2, 4, 8: the panel form, 128-pixel panels of that
                                      many tile rows per block; 3: bands for every picture up to 2048 pixels wide     */
-#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1280): the -1 fill of bricks found empty is done by
+#define SC_OPT_DEFER_STORES 14    /* n > 0 (default 1536): the -1 fill of bricks found empty is done by
                                      store blocks running beside n persistent blocks of the final
                                      survivor stage; 0: by the dense stage                          */
 #define SC_OPT_DEFER_SHARE 15     /* sixteenths of the strips filled by the final stage (16); 0: none */
@@ -36,12 +36,12 @@
                                      (one 128-byte line each) with per-region uniformity, and take the brick
                                      form too (a footprint over ONE value adds it without projecting);
                                      0: gathered row-major as handed over                                  */
-#define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (4) */
+#define SC_OPT_STAGE1_STORE_SHARE 17 /* sixteenths of those strips filled beside the FIRST survivor stage (5) */
 #define SC_OPT_STAGE1_LIST_BLOCKS 21 /* persistent list blocks of that stage when it carries a share (1280)   */
 #define SC_OPT_PACK_RIDE 22        /* 1 (default): a batch of device-resident 1-byte masks (sc_process_views_device)
                                      is packed when it is launched, in the order its views are applied: the
                                      first ones ahead, the rest beside the dense stage; 0: all at enqueue    */
-#define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1024) */
+#define SC_OPT_BRICK_WALKERS 23    /* persistent blocks of the dense stage when packing rides beside it (1280) */
 #define SC_OPT_FILL_BLOCKS 25      /* store blocks of a list stage: 0 one short block per strip of bricks, n > 0
                                      that many persistent blocks walking the strips (256 = one per CU: a
                                      wavefront's stores do not hold it up, so few keep the write path busy;

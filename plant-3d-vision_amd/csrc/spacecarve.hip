@@ -177,11 +177,12 @@ struct sc_engine {
     size_t verd_cap = 0;
     uint32_t *verdf = nullptr;    // ... and, for tiled float32 masks, the value a flat footprint adds
     size_t verdf_cap = 0;
-    int64_t stage1_store_share = 4;  // sixteenths of the deferred strips filled beside the FIRST list stage
+    int64_t stage1_store_share = 5;  // sixteenths of the deferred strips filled beside the FIRST list stage
     int64_t stage1_list_blocks = 1280; // ... and that stage's persistent list blocks then
     int64_t defer_share = 16;     // sixteenths of the strips whose empty bricks the final list stage fills
-    int64_t defer_stores = 1280;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them);
-                                  // 5 per CU beside 2 store blocks: 1024 -> 1280 is worth 4-5 % on bulky scenes, nothing on a plant; 1536 loses
+    int64_t defer_stores = 1536;  // list blocks of a final stage that also fills the empty bricks (0: the dense stage fills them);
+                                  // 6 per CU beside the store blocks: with six first-stage views 1280 -> 1536 is worth 3-4 % on bulky scenes
+                                  // and nothing on a plant (round 5's last sweep, tools/sweep_blocks*.json); 1600 and more lose 7 % there
     int64_t pack_rows = 0;     // 0: the band form of the 16-byte pack kernel; 1, 2, 4, 8: the panel form, tile rows per block
     int64_t view_brick = 1;    // a single-view carve launch goes through the brick kernels too (0: streaming kernel)
     uint8_t *dead = nullptr;   // per brick: an earlier launch found it empty, every voxel is -1 (until the next clear)
@@ -191,7 +192,7 @@ struct sc_engine {
     int64_t fill_blocks = 256; // persistent store blocks of a list stage (0: one short block per strip); round 4: 256 (one per CU) from 512, measured after their loop lost its vector instructions
     int64_t pack_ride = 1;     // a device batch is packed at flush, in view order: the first views ahead of
                                // the flags kernel, the others beside the dense stage (0: all ahead)
-    int64_t brick_walkers = 1024;  // persistent blocks of the dense stage when packing rides with it
+    int64_t brick_walkers = 1280;  // persistent blocks of the dense stage when packing rides with it (1024 until round 5: noise -4 %, plant +-0)
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *packed_labels = nullptr;  // sc_values_packed: the labels at 2 or 1 bits each
     uint32_t *wire_stage = nullptr;     // sc_get_values_wire2: page-locked landing place of the packed labels
@@ -262,7 +263,7 @@ struct sc_engine {
     int64_t compact = 1;
     int64_t brick = 1;
     int64_t dense_views = 2;     // views applied to every voxel before compaction
-    int64_t stage1_views = 8;    // views applied to the first survivor list
+    int64_t stage1_views = 6;    // views applied to the first survivor list (8 until round 5)
     int64_t stage2_views = 0;    // views applied to the second survivor list (0: no such stage)
     int64_t list_blocks = 2048;  // persistent grid of list stages without store blocks
     int64_t view_group = 2;      // the spans of the final list stage are a multiple of this many views

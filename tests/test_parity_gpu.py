@@ -304,6 +304,7 @@ def test_brick_culling_is_exact(gpu_device, shape, kw, kind):
     {"SC_OPT_DEFER_SHARE": 2, "SC_OPT_FILL_BLOCKS": 0},
     {"SC_OPT_FILL_BLOCKS": 64, "SC_OPT_DEFER_SHARE": 11, "SC_OPT_STAGE1_STORE_SHARE": 3},  # few store blocks, odd shares
     {"SC_OPT_DENSE_VIEWS": 3, "SC_OPT_UNIT_CULL": 0},
+    {"SC_OPT_DEFER_STORES": 1280, "SC_OPT_STAGE1_VIEWS": 8, "SC_OPT_STAGE1_STORE_SHARE": 4, "SC_OPT_BRICK_WALKERS": 1024},  # rounds 3-5's defaults
 ])
 @pytest.mark.parametrize("kind,shape", [("plant", (24, 32, 128)), ("noise", (6, 16, 64)), ("plant", (9, 48, 192)),
                                         ("dense", (14, 48, 192)),    # a bulky object: whole-brick masks at work

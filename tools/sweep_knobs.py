@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-knob-at-a-time sweep of the fused carve on the plant scene (GPU box): ms per batch by option value, three
+"""One-knob-at-a-time sweep of the fused carve on a scene (plant, dense, noise, solid, literal; GPU box): ms per batch by option value, three
 repeats each, the best kept.  usage: python tools/sweep_knobs.py [scene] [sets.json] > out.json"""
 import json
 import os
@@ -33,7 +33,10 @@ def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "plant"
     if len(sys.argv) > 2:  # a sweep of one's own: a JSON list of {option: value} sets
         SWEEP = [tuple(d.items()) for d in json.load(open(sys.argv[2]))]
-    shape, origin, vs, views = scenes.make_scene(512, 72, kind)
+    if kind == "literal":  # the reference's own configuration: 301 x 301 x 561 voxels, 60 views
+        shape, origin, vs, views = scenes.literal_real_plant_scene(60, "plant")
+    else:
+        shape, origin, vs, views = scenes.make_scene(512, 72, kind)
     stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
     K = np.stack([v[0] for v in views]); R = np.stack([v[1] for v in views]); t = np.stack([v[2] for v in views])
     V, H, W = stack.shape
