@@ -350,23 +350,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void c
             const uint32_t unit = it.x >> 1, lb = unit >> 2;
             const uint32_t il = lb / per_plane, rem = lb - il * per_plane;
             const uint32_t by = rem / ui.bricks_z, bz = rem - by * ui.bricks_z;
-            // half h of a unit: its columns 8 h .. 8 h + 7; lane = (column & 3) * 16 + voxel, p = column >> 2
-            const uint32_t j0 = by * kBrickY + (it.x & 1u) * 8u + (lane >> 4), k = bz * kBrickZ + (unit & 3u) * 16u + (lane & 15u);
+            // half h of a unit: its columns 8 h .. 8 h + 7; lane = column * 8 + (voxel & 7), p = voxel >> 3: a lane's two
+            // voxels share their column, so the x and y terms of a view's three sums are computed once for both
+            const uint32_t j = by * kBrickY + (it.x & 1u) * 8u + (lane >> 3), k0 = bz * kBrickZ + (unit & 3u) * 16u + (lane & 7u);
             const float x = g.ox + (float)(int)(il * g.istride + g.i0) * g.vs;  // backprojection.c:71-73
-            const float z = g.oz + (float)(int)k * g.vs;
+            const float y = g.oy + (float)(int)j * g.vs;
             uint32_t idx[2];
             unsigned long long alive_m[2], zero_m[2];
-            float y[2];
+            float z[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const uint32_t j = j0 + 4u * (uint32_t)p;
+                const uint32_t k = k0 + 8u * (uint32_t)p;
                 const bool inside = j < g.ny && k < g.nz;
                 idx[p] = (il * g.ny + j) * g.nzp + k;
                 int32_t lab = -1;
                 if (inside) lab = labels[idx[p]];
                 alive_m[p] = __ballot(lab != -1);
                 zero_m[p] = __ballot(lab == 0);
-                y[p] = g.oy + (float)(int)j * g.vs;
+                z[p] = g.oz + (float)(int)k * g.vs;
             }
             unsigned long long m = ((unsigned long long)it.w << 32) | it.z;
             const uint32_t vbase = it.y;
@@ -382,16 +383,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void c
                 unsigned long long okm[2][2];
                 uint32_t w[2][2];
                 int sh[2][2];
+                // both descriptors in scalar registers before either view projects: one scalar-load round trip per turn
+                const ViewDesc dq[2] = {scalar_desc(ui.views, vbase + a), scalar_desc(ui.views, vbase + b)};  // (`ui.views`: a pointer inside a struct)
+                asm volatile("" ::"s"(dq[0].Wf), "s"(dq[0].Hf), "s"(dq[0].tiles_x), "s"(dq[0].mask), "s"(dq[0].R[0]), "s"(dq[0].K[0]), "s"(dq[0].t[0]),
+                             "s"(dq[1].Wf), "s"(dq[1].Hf), "s"(dq[1].tiles_x), "s"(dq[1].mask), "s"(dq[1].R[0]), "s"(dq[1].K[0]), "s"(dq[1].t[0]));
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const ViewDesc d = scalar_desc(ui.views, vbase + (q ? b : a));  // (`ui.views`: a pointer inside a struct)
-                    asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
+                    const ViewDesc &d = dq[q];
                     const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         int vv;
-                        const bool ok = project<ALL_SAFE>(d.R[0] * x + d.R[1] * y[p], d.R[3] * x + d.R[4] * y[p],
-                                                          d.R[6] * x + d.R[7] * y[p], z, d, sh[q][p], vv, okm[q][p]);
+                        const bool ok = project<ALL_SAFE>(d.R[0] * x + d.R[1] * y, d.R[3] * x + d.R[4] * y,
+                                                          d.R[6] * x + d.R[7] * y, z[p], d, sh[q][p], vv, okm[q][p]);
                         w[q][p] = 0;
                         if (ok) w[q][p] = load_mask_at(d.mask, mask_byte_offset(sh[q][p], vv, tile_row));
                     }

@@ -12,4 +12,5 @@ STEPS=${4:-40}
 for rep in $(seq $REPS); do
   SPACECARVE_LIB=$R/build/prev/plant-3d-vision_amd/libspacecarve.so python3 tools/bench_scenes.py --steps $STEPS --scenes $SC --tag prev 2>/dev/null | tail -1
   python3 tools/bench_scenes.py --steps $STEPS --scenes $SC --tag new $1 2>/dev/null | tail -1
+  echo "rep $rep done" >&2
 done

@@ -13,5 +13,6 @@ for rep in $(seq $REPS); do
     else
       SPACECARVE_LIB=$R/$lib python3 tools/bench_scenes.py --steps $STEPS --scenes $SC --tag $(basename $lib .so) $5 2>/dev/null | tail -1
     fi
+    echo "rep $rep $lib done" >&2
   done
 done
