@@ -14,7 +14,7 @@ __device__ __forceinline__ void two_views(const ViewDesc &da, const ViewDesc &db
                                           const float (&z)[4], unsigned long long (&alive)[4], unsigned long long (&kept)[4]) {
     const float aax = da.R[0] * x + da.R[1] * y, aay = da.R[3] * x + da.R[4] * y, aaz = da.R[6] * x + da.R[7] * y;
     const float bax = db.R[0] * x + db.R[1] * y, bay = db.R[3] * x + db.R[4] * y, baz = db.R[6] * x + db.R[7] * y;
-    const uint32_t rowa = (uint32_t)da.tiles_x * 4u, rowb = (uint32_t)db.tiles_x * 4u;
+    const uint32_t rowa = (uint32_t)da.strip, rowb = (uint32_t)db.strip;
     unsigned long long oka[4], okb[4];
     uint32_t wa[4], wb[4];
     int sha[4], shb[4];

@@ -258,8 +258,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void c
                 // every field in scalar registers NOW: left alone the compiler fetches Wf/Hf,
                 // tiles_x and the mask pointer one by one where they are first used, three
                 // more scalar-load round trips inside each projection
-                asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.tiles_x), "s"(d.mask));
-                const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
+                asm volatile("" ::"s"(d.Wf), "s"(d.Hf), "s"(d.strip), "s"(d.mask));
+                const uint32_t tile_row = (uint32_t)d.strip;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     int vv;
@@ -385,12 +385,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void c
                 int sh[2][2];
                 // both descriptors in scalar registers before either view projects: one scalar-load round trip per turn
                 const ViewDesc dq[2] = {scalar_desc(ui.views, vbase + a), scalar_desc(ui.views, vbase + b)};  // (`ui.views`: a pointer inside a struct)
-                asm volatile("" ::"s"(dq[0].Wf), "s"(dq[0].Hf), "s"(dq[0].tiles_x), "s"(dq[0].mask), "s"(dq[0].R[0]), "s"(dq[0].K[0]), "s"(dq[0].t[0]),
-                             "s"(dq[1].Wf), "s"(dq[1].Hf), "s"(dq[1].tiles_x), "s"(dq[1].mask), "s"(dq[1].R[0]), "s"(dq[1].K[0]), "s"(dq[1].t[0]));
+                asm volatile("" ::"s"(dq[0].Wf), "s"(dq[0].Hf), "s"(dq[0].strip), "s"(dq[0].mask), "s"(dq[0].R[0]), "s"(dq[0].K[0]), "s"(dq[0].t[0]),
+                             "s"(dq[1].Wf), "s"(dq[1].Hf), "s"(dq[1].strip), "s"(dq[1].mask), "s"(dq[1].R[0]), "s"(dq[1].K[0]), "s"(dq[1].t[0]));
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const ViewDesc &d = dq[q];
-                    const uint32_t tile_row = (uint32_t)d.tiles_x * 4u;
+                    const uint32_t tile_row = (uint32_t)d.strip;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         int vv;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void project_selftest_kernel(uint64_t count
 #pragma unroll
             for (int q = 0; q < 3; ++q) d.t[q] = r.t[q];
             d.mask = nullptr; d.occ = nullptr; d.W = r.W; d.H = r.H; d.tiles_x = 0; d.pad = 0;
-            d.safe = r.pad[0]; d.pad2 = 0;  // certified by the host for the box the samples come from
+            d.safe = r.pad[0]; d.strip = 0;  // certified by the host for the box the samples come from
             d.Wf = (float)r.W; d.Hf = (float)r.H;
             // exactly what the voxel kernels do: coordinates as backprojection.c:71-73, the x / y
             // partial sums of the three dot products first (the reference's own association)
@@ -298,13 +298,13 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(const T *__restrict__ raw,
     unsigned long long vote = __ballot(fg);
     uint32_t *o = out + view * out_view_words;
     uint32_t base = (uint32_t)(v >> 5) * (uint32_t)tiles_x;
-    uint32_t rowin = (uint32_t)(v & 31);
+    const size_t strip = (size_t)tiles_y * 32u;  // tile (tx, ty) at word tx * strip + 32 ty: row v of strip tx at tx * strip + v
     uint8_t *oc = occ + (int64_t)view * tiles_x * tiles_y;  // zeroed by the host; racing stores all write 1
     if (lane == 0) {
-        o[(base + seg * 2) * 32u + rowin] = (uint32_t)vote;
+        o[(size_t)(seg * 2) * strip + (uint32_t)v] = (uint32_t)vote;
         if ((uint32_t)vote) oc[base + seg * 2] = 1;
     } else if (lane == 32 && seg * 2 + 1 < tiles_x) {
-        o[(base + seg * 2 + 1) * 32u + rowin] = (uint32_t)(vote >> 32);
+        o[(size_t)(seg * 2 + 1) * strip + (uint32_t)v] = (uint32_t)(vote >> 32);
         if ((uint32_t)(vote >> 32)) oc[base + seg * 2 + 1] = 1;
     }
 }

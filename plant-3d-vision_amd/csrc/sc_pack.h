@@ -89,7 +89,7 @@ __device__ __forceinline__ void pack16_block(const PackJob &pj, uint32_t b) {
         uint32_t other = __shfl_xor(half, 1);
         uint32_t word = half | (other << 16);
         if ((c & 1) == 0 && tx < tiles_x && ty < tiles_y)
-            pj.out[(int64_t)slot * pj.out_view_words + ((int64_t)ty * tiles_x + tx) * 32 + row] = word;
+            pj.out[(int64_t)slot * pj.out_view_words + ((int64_t)tx * tiles_y + ty) * 32 + row] = word;  // strip tx, tile ty of it
         // 8x8-pixel cells: this wavefront holds rows 8w .. 8w + 7 of the tile (cell row w), lane 8r + c the
         // pixels 16c .. 16c + 15 of row r -- two cells' worth.  Four ballots; bit c + 8r of each belongs to
         // lane 8r + c, so lane c < 8 reads off its two cells over the eight rows.
@@ -181,10 +181,11 @@ __device__ __forceinline__ void pack_band_block(const PackJob &pj, uint32_t b) {
         }
     }
     __syncthreads();
-    // the band's tiles: tiles_x * 32 words in a row in the packed arena
-    uint4 *out = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * tiles_x * 32);
+    // the band's tiles: tile tx of it is tile ty of strip tx in the packed arena (8 pieces of 16 bytes each)
+    uint4 *out = reinterpret_cast<uint4 *>(pj.out + (int64_t)slot * pj.out_view_words + (int64_t)ty * 32);
     const uint4 *src = reinterpret_cast<const uint4 *>(band_s);
-    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) out[i] = src[i];
+    const uint32_t strip4 = (uint32_t)pj.tiles_y * 8u;  // a strip in 16-byte pieces
+    for (uint32_t i = tid; i < (uint32_t)tiles_x * 8u; i += kBlock) out[(size_t)(i >> 3) * strip4 + (i & 7u)] = src[i];
     // The 8x8-pixel cells from the finished words (round 5; until then every task worked out its two cells' flags and
     // sent them to LDS atomics: a third of the packer's instructions): thread 4 t + cy takes cell row cy of tile t --
     // the OR and the AND of its eight words, a byte of them per cell -- and the four threads of a tile join their
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void bits_tiles_kernel(const char *__restri
     const uint32_t *bits = reinterpret_cast<const uint32_t *>(arena + rec.src_off);
     uint32_t word = 0u;
     if (have && v < (uint32_t)rec.H) word = bits[(size_t)v * (uint32_t)rec.tiles_x + tx];
-    if (have) rec.tiles[(size_t)t * 32u + r] = word;
+    if (have) rec.tiles[((size_t)tx * (uint32_t)rec.tiles_y + ty) * 32u + r] = word;  // strip tx, tile ty of it
     // cells: row of cells r >> 3, column of cells = the byte of the word
     unsigned long long anyf[4], anyb[4];
 #pragma unroll

@@ -123,10 +123,13 @@ __device__ __forceinline__ bool project(float ax, float ay, float az, float z, c
     return project<ALL_SAFE>(ax, ay, az, z, d, u, v, okm);
 }
 
-__device__ __forceinline__ uint32_t mask_word_index(int u, int v, int tiles_x) {
-    // all factors are < 2^24 for in-image pixels: the 24-bit multiply is full rate
-    return (__umul24((uint32_t)(v >> 5), (uint32_t)tiles_x) + (uint32_t)(u >> 5)) * 32u +
-           (uint32_t)(v & 31);
+// The bit tiles of a carve mask lie STRIP BY STRIP (round 5's end; row by row of tiles until then): a strip is 32
+// pixels wide and as tall as the picture rounded up to whole tiles, its rows one word each, one after the other -- a
+// 128-byte line is the same 32 x 32-pixel tile as before, and pixel (u, v) is bit u & 31 of word
+// (u >> 5) * strip + v: a shift, a 24-bit multiply-add and the scaling, where the tile order took four
+// instructions with a v_bfi among them.  strip = 32 x tile rows < 2^24 (check_view_args), u >> 5 < 2^19.
+__device__ __forceinline__ uint32_t mask_word_index(int u, int v, int strip) {
+    return __umul24((uint32_t)u >> 5, (uint32_t)strip) + (uint32_t)v;
 }
 
 // The mask pointer comes out of a descriptor, so the compiler cannot tell its address space and
@@ -137,13 +140,9 @@ __device__ __forceinline__ uint32_t load_mask_word(const void *mask, uint32_t wo
 }
 
 // The same as a BYTE offset, for loads of the form  scalar base + 32-bit lane offset  (no 64-bit address arithmetic per
-// lane): tile row v >> 5 starts at (v & ~31) * tile_row bytes with tile_row = 4 * tiles_x (a row of tiles is
-// 128 * tiles_x bytes), tile u >> 5 of it at (u & ~31) * 4, row v & 31 of the tile at (v & 31) * 4.  Both factors of the
-// product are below 2^24 (check_view_args: H <= 2^24, W <= 2^24) and a view's bits are below 2^32 bytes (H W <= 2^34).
-__device__ __forceinline__ uint32_t mask_byte_offset(int u, int v, uint32_t tile_row) {
-    uint32_t in_row;  // (u & ~31) | (v & 31): one v_bfi_b32 (left to itself the compiler makes v_and + v_and_or of it)
-    asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(in_row) : "v"(v), "v"(u));
-    return __umul24((uint32_t)v & ~31u, tile_row) + (in_row << 2);
+// lane); a view's bits are below 2^32 bytes (H W <= 2^34).
+__device__ __forceinline__ uint32_t mask_byte_offset(int u, int v, uint32_t strip) {
+    return (__umul24((uint32_t)u >> 5, strip) + (uint32_t)v) << 2;
 }
 typedef const __attribute__((address_space(1))) char *gbytes_t;
 __device__ __forceinline__ uint32_t load_mask_at(const void *mask, uint32_t byte_offset) {

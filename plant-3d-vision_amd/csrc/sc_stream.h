@@ -71,7 +71,7 @@ __device__ __forceinline__ void carve_group(int32_t *__restrict__ labels, const 
             ok[e] = project(ax, ay, az, z[e], d, u, v) & ((alive >> e) & 1u);
             sh[e] = u & 31;
             // unconditional gather (word 0 when the voxel is out): no branch per element
-            w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u, v, d.tiles_x) : 0u);
+            w[e] = load_mask_word(bits, ok[e] ? mask_word_index(u, v, d.strip) : 0u);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

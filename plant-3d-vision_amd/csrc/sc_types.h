@@ -6,7 +6,7 @@ struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave
     float K[4];     // fx fy cx cy
     float R[9];     // row-major
     float t[3];
-    const void *mask;  // carve: tiled bit words; average: float32 [H][W]
+    const void *mask;  // carve: bit words, 32 x 32-pixel tiles strip by strip (tile (tx, ty) at word tx * strip + 32 ty); average: tiled bytes / floats
     int32_t W, H;
     int32_t tiles_x;
     int32_t pad;
@@ -14,7 +14,7 @@ struct ViewDesc {   // 128 bytes, read with scalar loads (the view index is wave
     const uint8_t *occ;  // carve: one byte per 32x32 tile: bit 0 some foreground, bit 1 only foreground
     int32_t safe;        // certify_view(): every voxel centre of the grid has 2^-10 < pz and |px|, |py|, pz < 2^30
                          // under this pose, and the intrinsics are finite and below 2^30 (see project())
-    int32_t pad2;
+    int32_t strip;       // carve: the words of a 32-pixel-wide STRIP of the bit tiles = 32 x tile rows (mask_byte_offset)
     const uint32_t *cmask;  // carve, 16-byte pack form: per 32x32 tile the 4x4 map of its 8x8-pixel CELLS -- bits 0..15
                             // "cell holds some foreground", bits 16..31 "cell holds some background" (cell (cx, cy) of
                             // the tile at bit cy * 4 + cx; padding counts as background); null: no cell level

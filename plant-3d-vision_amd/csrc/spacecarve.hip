@@ -516,7 +516,7 @@ void fill_desc(const sc_engine *e, ViewDesc &d, const float *K, const float *R, 
     d.Hf = (float)H;
     const int64_t first[3] = {0, 0, 0}, last[3] = {e->nx - 1, e->ny - 1, e->nz - 1};  // the global grid: any partition of it is inside
     d.safe = certify_view(K, R, t, e->origin, e->vs, first, last);
-    d.pad2 = 0;
+    d.strip = ((H + kTile - 1) / kTile) * kTile;  // the words of a strip of the bit tiles (carve masks)
     d.cmask = nullptr;
     d.reserved = 0;
 }
@@ -1538,7 +1538,8 @@ int check_view_args(const sc_engine *e, const float *K, const float *R, const fl
                     const void *mask, int H, int W) {
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     if (!K || !R || !t || !mask) return fail(SC_ERR_INVALID, "null view argument");
-    if (H <= 0 || W <= 0 || H > (1 << 24) || W > (1 << 24) || (int64_t)H * W > ((int64_t)1 << 34))  // (a view's bits: below 2^32 bytes)
+    // (a view's bits: below 2^32 bytes; the words of a strip of its bit tiles, H rounded up to 32: below 2^24)
+    if (H <= 0 || W <= 0 || H > (1 << 24) - 32 || W > (1 << 24) || (int64_t)H * W > ((int64_t)1 << 34))
         return fail(SC_ERR_INVALID, "bad mask shape %d x %d", H, W);
     return SC_OK;
 }
