@@ -946,7 +946,7 @@ int hostbits_push_view(sc_engine *e, const float *K, const float *R, const float
 // device pass over the bits at the next flush (bits_tiles_kernel).  Appends one pending view.
 int enqueue_hostbits(sc_engine *e, const float *K, const float *R, const float *t, const void *mask, int H, int W,
                      int dtype, int64_t row_stride) {
-    const int wpr = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    const int wpr = (W + kTile - 1) / kTile;
     const size_t bits_bytes = ((size_t)H * wpr * 4 + 255) & ~(size_t)255;
     char *dst = nullptr;
     int rc = hostbits_reserve(e, bits_bytes, &dst);
