@@ -438,6 +438,10 @@ def extra_scenes(a, nat, torch, eng, shape, masks_dev, steps):
     from plant3dvision_amd import scenes
     out = {}
     n_local = eng.num_voxels()
+    # (3 x --extra-steps per run since round 5: a run carries ~90 us of launch and wake-up latency on the host's
+    # clock whatever its length -- 4 % of a 0.2 ms batch over 10 steps, what tools/bench_scenes.py's 40-step runs
+    # read lower than this line did)
+    steps = 3 * steps
     for kind in ("dense", "solid", "noise"):
         _, _, _, views = scenes.make_scene(tuple(shape), a.views, kind)
         V = len(views)
