@@ -161,6 +161,7 @@ int sc_order_before(sc_engine *e, void *consumer_stream);
  * Carve masks (cl.py:215 + backprojection.c:79: a pixel counts when it is != 0) are reduced to 1 bit per pixel on
  * the library's host threads during the call and cross PCIe as bits, one copy per flush (sc_hostpack_bits is that
  * bit form by itself; SC_OPT_HOST_PACK 0: the bytes travel and are packed on the device).
+ * Picture sizes: 1 <= H <= 2^24 - 32, 1 <= W <= 2^24, H W <= 2^34; else SC_ERR_INVALID ("bad mask shape").
  */
 int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
                     const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes);
