@@ -37,6 +37,9 @@ def load():
     common_tail = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
     lib.oracle_carve_view.argtypes = [ip, ip, fp, fp, fp, fp, ip] + common_tail
     lib.oracle_carve_view.restype = ctypes.c_int
+    lib.oracle_carve_view_planes.argtypes = [ip, ip, fp, fp, fp, fp, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    lib.oracle_carve_view_planes.restype = ctypes.c_int
     lib.oracle_average_view.argtypes = [fp, ip, fp, fp, fp, fp, fp] + common_tail
     lib.oracle_average_view.restype = ctypes.c_int
     lib.oracle_project.argtypes = [ip, ctypes.c_int64, fp, fp, fp, fp, ctypes.c_int,
@@ -115,6 +118,24 @@ def carve(shape, origin, voxel_size, views, default_value=0, nthreads=1):
     for K, R, t, mask in views:
         vol.process_view(K, R, t, mask, nthreads=nthreads)
     return vol.values
+
+
+def carve_planes(shape, origin, voxel_size, views, first, stride, nplanes, default_value=0, nthreads=1):
+    """A rank's share of the carve: planes first, first + stride, ... (nplanes of them) of the
+    [nx][ny][nz] grid, coordinates from the GLOBAL plane index.  Returns int32 [nplanes][ny][nz]."""
+    lib = load()
+    shape_h = np.array([int(s) for s in shape], dtype=np.int32)
+    volinfo = np.array([*origin, voxel_size], dtype=np.float32)
+    labels = np.full((int(nplanes), int(shape[1]), int(shape[2])), default_value, dtype=np.int32)
+    for K, R, t, mask in views:
+        K, R, t = _f32(K, 4), _f32(R, 9), _f32(t, 3)
+        H, W = mask.shape
+        mask_h = np.ascontiguousarray(mask, dtype=np.int32)  # cl.py:215
+        rc = lib.oracle_carve_view_planes(_ip(labels), _ip(shape_h), _fp(volinfo), _fp(K), _fp(R), _fp(t),
+                                          _ip(mask_h), W, H, int(first), int(stride), int(nplanes), int(nthreads))
+        if rc != 0:
+            raise RuntimeError(f"oracle returned {rc}")
+    return labels
 
 
 def average(shape, origin, voxel_size, views, default_value=0, nthreads=1):

@@ -103,7 +103,20 @@ typedef struct {
     const void *mask;
     int W, H;
     int64_t begin, end;
+    /* the state may hold only some x-planes of the grid (a rank's share): local plane p is
+     * plane first + p * stride of the grid; begin / end count the elements of the state */
+    int64_t first, stride;
 } job_t;
+
+/* flat index in the whole grid (what get_global_id(0) is in backprojection.c:59) of element idx of the state */
+static int64_t global_index(const job_t *jb, int64_t idx) {
+    if (jb->first == 0 && jb->stride == 1) {
+        return idx;
+    }
+    int64_t plane = (int64_t)jb->shape[1] * jb->shape[2];
+    int64_t p = idx / plane;
+    return (jb->first + p * jb->stride) * plane + (idx - p * plane);
+}
 
 /* backprojection.c:57-84 over idx in [begin, end) */
 static void carve_range(const job_t *jb) {
@@ -111,7 +124,7 @@ static void carve_range(const job_t *jb) {
     const int32_t *mask = (const int32_t *)jb->mask;
     const float *vi = jb->volinfo;
     for (int64_t idx = jb->begin; idx < jb->end; ++idx) {
-        int3_t ijk = unravel_index(idx, jb->shape);
+        int3_t ijk = unravel_index(global_index(jb, idx), jb->shape);
         if (labels[idx] == -1) { /* :67 */
             continue;
         }
@@ -136,7 +149,7 @@ static void average_range(const job_t *jb) {
     const float *mask = (const float *)jb->mask;
     const float *vi = jb->volinfo;
     for (int64_t idx = jb->begin; idx < jb->end; ++idx) {
-        int3_t ijk = unravel_index(idx, jb->shape);
+        int3_t ijk = unravel_index(global_index(jb, idx), jb->shape);
         float x = vi[0] + ijk.x * vi[3];
         float y = vi[1] + ijk.y * vi[3];
         float z = vi[2] + ijk.z * vi[3];
@@ -161,14 +174,18 @@ static void *worker(void *arg) {
 
 static int run_view(int mode, void *state, const int32_t *shape, const float *volinfo,
                     const float *K, const float *R, const float *t, const void *mask, int W,
-                    int H, int64_t begin, int64_t end, int nthreads) {
+                    int H, int64_t begin, int64_t end, int nthreads, int64_t first, int64_t stride,
+                    int64_t nplanes) {
     if (!state || !shape || !volinfo || !K || !R || !t || !mask) {
         return -1;
     }
     if (shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0 || W <= 0 || H <= 0) {
         return -2;
     }
-    int64_t n = (int64_t)shape[0] * shape[1] * shape[2];
+    if (first < 0 || stride < 1 || nplanes < 0 || (nplanes > 0 && first + (nplanes - 1) * stride >= shape[0])) {
+        return -4;
+    }
+    int64_t n = nplanes * shape[1] * shape[2];
     if (begin < 0) begin = 0;
     if (end < 0 || end > n) end = n;
     if (nthreads < 1) nthreads = 1;
@@ -190,6 +207,8 @@ static int run_view(int mode, void *state, const int32_t *shape, const float *vo
         jb->H = H;
         jb->begin = begin + span * w / nthreads;
         jb->end = begin + span * (w + 1) / nthreads;
+        jb->first = first;
+        jb->stride = stride;
     }
     if (nthreads == 1) {
         worker(&jobs[0]);
@@ -213,14 +232,25 @@ static int run_view(int mode, void *state, const int32_t *shape, const float *vo
 int oracle_carve_view(int32_t *labels, const int32_t *shape, const float *volinfo,
                       const float *K, const float *R, const float *t, const int32_t *mask,
                       int W, int H, int64_t begin, int64_t end, int nthreads) {
-    return run_view(0, labels, shape, volinfo, K, R, t, mask, W, H, begin, end, nthreads);
+    return run_view(0, labels, shape, volinfo, K, R, t, mask, W, H, begin, end, nthreads, 0, 1, shape ? shape[0] : 0);
+}
+
+/*
+ * The same launch over a rank's planes only (multi-GPU sharding): labels holds nplanes planes,
+ * local plane p being plane first + p * stride of the [nx][ny][nz] grid; every voxel's coordinates come from its
+ * index in the WHOLE grid, as get_global_id(0) would give them (backprojection.c:59, 71-73).
+ */
+int oracle_carve_view_planes(int32_t *labels, const int32_t *shape, const float *volinfo, const float *K,
+                             const float *R, const float *t, const int32_t *mask, int W, int H, int64_t first,
+                             int64_t stride, int64_t nplanes, int nthreads) {
+    return run_view(0, labels, shape, volinfo, K, R, t, mask, W, H, -1, -1, nthreads, first, stride, nplanes);
 }
 
 /* One `average` launch; values float32[nx*ny*nz], mask float32[H*W]. */
 int oracle_average_view(float *values, const int32_t *shape, const float *volinfo,
                         const float *K, const float *R, const float *t, const float *mask,
                         int W, int H, int64_t begin, int64_t end, int nthreads) {
-    return run_view(1, values, shape, volinfo, K, R, t, mask, W, H, begin, end, nthreads);
+    return run_view(1, values, shape, volinfo, K, R, t, mask, W, H, begin, end, nthreads, 0, 1, shape ? shape[0] : 0);
 }
 
 /*

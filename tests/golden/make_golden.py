@@ -114,9 +114,41 @@ def main():
     lab = both_carve(shape, origin, vs, views)
     syn["plant_61x45x113_8"] = lab.astype(np.int8)
     np.savez_compressed(os.path.join(OUT, "synthetic_expected.npz"), **syn)
-    json.dump(digests, open(os.path.join(OUT, "synthetic_digests.json"), "w"), indent=1,
-              sort_keys=True)
+    path = os.path.join(OUT, "synthetic_digests.json")
+    if os.path.exists(path):  # keep the full-size entries of big_digests()
+        digests = {**json.load(open(path)), **digests}
+    json.dump(digests, open(path, "w"), indent=1, sort_keys=True)
+
+
+def big_digests(nthreads=None):
+    """BASELINE cfg 3 (512^3 x 72: the benchmarked scene and the bench's other three) and cfg 4 (1024^3 x 72, the
+    planes of ranks 0, 3 and 7 of 8, both partitions): SHA-256 + histogram of the ORACLE's int32 labels over the
+    whole grid / the rank's planes.  `python tests/golden/make_golden.py big` (about ten minutes on 8 cores; the
+    sizes at which tests and bench.py's parity_check compare the HIP path with these)."""
+    from plant3dvision_amd.sharded import rank_planes
+    nthreads = nthreads or min(32, os.cpu_count() or 8)
+    path = os.path.join(OUT, "synthetic_digests.json")
+    digests = json.load(open(path))
+    for kind in ("plant", "solid", "dense", "noise"):
+        shape, origin, vs, views = scenes.make_scene(512, 72, kind)
+        lab = oracle_c.carve(shape, origin, vs, views, nthreads=nthreads)
+        digests[f"{kind}_512_72"] = {"sha256_int32": sha256(lab), "hist_m1_0_p1": histogram3(lab)}
+        print(kind, 512, 72, digests[f"{kind}_512_72"], flush=True)
+        del lab
+    shape, origin, vs, views = scenes.make_scene(1024, 72, "plant")
+    for partition in ("cyclic", "slab"):
+        for rank in (0, 3, 7):
+            pl = rank_planes(shape[0], 8, rank, partition)
+            lab = oracle_c.carve_planes(shape, origin, vs, views, pl.start, pl.step, len(pl), nthreads=nthreads)
+            key = f"plant_1024_72_{partition}_rank{rank}of8"
+            digests[key] = {"sha256_int32": sha256(lab), "hist_m1_0_p1": histogram3(lab)}
+            print(key, digests[key], flush=True)
+            del lab
+    json.dump(digests, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big_digests()
+    else:
+        main()

@@ -3,11 +3,13 @@
 * the reference's literal ``configs/test_geom_pipe_real.toml`` grid (301 x 301 x 561, 60 views): the
   whole grid against the threaded oracle;
 * cfg 4 (1024^3 x 72 over 8 ranks): ranks 0, 3 and 7 of 8 built one after the other on one device,
-  plane-cyclic and slab partitions -- properties + a voxel sample against the oracle's projection;
+  plane-cyclic and slab partitions -- every voxel of a rank's 128 planes against the oracle over those planes
+  (coordinates from the GLOBAL plane index) + the committed digests + properties;
 * cfg 5 (Masks2D feeding a 512^3 volume): 72 stand-in predictions of 896 x 896 -> per-label masks on
   the device -> 512^3 averaging and carving volumes -- properties + a voxel sample;
-* the bench's extra scenes (dense, solid, noise) at 512^3: fused == per view, sample against the oracle.
+* the bench's extra scenes (dense, solid, noise) at 512^3: the whole grid against the oracle, fused == per view.
 """
+import json
 import os
 
 import numpy as np
@@ -22,6 +24,7 @@ from tests.helpers import histogram3, scene, sha256
 
 pytestmark = pytest.mark.gpu
 THREADS = min(32, os.cpu_count() or 8)
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_digests.json")))
 
 
 def _poses(views):
@@ -106,8 +109,8 @@ def test_literal_test_geom_pipe_real_grid_whole_grid_vs_oracle(gpu_device, kind)
 @pytest.mark.parametrize("partition", ["cyclic", "slab"])
 def test_cfg4_1024_cubed_ranks_of_8(gpu_device, partition):
     """BASELINE cfg 4: what ranks 0, 3 and 7 of 8 compute of the 1024^3 grid (128 planes = 512 MiB
-    each).  Fused == one launch per view == permuted order (sha), and 20 000 voxels of every rank
-    against the oracle's projection with GLOBAL indices."""
+    each): every voxel against the oracle run over the same planes with GLOBAL indices (and its committed
+    digest); fused == one launch per view == permuted order (sha)."""
     shape, origin, vs, views = scene(1024, 72, "plant")
     K, R, t = _poses(views)
     rng = np.random.default_rng(11)
@@ -120,14 +123,14 @@ def test_cfg4_1024_cubed_ranks_of_8(gpu_device, partition):
         assert eng.slab_shape == (128, 1024, 1024)
         ptr, dims = _device_masks(eng, views)
         fused = _run(eng, K, R, t, ptr, dims, 0).copy()
+        want = oracle_c.carve_planes(shape, origin, vs, views, planes.start, planes.step, len(planes), nthreads=THREADS)
+        assert np.array_equal(fused, want), (partition, rank, histogram3(fused), histogram3(want))
+        del want
         dig = sha256(fused)
+        gold = GOLD[f"plant_1024_72_{partition}_rank{rank}of8"]
+        assert dig == gold["sha256_int32"] and histogram3(fused) == gold["hist_m1_0_p1"]
         assert sha256(_run(eng, K, R, t, ptr, dims, 1)) == dig
         assert sha256(_run(eng, K, R, t, ptr, dims, 5, order=perm)) == dig
-        local = np.stack([rng.integers(0, s, 20000) for s in eng.slab_shape], axis=1)
-        ijk = local.copy()
-        ijk[:, 0] = np.array(planes)[local[:, 0]]
-        want = _carve_sample(ijk.astype(np.int32), origin, vs, views)
-        assert np.array_equal(fused[local[:, 0], local[:, 1], local[:, 2]], want), (partition, rank)
         alive += int((fused == 1).sum())
         eng.dev_free(ptr)
         eng.close()
@@ -136,18 +139,22 @@ def test_cfg4_1024_cubed_ranks_of_8(gpu_device, partition):
 
 # -- the bench's other scenes at cfg 3's size ---------------------------------------------------------
 @pytest.mark.parametrize("kind", ["dense", "solid", "noise"])
-def test_cfg3_other_scenes_properties(gpu_device, kind):
+def test_cfg3_other_scenes_whole_grid_vs_oracle(gpu_device, kind):
+    """The bench's other scenes at 512^3 x 72: every voxel against the oracle (a few seconds of host threads) and
+    its committed digest, then fused == one launch per view == permuted order."""
     shape, origin, vs, views = scene(512, 72, kind)
     K, R, t = _poses(views)
     eng = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE)
     ptr, dims = _device_masks(eng, views)
     fused = _run(eng, K, R, t, ptr, dims, 0).copy()
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=THREADS)
+    assert np.array_equal(fused, want), (kind, histogram3(fused), histogram3(want))
+    del want
     dig = sha256(fused)
+    gold = GOLD[f"{kind}_512_72"]
+    assert dig == gold["sha256_int32"] and histogram3(fused) == gold["hist_m1_0_p1"]
     assert sha256(_run(eng, K, R, t, ptr, dims, 1)) == dig
     assert sha256(_run(eng, K, R, t, ptr, dims, 9, order=np.random.default_rng(3).permutation(72))) == dig
-    rng = np.random.default_rng(5)
-    ijk = np.stack([rng.integers(0, s, 20000) for s in shape], axis=1).astype(np.int32)
-    assert np.array_equal(fused[ijk[:, 0], ijk[:, 1], ijk[:, 2]], _carve_sample(ijk, origin, vs, views))
     h = histogram3(fused)
     if kind == "dense":
         assert 0.19 * fused.size < h[2] < 0.30 * fused.size  # the visual hull of a 20 % object
