@@ -273,6 +273,69 @@ int sc_hostpack_bits(const void *mask, int H, int W, int mask_dtype, int64_t row
 int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int partition,
                      int64_t nx, int64_t ny, int64_t nz, int bits, void *out_dev, int out_bytes);
 
+/*
+ * The BRICK-SPARSE transport form of carve labels (round 6; multi-GPU assembly; no reference counterpart:
+ * the reference is single-device, cl.py:29-30 -- what the far end needs is what cl.py:229-232 returns, the labels).
+ * A carved volume is uniform almost everywhere, and the engine already holds a 1-byte verdict per 16 x 64-voxel brick
+ * of one x-plane (brick b = (plane * bricks_y + j / 16) * bricks_z + k / 64).  One rank's buffer:
+ *     header   64 bytes: uint32 magic "SCSP", version 1, bits 2, nbricks, cap, nmixed, planes, ny, nz, bricks_y,
+ *              bricks_z, first, stride (its planes are first, first + stride, ... of the grid), 3 spare
+ *     codes    [nbricks] bytes: 0 / 1 / 3 = every voxel of the brick is 0 / 1 / -1 (label & 3); 2 = MIXED   (to 64 bytes)
+ *     ids      [cap] uint32: the brick of payload slot s                                       (cap is a multiple of 16)
+ *     payload  [cap][256] bytes: slot s = the brick's labels at 2 bits each, voxel (column jl, depth kl) of the brick
+ *              at bits 2 (v % 16) of word v / 16, v = jl * 64 + kl; voxels beyond ny / nz are 0
+ * sc_sparse_bricks / sc_sparse_rank_bytes give the sizes (cap is clamped to [16, nbricks] and rounded up to 16).
+ * sc_values_sparse flushes and packs on the engine's stream into an engine-owned device buffer (two alternate: the
+ * buffer of a call stays untouched until the call after next) and returns it (work may still be running).  It reads
+ * only bricks nothing settles: behind ONE fused batch on a cleared volume the batch's verdict bytes settle most
+ * bricks and its live list names the others (one launch, a plant's 7 577 live bricks of 131 072: 31 MB read, 2 MB
+ * written, where the dense 2-bit form writes 32 MiB); otherwise bricks an earlier launch found empty are skipped and
+ * the rest is read.  A brick that is read and turns out uniform gets its code, not a slot.  cap = 0: the engine's
+ * last capacity (first call: an eighth of the bricks).  nmixed > cap: slots were refused -- the codes are complete,
+ * the payload is not; ask again with cap >= nmixed.  SC_ERR_STATE unless default_value is -1, 0 or 1.
+ * sc_sparse_headers waits for `hip_stream` and returns nmixed[r], cap[r] of the `world` buffers rank_bytes apart in
+ * device memory (every rank of an all-gather sees the same numbers, so all ranks take the same decision about a
+ * retry without talking).  sc_unpack_sparse writes ONE [nx][ny][nz] grid in global order from them on hip_stream:
+ * out_kind 4 int32 labels, 1 int8 labels, 0 the uint8 occupancy label == 1 (what proc3d.py:515 binarises to).
+ * sc_widen_sparse_ranks is the same on the host (no device) into int32, on the library's host pool.
+ */
+int64_t sc_sparse_bricks(int64_t planes, int64_t ny, int64_t nz);
+int64_t sc_sparse_rank_bytes(int64_t nbricks, int64_t cap);
+int sc_values_sparse(sc_engine *e, int64_t cap, void **ptr, int64_t *bytes);
+int sc_get_values_sparse(sc_engine *e, int64_t cap, void *out, int64_t out_bytes);
+int sc_sparse_headers(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, uint32_t *nmixed,
+                      uint32_t *cap);
+int sc_unpack_sparse(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int64_t nx, int64_t ny,
+                     int64_t nz, void *out_dev, int out_kind);
+int sc_widen_sparse_ranks(const void *packed, int64_t rank_bytes, int world, int64_t nx, int64_t ny, int64_t nz, int32_t *out);
+
+/*
+ * RCCL behind the C ABI (round 6): one communicator per process and GPU, so that a carve rank assembles the grid without
+ * torch.  librccl is opened at the first call (the copy already in the process, if any); rank 0 makes the 128-byte id
+ * (sc_comm_unique_id) and hands it to the others by whatever means the host has (plant-3d-vision_amd/sharded.py: a TCP
+ * socket on MASTER_ADDR / MASTER_PORT); sc_comm_create is collective (ncclCommInitRank).  The communicator owns a
+ * non-blocking stream (sc_comm_stream) for collectives that run beside an engine's work.
+ * sc_all_gather_sparse / sc_all_gather_packed: flush, pack the engine's labels (sc_values_sparse with the capacity EVERY
+ * rank names alike / sc_values_packed) and all-gather `rank_stride` bytes per rank -- the size of the rank with the most
+ * planes, the same on every rank -- into recv_dev[nranks][rank_stride].  overlap = 0: the collective is enqueued on the
+ * engine's own stream.  overlap = 1: on the communicator's stream behind an event, and the engine's stream does not
+ * wait -- the next batch's carve runs beside the collective; the engine waits by itself before it packs into a send
+ * buffer a collective may still be reading.  The caller keeps recv_dev untouched until it has waited
+ * (sc_comm_synchronize, sc_sparse_headers on the stream the collective ran on).
+ */
+typedef struct sc_comm sc_comm;
+int sc_comm_unique_id(void *id, int64_t id_bytes /* >= 128 */);
+int sc_comm_create(sc_comm **out, const void *id, int nranks, int rank, int device);
+void sc_comm_destroy(sc_comm *c);
+int sc_comm_size(const sc_comm *c);
+int sc_comm_rank(const sc_comm *c);
+int sc_comm_stream(sc_comm *c, void **hip_stream);
+int sc_comm_synchronize(sc_comm *c);
+int sc_comm_all_gather(sc_comm *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *hip_stream /* NULL: its own */);
+int sc_engine_stream(sc_engine *e, void **hip_stream);
+int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, int64_t rank_stride, int overlap);
+int sc_all_gather_packed(sc_engine *e, sc_comm *c, int bits, void *recv_dev, int64_t rank_stride, int overlap);
+
 /* number of voxels this engine owns */
 int64_t sc_num_voxels(const sc_engine *e);
 

@@ -82,6 +82,24 @@ _SIGNATURES = {
     "sc_widen_labels2_ranks": ("i", ["p", "q", "i", "i", "q", "q", "q", "p"]),
     "sc_vol2pcd_packed": ("i", ["p", "q", "i", "i", "i", "q", "q", "q", "p", "d", "d", "p", "i", "p", "p", "p"]),
     "sc_unpack_labels": ("i", ["i", "p", "p", "q", "i", "i", "q", "q", "q", "i", "p", "i"]),
+    "sc_sparse_bricks": ("q", ["q", "q", "q"]),
+    "sc_sparse_rank_bytes": ("q", ["q", "q"]),
+    "sc_values_sparse": ("i", ["p", "q", "p", "p"]),
+    "sc_get_values_sparse": ("i", ["p", "q", "p", "q"]),
+    "sc_sparse_headers": ("i", ["i", "p", "p", "q", "i", "p", "p"]),
+    "sc_unpack_sparse": ("i", ["i", "p", "p", "q", "i", "q", "q", "q", "p", "i"]),
+    "sc_widen_sparse_ranks": ("i", ["p", "q", "i", "q", "q", "q", "p"]),
+    "sc_comm_unique_id": ("i", ["p", "q"]),
+    "sc_comm_create": ("i", ["p", "p", "i", "i", "i"]),
+    "sc_comm_destroy": ("v", ["p"]),
+    "sc_comm_size": ("i", ["p"]),
+    "sc_comm_rank": ("i", ["p"]),
+    "sc_comm_stream": ("i", ["p", "p"]),
+    "sc_comm_synchronize": ("i", ["p"]),
+    "sc_comm_all_gather": ("i", ["p", "p", "p", "q", "p"]),
+    "sc_engine_stream": ("i", ["p", "p"]),
+    "sc_all_gather_sparse": ("i", ["p", "p", "q", "p", "q", "i"]),
+    "sc_all_gather_packed": ("i", ["p", "p", "i", "p", "q", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
     "sc_fused_counts": ("i", ["p", "p"]),
@@ -417,6 +435,103 @@ def unpack_labels(device, stream_ptr, recv_ptr, rank_bytes, world, partition, sh
                          int(out_ptr), int(out_bytes)), "sc_unpack_labels")
 
 
+def sparse_bricks(planes, ny, nz):
+    """Bricks (16 columns x 64 voxels of one x-plane) of ``planes`` planes: the units of the sparse label form."""
+    n = backend().call("sc_sparse_bricks", int(planes), int(ny), int(nz))
+    if n < 0:
+        raise ValueError("bad shape for the sparse label form")
+    return int(n)
+
+
+def sparse_rank_bytes(nbricks, cap):
+    """Bytes of one rank's sparse label buffer: header + codes + ``cap`` payload slots (``include/spacecarve.h``)."""
+    n = backend().call("sc_sparse_rank_bytes", int(nbricks), int(cap))
+    if n < 0:
+        raise ValueError("bad brick count / capacity")
+    return int(n)
+
+
+def sparse_headers(device, stream_ptr, recv_ptr, rank_bytes, world):
+    """(nmixed[world], cap[world]) of gathered sparse buffers in device memory; waits for ``stream_ptr``."""
+    nm = np.zeros(int(world), dtype=np.uint32)
+    cp = np.zeros(int(world), dtype=np.uint32)
+    check(backend().call("sc_sparse_headers", int(device), int(stream_ptr or 0), int(recv_ptr), int(rank_bytes), int(world),
+                         addr(nm), addr(cp)), "sc_sparse_headers")
+    return nm, cp
+
+
+def unpack_sparse(device, stream_ptr, recv_ptr, rank_bytes, world, shape, out_ptr, out_kind):
+    """``sc_unpack_sparse``: the ranks' gathered sparse buffers -> ONE grid in global order on the device;
+    ``out_kind`` 4 int32 labels, 1 int8 labels, 0 uint8 occupancy (label == 1)."""
+    check(backend().call("sc_unpack_sparse", int(device), int(stream_ptr or 0), int(recv_ptr), int(rank_bytes), int(world),
+                         int(shape[0]), int(shape[1]), int(shape[2]), int(out_ptr), int(out_kind)), "sc_unpack_sparse")
+
+
+def widen_sparse_ranks(packed, rank_bytes, world, shape, out=None):
+    """Host code only: the ranks' sparse buffers (a uint8 array, ``rank_bytes`` apart) -> the int32 grid in global
+    order -- the host end of ``ShardedBackprojection.gather_to_host`` (cl.py:229-232 of a sharded run)."""
+    packed = np.ascontiguousarray(packed).view(np.uint8).reshape(-1)
+    if packed.size < int(rank_bytes) * int(world):
+        raise ValueError("buffer smaller than world x rank_bytes")
+    n = int(np.prod(shape))
+    if out is None or out.dtype != np.int32 or out.size != n or not out.flags["C_CONTIGUOUS"]:
+        out = np.empty(n, dtype=np.int32)
+    check(backend().call("sc_widen_sparse_ranks", addr(packed), int(rank_bytes), int(world), int(shape[0]), int(shape[1]),
+                         int(shape[2]), addr(out.reshape(-1))), "sc_widen_sparse_ranks")
+    return out.reshape(tuple(int(s) for s in shape))
+
+
+class Comm:
+    """One RCCL communicator of this process (``sc_comm_*``): the library enqueues the collectives itself, no torch.
+    ``unique_id()`` on rank 0, the 128 bytes to every rank by the host's own means, then ``Comm(id, world, rank, device)``
+    on every rank (collective)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(Comm.ID_BYTES, dtype=np.uint8)
+        check(backend().call("sc_comm_unique_id", addr(buf), Comm.ID_BYTES), "sc_comm_unique_id")
+        return buf.tobytes()
+
+    def __init__(self, unique_id, world_size, rank, device=0):
+        self._b = backend()
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        if uid.size != Comm.ID_BYTES:
+            raise ValueError("the id is %d bytes" % Comm.ID_BYTES)
+        out = np.zeros(1, dtype=np.uintp)
+        check(self._b.call("sc_comm_create", addr(out), addr(uid), int(world_size), int(rank), int(device)), "sc_comm_create")
+        self._h = int(out[0])
+        self.world_size, self.rank, self.device = int(world_size), int(rank), int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def stream(self):
+        out = np.zeros(1, dtype=np.uintp)
+        check(self._b.call("sc_comm_stream", self._h, addr(out)), "sc_comm_stream")
+        return int(out[0])
+
+    def synchronize(self):
+        check(self._b.call("sc_comm_synchronize", self._h), "sc_comm_synchronize")
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream_ptr=0):
+        check(self._b.call("sc_comm_all_gather", self._h, int(send_ptr), int(recv_ptr), int(bytes_per_rank), int(stream_ptr or 0)),
+              "sc_comm_all_gather")
+
+    def close(self):
+        if getattr(self, "_h", 0):
+            self._b.call("sc_comm_destroy", self._h)
+            self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def view_certified(shape, origin, voxel_size, K, R, t):
     """Does a view with this pose take the kernels' certified (cheaper, same results) projection path on
     this grid?  Host arithmetic only (``sc_view_certified``)."""
@@ -688,6 +803,32 @@ class Engine:
         out = np.empty((self.num_voxels() + per - 1) // per, dtype=np.uint32)
         self._call("sc_get_values_packed", int(bits), addr(out))
         return out
+
+    def values_sparse(self, cap=0):
+        """(device pointer, bytes) of the labels in the brick-sparse form (``sc_values_sparse``); work may still run."""
+        out = np.zeros(1, dtype=np.uintp)
+        nb = np.zeros(1, dtype=np.int64)
+        self._call("sc_values_sparse", int(cap), addr(out), addr(nb))
+        return int(out[0]), int(nb[0])
+
+    def get_values_sparse(self, cap=0):
+        """The sparse buffer in host memory (uint8 array); ``header`` fields via ``sparse_header``."""
+        nbricks = sparse_bricks(self.slab_shape[0], self.slab_shape[1], self.slab_shape[2])
+        cap = int(cap) if cap else max(1024, nbricks // 8)
+        out = np.zeros(sparse_rank_bytes(nbricks, cap), dtype=np.uint8)
+        self._call("sc_get_values_sparse", cap, addr(out), out.size)
+        return out
+
+    def stream(self):
+        out = np.zeros(1, dtype=np.uintp)
+        self._call("sc_engine_stream", addr(out))
+        return int(out[0])
+
+    def all_gather_sparse(self, comm, cap, recv_ptr, rank_stride, overlap=False):
+        self._call("sc_all_gather_sparse", comm.handle, int(cap), int(recv_ptr), int(rank_stride), 1 if overlap else 0)
+
+    def all_gather_packed(self, comm, bits, recv_ptr, rank_stride, overlap=False):
+        self._call("sc_all_gather_packed", comm.handle, int(bits), int(recv_ptr), int(rank_stride), 1 if overlap else 0)
 
     def num_voxels(self):
         return int(self._b.call("sc_num_voxels", self._h))

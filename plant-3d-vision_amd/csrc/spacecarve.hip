@@ -98,6 +98,7 @@ namespace {
 #include "sc_lists.h"
 #include "sc_average.h"
 #include "sc_misc.h"
+#include "sc_sparse.h"
 
 
 // ------------------------------------------------------------------------------------------
@@ -196,6 +197,23 @@ struct sc_engine {
     int8_t *narrow = nullptr;  // scratch of sc_get_values_i8
     uint32_t *packed_labels = nullptr;  // sc_values_packed: the labels at 2 or 1 bits each
     uint32_t *wire_stage = nullptr;     // sc_get_values_wire2: page-locked landing place of the packed labels
+    // sc_values_sparse (sc_sparse.h): two send buffers alternate, so that a collective may still read one while the next
+    // batch's labels are packed into the other
+    char *sparse_buf[2] = {nullptr, nullptr};
+    size_t sparse_bytes[2] = {0, 0};
+    int sparse_idx = 0;
+    SparseCounters *sparse_cnt = nullptr;  // two, alternating (the pack kernel of a call zeroes the other call's)
+    uint32_t *sparse_work = nullptr;       // bricks whose labels have to be read when no list of them exists
+    uint64_t sparse_calls = 0;
+    int64_t sparse_cap = 0;                // payload capacity (bricks) of the next call that does not name one
+    bool sparse_exact = false;             // the verdict bytes and the live / late lists describe the labels exactly: the
+                                           // last launch was a brick-form carve of a fresh volume, nothing since
+    bool sparse_late = false;              // ... and its late lists hold its failed candidates (verdict byte 5)
+    // a collective enqueued beside the engine's stream (sc_all_gather_*, overlap) still reads a send buffer: the next
+    // pack into that buffer waits for the event recorded behind the collective
+    hipEvent_t sparse_busy[2] = {nullptr, nullptr}, packed_busy = nullptr;
+    bool sparse_busy_armed[2] = {false, false}, packed_busy_armed = false;
+    size_t packed_cap = 0;                 // bytes of packed_labels
     size_t wire_stage_words = 0;
     int64_t unit_cull = 1;     // the dense stage asks the views packed ahead about every live brick's units (0: not;
                                // 2: even when the tiles settled less than half of the bricks)
@@ -1180,6 +1198,9 @@ int flush(sc_engine *e, size_t count = 0) {
         const int ndense = fp.ndense, nstage1 = fp.nstage1, flag_views = fp.flag_views;
         const uint32_t list_blocks = (uint32_t)e->list_blocks;
         const bool compact = fp.compact, brick = fp.brick, defer_stores = fp.defer_stores;
+        // what sc_values_sparse may take from this launch's verdict bytes and lists (sc_sparse.h)
+        e->sparse_exact = brick && e->fresh;
+        e->sparse_late = false;
         Append ap{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
         int dense_views = (int)nv;
         const uint32_t bys = fp.bys, bzs = fp.bzs, nbricks = fp.nbricks, nstrips = fp.nstrips;
@@ -1348,6 +1369,7 @@ int flush(sc_engine *e, size_t count = 0) {
             // open FULL candidates exist only when packing rode beside the dense stage
             CullStores none{nullptr, 0u, 0u, 0u, 0u, 0, 0, 0u, 0, 0u}, cs = none;
             if (ride_blocks) {
+                e->sparse_late = true;
                 // the riders have packed the rest of the masks: open FULL candidates get their answer
                 // (a block per 64 entries of the candidate list, a persistent grid of at most 4096; without candidates
                 // every block leaves after eight scalar loads)
@@ -1708,6 +1730,13 @@ void sc_destroy(sc_engine *e) {
     if (e->views_pin) (void)hipHostFree(e->views_pin);
     if (e->narrow) (void)hipFree(e->narrow);
     if (e->packed_labels) (void)hipFree(e->packed_labels);
+    for (int q = 0; q < 2; ++q)
+        if (e->sparse_buf[q]) (void)hipFree(e->sparse_buf[q]);
+    for (int q = 0; q < 2; ++q)
+        if (e->sparse_busy[q]) (void)hipEventDestroy(e->sparse_busy[q]);
+    if (e->packed_busy) (void)hipEventDestroy(e->packed_busy);
+    if (e->sparse_cnt) (void)hipFree(e->sparse_cnt);
+    if (e->sparse_work) (void)hipFree(e->sparse_work);
     if (e->wire_stage) (void)hipHostFree(e->wire_stage);
     if (e->dense) (void)hipFree(e->dense);
     if (e->verd) (void)hipFree(e->verd);
@@ -1734,6 +1763,7 @@ int sc_clear(sc_engine *e) {
     e->hb[e->hb_cur].used = 0;  // (nothing of it was uploaded)
     e->deferred.on = false;
     e->dead_clean = false;  // the labels go back to default_value: no brick is known to be all -1
+    e->sparse_exact = false;
     arena_reset(e);
     if (e->step_open) {  // the views of an open SC_KERNEL_STEP window are gone: no sample for them
         e->event_pool.push_back(e->step_start);
@@ -2453,11 +2483,14 @@ int sc_values_packed(sc_engine *e, int bits, void **ptr, int64_t *bytes) {
     if (rc) return rc;
     const int64_t nbytes = sc_packed_bytes(e->n, bits);
     if (!e->packed_labels) {
-        const size_t cap = (size_t)sc_packed_bytes(e->n, 2);
+        // room for one more plane than the engine owns: in an all-gather every rank sends the stride of the rank with
+        // the most planes (sc_all_gather_packed)
+        const size_t cap = (size_t)sc_packed_bytes(e->n + e->ny * e->nz, 2), own = (size_t)sc_packed_bytes(e->n, 2);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->packed_labels), cap));
         // the tail of the last 16-byte group lies behind the last word the pack kernel writes and travels with the
-        // buffer (all-gather, read-back): zero once, never garbage
-        HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(e->packed_labels) + (cap - 16), 0, 16, e->stream));
+        // buffer (all-gather, read-back), and so does the slack: zero once, never garbage
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(e->packed_labels) + (own - 16), 0, cap - (own - 16), e->stream));
+        e->packed_cap = cap;
     }
     const uint64_t words = ((uint64_t)e->n + (32 / bits) - 1) / (32 / bits);
     // bricks an earlier launch found empty are all -1 until the next clear: not read (see the kernel)
@@ -3053,3 +3086,6 @@ extern "C" int sc_debug_dense_trace(uint32_t *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_trace), sizeof(uint32_t) * 8192 * 8);
 }
 #endif
+
+#include "sc_api_sparse.inl"
+#include "sc_comm.inl"

@@ -60,7 +60,9 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
     ``Backprojection`` whose device-resident volume is used in place -- the 4N-byte grid then
     never crosses PCIe, only the shell's points and normals come back -- or the ``PackedGrid`` of a
     sharded run (``ShardedBackprojection.all_gather(compress="1bit" | "2bit", unpack=False)``): the
-    ranks' packed planes are read as they are and the full-size grid is never written.
+    ranks' packed planes are read as they are and the full-size grid is never written; or its ``SparseGrid``
+    (``compress="sparse"``): the uint8 occupancy ``label == 1`` is written on the device from the codes and the mixed
+    bricks (1 byte per voxel) and read in place.
     Returns an ``open3d.geometry.PointCloud`` when open3d is importable (and ``as_open3d``),
     else a :class:`PointCloud` with the same ``points`` / ``normals``.
     """
@@ -76,7 +78,13 @@ def vol2pcd(volume, origin, voxel_size, level_set_value=0, device=0, as_open3d=T
     assert gw.size == 5
     out = np.zeros(2, dtype=np.uintp)
     cnt = np.zeros(1, dtype=np.int64)
-    if hasattr(volume, "recv") and hasattr(volume, "rank_bytes"):  # a sharded run's PackedGrid: read as it is
+    if hasattr(volume, "occupancy_device"):  # a sharded run's SparseGrid: its occupancy (label == 1) on the device
+        sg = volume
+        ptr, keep = sg.occupancy_device()
+        rc = b.call("sc_vol2pcd", ptr, 1, codes[np.dtype(np.uint8)], sg.shape[0], sg.shape[1], sg.shape[2], nat.addr(origin64),
+                    float(voxel_size), float(level_set_value), nat.addr(gw), int(sg.device), nat.addr(out),
+                    nat.addr(out) + 8, nat.addr(cnt))
+    elif hasattr(volume, "recv") and hasattr(volume, "rank_bytes"):  # a sharded run's PackedGrid: read as it is
         import torch
         pg = volume
         torch.cuda.synchronize(pg.recv.device)  # the collective that filled it

@@ -79,6 +79,156 @@ class PackedGrid:
         return out[:n].view(self.shape)
 
 
+class SparseOverflow(RuntimeError):
+    """A rank had more mixed bricks than the capacity every rank sent with: gather again with ``needed`` slots."""
+
+    def __init__(self, needed, cap):
+        super().__init__(f"{needed} mixed bricks on some rank for a capacity of {cap}")
+        self.needed, self.cap = int(needed), int(cap)
+
+
+class DevMem:
+    """Device memory of the engine's device without torch (``sc_dev_alloc``): the receive buffers of the library's own
+    collectives."""
+
+    def __init__(self, engine, nbytes):
+        self._engine, self.nbytes = engine, int(nbytes)
+        self.ptr = engine.dev_alloc(max(16, self.nbytes))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def free(self):
+        if self.ptr:
+            self._engine.dev_free(self.ptr)
+            self.ptr = 0
+
+
+class SparseGrid:
+    """The assembled grid in the BRICK-SPARSE form (``include/spacecarve.h``): every rank's header, one code per
+    16 x 64-voxel brick and the 2-bit labels of its mixed bricks only, rank-major -- 131 KB + 260 bytes per mixed brick
+    and rank where the dense 2-bit form is 32 MiB.  ``recv`` is a CUDA / host torch tensor or a :class:`DevMem`;
+    ``stream`` the HIP stream the collective ran on (0: torch's current / none).  ``verify()`` waits for the
+    collective and checks that no rank ran out of slots; ``unpack()`` writes the int8 / int32 grid in global order;
+    ``occupancy_device()`` the uint8 ``label == 1`` volume ``proc3d.vol2pcd`` reads (proc3d.py:515);
+    ``to_host()`` the int32 array of cl.py:229-232 (widened by the library's host pool)."""
+
+    def __init__(self, recv, rank_bytes, world, shape, device, cap, stream=0, on_gpu=True, engine=None):
+        self.recv, self.rank_bytes, self.world = recv, int(rank_bytes), int(world)
+        self.shape, self.device, self.cap = [int(s) for s in shape], int(device), int(cap)
+        self.stream, self.on_gpu, self._engine = int(stream or 0), bool(on_gpu), engine
+        self.nmixed = None
+
+    def _ptr(self):
+        return int(self.recv.data_ptr())
+
+    def _host_bytes(self):
+        if self.on_gpu:
+            if hasattr(self.recv, "cpu"):
+                return self.recv.cpu().numpy()
+            out = np.empty(self.rank_bytes * self.world, dtype=np.uint8)
+            self._engine.dev_download(out, self.recv.ptr)
+            return out
+        return self.recv.numpy() if hasattr(self.recv, "numpy") else np.asarray(self.recv)
+
+    def verify(self):
+        """Waits for the collective; raises :class:`SparseOverflow` if some rank had more mixed bricks than slots."""
+        if self.nmixed is None:
+            if self.on_gpu:
+                stream = self.stream
+                if not stream and hasattr(self.recv, "is_cuda"):
+                    import torch
+                    stream = torch.cuda.current_stream(self.recv.device).cuda_stream
+                nm, cp = nat.sparse_headers(self.device, stream, self._ptr(), self.rank_bytes, self.world)
+            else:
+                buf = self._host_bytes().reshape(self.world, self.rank_bytes)
+                hdr = np.ascontiguousarray(buf[:, :64]).view(np.uint32)
+                if not (hdr[:, 0] == 0x50534353).all():
+                    raise ValueError("not a sparse label buffer")
+                nm, cp = hdr[:, 5].copy(), hdr[:, 4].copy()
+            self.nmixed, self.caps = nm, cp
+        worst = int(max(int(n) for n in self.nmixed))
+        if any(int(n) > int(c) for n, c in zip(self.nmixed, self.caps)):
+            raise SparseOverflow(worst, self.cap)
+        return self
+
+    def unpack(self, widen=False, out=None, kind=None):
+        """The grid in global order on the device: int8 labels, ``widen``: int32; ``kind=0``: uint8 occupancy."""
+        self.verify()
+        kind = (4 if widen else 1) if kind is None else int(kind)
+        n = int(np.prod(self.shape))
+        if not self.on_gpu:
+            raise RuntimeError("host tensors: use to_host()")
+        if hasattr(self.recv, "is_cuda"):
+            import torch
+            dt = {4: torch.int32, 1: torch.int8, 0: torch.uint8}[kind]
+            if out is None or out.dtype != dt or out.numel() < n:
+                out = torch.empty(n, dtype=dt, device=self.recv.device)
+            stream = self.stream or torch.cuda.current_stream(self.recv.device).cuda_stream
+            nat.unpack_sparse(self.device, stream, self._ptr(), self.rank_bytes, self.world, self.shape, out.data_ptr(), kind)
+            return out[:n].view(self.shape)
+        if out is None:
+            out = DevMem(self._engine, n * (4 if kind == 4 else 1))
+        nat.unpack_sparse(self.device, self.stream, self._ptr(), self.rank_bytes, self.world, self.shape, out.data_ptr(), kind)
+        return out
+
+    def occupancy_device(self):
+        """(device pointer, keep-alive object) of the uint8 occupancy ``label == 1`` in global order; the kernel has
+        completed when this returns."""
+        occ = self.unpack(kind=0)
+        if hasattr(occ, "is_cuda"):
+            import torch
+            torch.cuda.current_stream(occ.device).synchronize()
+            return int(occ.data_ptr()), occ
+        nat.sparse_headers(self.device, self.stream, self._ptr(), self.rank_bytes, self.world)  # (waits for the stream)
+        return int(occ.ptr), occ
+
+    def to_host(self, out=None):
+        self.verify()
+        return nat.widen_sparse_ranks(self._host_bytes(), self.rank_bytes, self.world, self.shape, out=out)
+
+
+def exchange_unique_id(rank, world_size, addr=None, port=None, timeout=300.0):
+    """The 128-byte RCCL id from rank 0 to every rank over a TCP socket of the standard library (no torch): rank 0
+    listens on (``addr``, ``port``) -- ``SC_COMM_ADDR`` / ``SC_COMM_PORT``, else ``MASTER_ADDR`` / ``MASTER_PORT`` + 1 --
+    and serves the id to the world_size - 1 others, who retry their connection until it is there."""
+    import os
+    import socket
+    import time
+    addr = addr or os.environ.get("SC_COMM_ADDR") or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ.get("SC_COMM_PORT") or int(os.environ.get("MASTER_PORT", "29511")) + 1)
+    if rank == 0:
+        uid = nat.Comm.unique_id()
+        if world_size > 1:
+            with socket.socket() as srv:
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(world_size)
+                srv.settimeout(timeout)
+                for _ in range(world_size - 1):
+                    conn, _ = srv.accept()
+                    with conn:
+                        conn.sendall(uid)
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as so:
+                buf = b""
+                while len(buf) < nat.Comm.ID_BYTES:
+                    chunk = so.recv(nat.Comm.ID_BYTES - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+            if len(buf) == nat.Comm.ID_BYTES:
+                return buf
+        except OSError:
+            pass
+        if time.time() > deadline:
+            raise TimeoutError(f"no RCCL id from rank 0 at {addr}:{port}")
+        time.sleep(0.05)
+
+
 class ShardedBackprojection:
     """Slab-sharded ``Backprojection``: same per-view interface, one slab per rank."""
 
@@ -126,6 +276,44 @@ class ShardedBackprojection:
         self._lazy_wait = None
         #: host tensors only (CPU tests of the host logic over gloo): what stands in for ``sc_unpack_labels``
         self._unpack_fn = unpack_fn
+        #: the library's own RCCL communicator (``init_comm``): collectives without torch
+        self.comm = None
+        #: payload slots (bricks) every rank sends with in the sparse form; grows when a rank runs out (every rank sees
+        #: the same headers, so all ranks change it alike)
+        self._sparse_cap = max(1024, self._bricks_max() // 8)
+        self._sparse_recv = [None, None]
+        self._sparse_turn = 0
+
+    def _bricks_max(self):
+        ny, nz = self.shape[1], self.shape[2]
+        return self._planes_max() * ((ny + 15) // 16) * ((nz + 63) // 64)
+
+    def init_comm(self, unique_id=None):
+        """The library's RCCL communicator for this rank (collective: every rank calls it).  The 128-byte id comes from
+        rank 0 -- ``unique_id`` if the caller has moved it, else over ``torch.distributed`` when a process group
+        exists, else over a TCP socket (``exchange_unique_id``: no torch anywhere on a carve rank)."""
+        if self.comm is not None:
+            return self.comm
+        if not self._on_gpu:
+            raise RuntimeError("the library's collectives need the HIP engine")
+        if unique_id is None:
+            dist = None
+            try:
+                import sys
+                if "torch" in sys.modules:
+                    import torch.distributed as dist
+                    if not dist.is_initialized():
+                        dist = None
+            except ImportError:
+                dist = None
+            if dist is not None:
+                box = [nat.Comm.unique_id() if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                unique_id = box[0]
+            else:
+                unique_id = exchange_unique_id(self.rank, self.world_size)
+        self.comm = nat.Comm(unique_id, self.world_size, self.rank, self.device)
+        return self.comm
 
     @property
     def engine(self):
@@ -289,7 +477,95 @@ class ShardedBackprojection:
                                                             np.int32 if widen else np.int8).reshape(-1))
         return out[:n_out].view(self.shape)
 
-    def all_gather(self, compress=False, widen=True, recv=None, out=None, unpack=True, overlap=False):
+    def sparse_rank_bytes(self, cap=None):
+        """Bytes every rank contributes to a sparse all-gather with ``cap`` payload slots (the rank with the most planes)."""
+        return nat.sparse_rank_bytes(self._bricks_max(), self._sparse_cap if cap is None else cap)
+
+    def _all_gather_sparse(self, widen, recv, out, unpack=True, overlap=False, check=True):
+        """Labels in the brick-sparse form over the wire (``include/spacecarve.h``): codes for all bricks, 2-bit labels
+        of the mixed ones only, packed from the batch's own verdict bytes and live list.  Through the library's RCCL
+        communicator when ``init_comm`` was called (no torch: ``recv`` is then a :class:`DevMem`, kept and reused),
+        else through ``torch.distributed`` (gloo rehearsals, CPU tests).  ``check``: wait for the headers and gather
+        again with more slots if a rank ran out (every rank takes the same decision from the same headers);
+        ``check=False`` (pipelines): the :class:`SparseGrid` comes back unverified -- ``verify()`` it later."""
+        if self.dtype != np.int32:
+            raise ValueError("packed labels are carve labels")
+        W = self.world_size
+        while True:
+            cap = self._sparse_cap
+            stride = self.sparse_rank_bytes(cap)
+            if self.comm is not None:
+                if recv is None or not isinstance(recv, DevMem) or recv.nbytes < stride * W:
+                    turn = self._sparse_turn
+                    self._sparse_turn ^= 1
+                    buf = self._sparse_recv[turn]
+                    if buf is None or buf.nbytes < stride * W:
+                        if buf is not None:
+                            self.comm.synchronize()
+                            self._engine.synchronize()
+                            buf.free()
+                        buf = self._sparse_recv[turn] = DevMem(self._engine, stride * W)
+                    rbuf = buf
+                else:
+                    rbuf = recv
+                self._engine.all_gather_sparse(self.comm, cap, rbuf.ptr, stride, overlap=overlap)
+                grid = SparseGrid(rbuf, stride, W, self.shape, self.device, cap,
+                                  stream=self.comm.stream() if overlap else self._engine.stream(), engine=self._engine)
+            else:
+                grid = self._all_gather_sparse_torch(cap, stride, recv, overlap)
+            if not check:
+                return grid if not unpack else grid.unpack(widen=widen, out=out)
+            try:
+                grid.verify()
+            except SparseOverflow as ex:
+                # (the engine's labels are as they were: gather again, every rank with the same larger capacity)
+                self._sparse_cap = min(self._bricks_max(), (ex.needed + ex.needed // 8 + 15) & ~15)
+                recv = None
+                continue
+            return grid.unpack(widen=widen, out=out) if unpack else grid
+
+    def _all_gather_sparse_torch(self, cap, stride, recv, overlap):
+        import torch
+        import torch.distributed as dist
+        W = self.world_size
+        tstream = None
+        if self._on_gpu:
+            self._engine.flush()
+            self._settle()
+            ptr, nbytes = self._engine.values_sparse(cap)
+            tstream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+            self._engine.order_before(tstream)
+            local = torch.as_tensor(_DeviceBuffer(ptr, nbytes, "|u1"), device=f"cuda:{self.device}")
+        else:
+            local = torch.from_numpy(np.ascontiguousarray(self._engine.get_values_sparse(cap)).view(np.uint8))
+        single = W == 1 and not self.force_collective
+        send = local
+        if local.numel() != stride:  # a rank with one plane fewer
+            send = torch.zeros(stride, dtype=torch.uint8, device=local.device)
+            send[: local.numel()] = local
+        if single:
+            recv = send.clone() if send.is_cuda else send
+        else:
+            if recv is None or not hasattr(recv, "dtype") or recv.dtype != torch.uint8 or recv.numel() < stride * W \
+                    or recv.device != local.device:
+                recv = torch.empty(stride * W, dtype=torch.uint8, device=local.device)
+            recv = recv[: stride * W]
+            if dist.get_backend() == "gloo" and recv.is_cuda:  # rehearsal on one box: through the host
+                hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_gather_into_tensor(hrecv, send.cpu())
+                recv.copy_(hrecv)
+            else:
+                dist.all_gather_into_tensor(recv, send)
+        if tstream is not None:
+            # two send buffers alternate inside the engine: the next pack does not touch the one this collective reads,
+            # the one after it does -- the engine waits then (lazily), or now
+            if overlap:
+                self._lazy_wait = tstream
+            else:
+                self._engine.order_after(tstream)
+        return SparseGrid(recv, stride, W, self.shape, self.device, cap, on_gpu=bool(recv.is_cuda), engine=self._engine)
+
+    def all_gather(self, compress=False, widen=True, recv=None, out=None, unpack=True, overlap=False, check=True):
         """Full grid on every rank (torch tensor on the slab's device), by all-gather.
 
         compress=True sends carve labels as int8 (labels are in {-1, 0, 1} when default_value
@@ -299,6 +575,9 @@ class ShardedBackprojection:
         compress="2bit" sends them at 2 bits each, "1bit" the occupancy ``label == 1`` alone (what
         ``vol2pcd`` binarises to): 16x / 32x less traffic, packed by the engine and unpacked into global
         order by one kernel (``_all_gather_packed``).
+        compress="sparse" (round 6): one code per 16 x 64-voxel brick + the 2-bit labels of the mixed bricks only,
+        packed from the batch's verdict bytes and live list (``_all_gather_sparse``): 2 MB per rank on a plant where
+        "2bit" is 32 MiB; ``unpack=False`` returns a :class:`SparseGrid`.
         recv / out: reusable buffers (``W * P * ny * nz`` elements of the wire dtype; packed: recv
         ``W * packed_rank_bytes(bits)`` bytes, out ``nx * ny * nz`` int8 / int32).
         unpack=False (packed forms only): no grid is written at all -- the result is a ``PackedGrid`` (the ranks'
@@ -307,10 +586,16 @@ class ShardedBackprojection:
         overlap=True (with unpack=False): a pipeline of batches -- the collective of this batch runs beside the
         carve of the next one; the engine waits for it only before it packs again.
         """
+        if overlap and (unpack or compress not in ("2bit", "1bit", "sparse")):
+            raise ValueError("overlap=True is for the packed forms left packed (compress='2bit' / '1bit' / 'sparse', unpack=False)")
+        if compress == "sparse":
+            if unpack and not self._on_gpu:
+                import torch
+                grid = self._all_gather_sparse(widen, recv, None, unpack=False, overlap=False, check=True)
+                return torch.from_numpy(grid.to_host().astype(np.int32 if widen else np.int8))
+            return self._all_gather_sparse(widen, recv, out, unpack, overlap, check and not overlap)
         import torch
         import torch.distributed as dist
-        if overlap and (unpack or compress not in ("2bit", "1bit")):
-            raise ValueError("overlap=True is for the packed forms left packed (compress='2bit' / '1bit', unpack=False)")
         if compress in ("2bit", "1bit"):
             if not unpack and not self._on_gpu:
                 # (ADVICE r04: a PackedGrid is a device object -- unpack() and vol2pcd read it with HIP kernels)
@@ -379,6 +664,15 @@ class ShardedBackprojection:
         Carve labels of a default value of -1 / 0 / 1 take the 2-bit wire instead (``_gather_to_host_2bit``);
         ``out``: an int32 array of the grid's size to widen into on ``dst`` -- one whose pages have been touched
         takes 512^3 labels in ~4 ms, a fresh ``np.empty`` ~30 (first-touch page faults, not the transfer)."""
+        if compress == "sparse":
+            # (round 6) codes + mixed bricks only over the collective (every rank ends with every rank's buffer: they
+            # are small), ONE PCIe copy on ``dst``, widened and put in global order by the host pool
+            if not (self.dtype == np.int32 and float(self.default_value) in (-1.0, 0.0, 1.0)
+                    and hasattr(self._engine, "get_values_sparse")):
+                raise ValueError("the sparse wire carries carve labels of a default_value of -1, 0 or 1")
+            self._settle()
+            grid = self._all_gather_sparse(True, None, None, unpack=False, overlap=False, check=True)
+            return grid.to_host(out=out) if self.rank == dst else None
         import torch
         import torch.distributed as dist
         self._settle()
@@ -456,5 +750,15 @@ class ShardedBackprojection:
     def close(self):
         if self._engine is not None:
             self._settle()
+            if self.comm is not None:
+                self.comm.synchronize()
+            self._engine.synchronize()
+            for buf in self._sparse_recv:
+                if buf is not None:
+                    buf.free()
+            self._sparse_recv = [None, None]
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
             self._engine.close()
             self._engine = None

@@ -80,11 +80,94 @@ class OracleEngine:
         bits * (v % (32 / bits)) of word v / (32 / bits)."""
         return pack_labels_np(self.get_values(), bits)
 
+    def get_values_sparse(self, cap=0):
+        """NumPy restatement of ``sparse_pack_kernel`` (the brick-sparse form of include/spacecarve.h)."""
+        pl = self.planes
+        return pack_sparse_np(self.get_values(), pl.start, pl.step if len(pl) > 1 else 1, cap)
+
     def num_voxels(self):
         return int(np.prod(self.slab_shape))
 
     def close(self):
         pass
+
+
+SPARSE_MAGIC = 0x50534353
+
+
+def sparse_layout_np(nbricks, cap):
+    codes = 64
+    ids = codes + ((nbricks + 63) & ~63)
+    payload = ids + ((cap * 4 + 63) & ~63)
+    return codes, ids, payload, payload + cap * 256
+
+
+def sparse_cap_np(cap, nbricks):
+    cap = min(max(int(cap), 16), nbricks)
+    return (cap + 15) & ~15
+
+
+def pack_sparse_np(values, first, stride, cap=0):
+    """One rank's planes ``values[P][ny][nz]`` (int32 labels in {-1, 0, 1}) -> its sparse buffer (uint8 array): header,
+    one code per 16 x 64 brick (0 / 1 / 3 uniform, 2 mixed), ids and 256-byte payloads of the mixed bricks in brick
+    order (the device hands slots out in any order; a reader goes by the ids)."""
+    v = np.asarray(values, dtype=np.int32)
+    P, ny, nz = v.shape
+    bys, bzs = (ny + 15) // 16, (nz + 63) // 64
+    nbricks = P * bys * bzs
+    cap = sparse_cap_np(cap if cap else max(1024, nbricks // 8), nbricks)
+    o_codes, o_ids, o_pay, total = sparse_layout_np(nbricks, cap)
+    buf = np.zeros(total, dtype=np.uint8)
+    padded = np.zeros((P, bys * 16, bzs * 64), dtype=np.int64)
+    valid = np.zeros((P, bys * 16, bzs * 64), dtype=bool)
+    padded[:, :ny, :nz] = v & 3
+    valid[:, :ny, :nz] = True
+    bricks = padded.reshape(P, bys, 16, bzs, 64).transpose(0, 1, 3, 2, 4).reshape(nbricks, 1024)
+    bvalid = valid.reshape(P, bys, 16, bzs, 64).transpose(0, 1, 3, 2, 4).reshape(nbricks, 1024)
+    codes = np.full(nbricks, 2, dtype=np.uint8)
+    for c in (0, 1, 3):  # (the kernel's priority: all -1, then all 1, then all 0 -- they exclude each other on valid voxels)
+        codes[np.all((bricks == c) | ~bvalid, axis=1)] = c
+    mixed = np.nonzero(codes == 2)[0]
+    buf[o_codes:o_codes + nbricks] = codes
+    shifts = (np.arange(16, dtype=np.int64) * 2)[None, None, :]
+    nput = min(len(mixed), cap)
+    if nput:
+        words = (np.where(bvalid[mixed[:nput]], bricks[mixed[:nput]], 0).reshape(nput, 64, 16) << shifts).sum(axis=2).astype(np.uint32)
+        buf[o_ids:o_ids + 4 * nput] = mixed[:nput].astype(np.uint32).view(np.uint8)
+        buf[o_pay:o_pay + 256 * nput] = words.reshape(-1).view(np.uint8)
+    hdr = np.array([SPARSE_MAGIC, 1, 2, nbricks, cap, len(mixed), P, ny, nz, bys, bzs, first, stride, 0, 0, 0], dtype=np.uint32)
+    buf[:64] = hdr.view(np.uint8)
+    return buf
+
+
+def sparse_header_np(buf):
+    h = np.ascontiguousarray(buf[:64]).view(np.uint32)
+    keys = ("magic", "version", "bits", "nbricks", "cap", "nmixed", "planes", "ny", "nz", "bricks_y", "bricks_z", "first", "stride")
+    return {k: int(h[i]) for i, k in enumerate(keys)}
+
+
+def unpack_sparse_np(recv, rank_bytes, world, shape, dtype=np.int32):
+    """NumPy restatement of ``sparse_unpack_kernel`` / ``sc_widen_sparse_ranks``: the ranks' sparse buffers -> one grid."""
+    nx, ny, nz = shape
+    full = np.full((nx, ny, nz), 99, dtype=dtype)
+    recv = np.ascontiguousarray(recv).view(np.uint8).reshape(-1)
+    for r in range(world):
+        buf = recv[r * rank_bytes:(r + 1) * rank_bytes]
+        h = sparse_header_np(buf)
+        assert h["magic"] == SPARSE_MAGIC and h["nmixed"] <= h["cap"], h
+        o_codes, o_ids, o_pay, _ = sparse_layout_np(h["nbricks"], h["cap"])
+        codes = buf[o_codes:o_codes + h["nbricks"]]
+        ids = buf[o_ids:o_ids + 4 * h["nmixed"]].view(np.uint32)
+        words = buf[o_pay:o_pay + 256 * h["nmixed"]].view(np.uint32).reshape(-1, 64).astype(np.int64)
+        bys, bzs = h["bricks_y"], h["bricks_z"]
+        lab = np.where(codes == 3, -1, codes.astype(np.int64))[:, None] * np.ones((1, 1024), dtype=np.int64)
+        if len(ids):
+            two = (words[:, :, None] >> (np.arange(16, dtype=np.int64) * 2)[None, None, :]) & 3
+            lab[ids] = np.where(two == 3, -1, two).reshape(-1, 1024)
+        planes = lab.reshape(h["planes"], bys, bzs, 16, 64).transpose(0, 1, 3, 2, 4).reshape(h["planes"], bys * 16, bzs * 64)
+        gi = h["first"] + np.arange(h["planes"]) * h["stride"]
+        full[gi] = planes[:, :ny, :nz].astype(dtype)
+    return full
 
 
 def pack_labels_np(values, bits):

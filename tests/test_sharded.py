@@ -88,6 +88,16 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
             out2 = torch.empty(int(np.prod(shape)), dtype=torch.int8)
             a2 = sb.all_gather(compress="2bit", widen=False, recv=recv2, out=out2)
             assert a2.data_ptr() == out2.data_ptr()
+            # the brick-sparse form (round 6): codes + the mixed bricks' labels only; bit-equal to the dense 2-bit form
+            ps = sb.all_gather(compress="sparse")
+            assert ps.dtype == torch.int32
+            res["ags"] = ps.numpy()
+            res["agsn"] = sb.all_gather(compress="sparse", widen=False).numpy()
+            res["hosts"] = sb.gather_to_host(dst=0, compress="sparse")
+            # a capacity too small for some rank: every rank sees the same headers and gathers again with more slots
+            sb._sparse_cap = 16
+            res["ags_small_cap"] = sb.all_gather(compress="sparse").numpy()
+            res["cap_after"] = sb._sparse_cap
         q.put(res)
     finally:
         dist.barrier()
@@ -127,6 +137,12 @@ def test_gloo_sharded_equals_single(world, shape, mode, partition):
             assert res["ag8n"].dtype == np.int8 and np.array_equal(res["ag8n"], want)
             assert np.array_equal(res["ag2"], want) and np.array_equal(res["ag2n"], want)
             assert np.array_equal(res["ag1"], (want == 1).astype(np.int8))
+            assert np.array_equal(res["ags"], want) and res["agsn"].dtype == np.int8 and np.array_equal(res["agsn"], want)
+            assert np.array_equal(res["ags_small_cap"], want) and res["cap_after"] >= 16
+            if res["rank"] == 0:
+                assert res["hosts"].dtype == np.int32 and np.array_equal(res["hosts"], want)
+            else:
+                assert res["hosts"] is None
             if res["rank"] == world - 1:
                 assert res["host32"].dtype == np.int32 and np.array_equal(res["host32"], want)
             else:

@@ -130,3 +130,62 @@ def test_host_pool_works_in_a_forked_child():
     assert os.read(r, 1) == b"1" and os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     os.close(r)
     assert np.array_equal(nat.widen_labels2(packed, n, threads=8), labels)  # the parent's pool is untouched
+
+
+# -- the brick-sparse label form (round 6): host end -------------------------------------------------------------------
+def _random_labels(rng, shape, kind):
+    nx, ny, nz = shape
+    if kind == "carved":      # mostly -1, a blob of 1s, a little 0
+        lab = np.full(shape, -1, dtype=np.int32)
+        lab[nx // 3:nx // 3 + max(1, nx // 4), ny // 4:ny // 2 + 1, nz // 5:nz // 2 + 1] = 1
+        lab[rng.random(shape) < 0.002] = 0
+        return lab
+    if kind == "solid":
+        return np.ones(shape, dtype=np.int32)
+    return rng.integers(-1, 2, size=shape).astype(np.int32)  # noise: every brick mixed
+
+
+@pytest.mark.parametrize("shape,world,partition", [((8, 32, 128), 1, "cyclic"), ((9, 20, 70), 2, "cyclic"),
+                                                   ((9, 20, 70), 3, "slab"), ((5, 16, 64), 5, "cyclic"), ((7, 33, 129), 2, "slab")])
+@pytest.mark.parametrize("kind", ["carved", "solid", "noise"])
+def test_sparse_labels_widen_on_the_host_to_the_grid(shape, world, partition, kind):
+    """``sc_widen_sparse_ranks`` (the host end of gather_to_host over the sparse wire) against the labels themselves and
+    the NumPy restatement of the format, ragged shapes and uneven ranks included."""
+    from plant3dvision_amd.sharded import rank_planes
+    from tests.helpers import pack_sparse_np, sparse_header_np, unpack_sparse_np
+    rng = np.random.default_rng(hash((shape, world, kind)) % (1 << 32))
+    lab = _random_labels(rng, shape, kind)
+    nbmax = max(nat.sparse_bricks(len(rank_planes(shape[0], world, r, partition)), shape[1], shape[2]) for r in range(world))
+    stride = nat.sparse_rank_bytes(nbmax, nbmax)
+    recv = np.zeros(world * stride, dtype=np.uint8)
+    mixed = 0
+    for r in range(world):
+        pl = rank_planes(shape[0], world, r, partition)
+        buf = pack_sparse_np(lab[pl.start:pl.stop:pl.step], pl.start, pl.step if len(pl) > 1 else 1, cap=nbmax)
+        assert buf.size <= stride and buf.size == nat.sparse_rank_bytes(nat.sparse_bricks(len(pl), shape[1], shape[2]), nbmax)
+        recv[r * stride:r * stride + buf.size] = buf
+        mixed += sparse_header_np(buf)["nmixed"]
+    if kind == "solid":
+        assert mixed == 0
+    got = nat.widen_sparse_ranks(recv, stride, world, shape)
+    assert got.dtype == np.int32 and np.array_equal(got, lab)
+    assert np.array_equal(unpack_sparse_np(recv, stride, world, shape), lab)
+
+
+def test_sparse_labels_host_end_refuses_what_it_cannot_trust():
+    from tests.helpers import pack_sparse_np
+    rng = np.random.default_rng(3)
+    lab = rng.integers(-1, 2, size=(4, 32, 128)).astype(np.int32)
+    nb = nat.sparse_bricks(4, 32, 128)
+    full = pack_sparse_np(lab, 0, 1, cap=nb)
+    assert np.array_equal(nat.widen_sparse_ranks(full, full.size, 1, lab.shape), lab)
+    lab2 = rng.integers(-1, 2, size=(8, 32, 128)).astype(np.int32)
+    over = pack_sparse_np(lab2, 0, 1, cap=16)  # 32 mixed bricks, 16 slots: nmixed > cap
+    with pytest.raises(nat.SpaceCarveError):
+        nat.widen_sparse_ranks(over, over.size, 1, lab2.shape)
+    bad = full.copy()
+    bad[0] ^= 0xff  # not a sparse buffer
+    with pytest.raises(ValueError):
+        nat.widen_sparse_ranks(bad, bad.size, 1, lab.shape)
+    with pytest.raises(ValueError):
+        nat.widen_sparse_ranks(full, full.size, 1, (5, 32, 128))  # the ranks do not hold the grid's planes
