@@ -94,6 +94,17 @@ GRIDS_512 = {1: (512, 512, 512), 2: (640, 640, 640), 4: (808, 800, 832), 8: (102
 
 
 COLLECTIVE = False
+BARRIER = None  # the library communicator's barrier once it exists (sc_comm_barrier), else torch.distributed's
+
+
+def _barrier(dist):
+    """The barrier that brackets every timed region.  With the library's own RCCL communicator it is a 16-byte all-gather
+    on that communicator, waited for on the host (~20 us); torch.distributed's gloo barrier -- the control plane then --
+    costs 0.3-0.5 ms over loopback TCP, a tenth of twenty 0.17 ms steps."""
+    if BARRIER is not None:
+        BARRIER()
+    else:
+        dist.barrier()
 
 
 def parse():
@@ -131,8 +142,11 @@ def parse():
                     help="prefix of the .npy cache of the synthetic masks (the child passes reuse the parent's)")
     ap.add_argument("--skip-other-path", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option KEY=VALUE (sc_set_option)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --share-device rehearses the N>1 path on a one-GPU box")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "torch-nccl", "gloo"],
+                    help="nccl (default): the collectives of the data path are enqueued by the library's own RCCL communicator "
+                         "(sc_comm_*), torch.distributed (gloo) only carries the barriers and the MAX over ranks; torch-nccl: "
+                         "torch's NCCL process group for everything (rounds 2-5); gloo + --share-device rehearses the N>1 "
+                         "path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use device 0 (rehearsal)")
     ap.add_argument("--rccl-rehearsal", action="store_true",
                     help="one rank, but with an RCCL process group of one: barriers, the timing all-reduce and the "
@@ -172,7 +186,7 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world, time_kernels=
     engine.set_option(nat.SC_OPT_RESERVE_EVENTS,
                       8 if span else min(65536, (2 if time_kernels == 2 else 16) * steps * (1 if vpl == 0 else 80) + 64))
     if world > 1:
-        dist.barrier()
+        _barrier(dist)
     engine.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -183,7 +197,7 @@ def timed(engine, nat, torch, dist, args_tuple, steps, vpl, world, time_kernels=
     engine.synchronize()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        _barrier(dist)
     dt = time.perf_counter() - t0
     if world > 1:
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -558,37 +572,97 @@ def _maxed(torch, dist, dt):
     return float(tt.item())
 
 
-def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, overlap=True):
+def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, overlap=True, form="dense"):
     """`steps` steps of carve + assembly, barrier + synchronize on both sides, MAX over ranks (seconds).  A step:
-    clear, the batch of resident masks, pack the labels to `bits` bits each, all-gather (RCCL over xGMI) -- every
-    rank ends every step holding the whole grid in its packed form (a PackedGrid: what proc3d.vol2pcd reads).
-    overlap: the collective of step k runs beside the carve of step k + 1 (two receive buffers alternate; the
-    engine waits for collective k right before it packs step k + 1's labels); the last collective is waited for
-    inside the timed region."""
+    clear, the batch of resident masks, pack the labels, all-gather (RCCL over xGMI) -- every rank ends every step
+    holding the whole grid in its packed form (what proc3d.vol2pcd reads).
+    form "sparse" (round 6, the headline at N > 1): one code per 16 x 64-voxel brick + the 2-bit labels of the mixed
+    bricks only, packed from the batch's verdict bytes and live list (sc_values_sparse), the collective enqueued by
+    the library itself (sc_all_gather_sparse over the communicator of sc_comm_create; gloo rehearsals: torch); the
+    headers of step k -- did every rank's mixed bricks fit the capacity all ranks sent with? -- are read while step
+    k + 1 runs, and a step that did not fit fails the leg (the capacity is settled before the timed steps).
+    form "dense": `bits` per label for every voxel (rounds 3-5).
+    overlap: the collective of step k runs beside the carve of step k + 1 (receive buffers alternate); the last
+    collective is waited for inside the timed region."""
     dev = torch.device("cuda", eng.device)
-    comp = "2bit" if bits == 2 else "1bit"
-    recv = [torch.empty(sb.packed_rank_bytes(bits) * sb.world_size, dtype=torch.uint8, device=dev) for _ in range(2)]
     eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
+    if form == "sparse":
+        def batch():
+            eng.clear()
+            eng.process_views_device(*call, nat.SC_MASK_U8)
 
-    def step(i):
-        eng.clear()
-        eng.process_views_device(*call, nat.SC_MASK_U8)
-        return sb.all_gather(compress=comp, recv=recv[i & 1], unpack=False, overlap=overlap)
+        batch()
+        sb.all_gather(compress="sparse", unpack=False)  # settles the capacity (every rank alike), synchronously
+        prev = [None]
+
+        def step(i):
+            batch()
+            g = sb.all_gather(compress="sparse", unpack=False, overlap=overlap, check=False)
+            if prev[0] is not None:
+                prev[0].verify()  # the previous step's headers, while this one runs
+            prev[0] = g
+            return g
+
+        def finish():
+            if prev[0] is not None:
+                prev[0].verify()
+                prev[0] = None
+            sb.synchronize()
+            if sb.comm is not None:
+                sb.comm.synchronize()
+    else:
+        comp = "2bit" if bits == 2 else "1bit"
+        recv = [torch.empty(sb.packed_rank_bytes(bits) * sb.world_size, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def step(i):
+            eng.clear()
+            eng.process_views_device(*call, nat.SC_MASK_U8)
+            return sb.all_gather(compress=comp, recv=recv[i & 1], unpack=False, overlap=overlap)
+
+        def finish():
+            sb.synchronize()          # the engine's stream (behind the last collective)
 
     for i in range(max(1, warmup)):
         step(i)
-    sb.synchronize()
+    finish()
     torch.cuda.synchronize()
-    dist.barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
-    sb.synchronize()          # the engine's stream (behind the last collective)
-    torch.cuda.synchronize()  # the collectives' stream
-    dist.barrier()
+    finish()
+    torch.cuda.synchronize()  # the collectives' stream (torch path)
+    _barrier(dist)
     dt = _maxed(torch, dist, time.perf_counter() - t0)
-    del recv
     return dt
+
+
+def _gather_to_host_legs(res, sb, dist, maxed):
+    """gather_to_host timed once per form (the engine's state is whatever the last leg left)."""
+    dest = np.zeros(sb.shape, dtype=np.int32) if dist.get_rank() == 0 else None  # (its pages touched: see below)
+    sb.gather_to_host(dst=0, out=dest)  # once untimed: the engine's packed buffer, RCCL's first gather
+    _barrier(dist)
+    t0 = time.perf_counter()
+    hostvol = sb.gather_to_host(dst=0, out=dest)
+    _barrier(dist)
+    res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
+    _barrier(dist)
+    t0 = time.perf_counter()
+    fresh = sb.gather_to_host(dst=0)
+    _barrier(dist)
+    res["gather_to_host_fresh_array_ms"] = maxed(time.perf_counter() - t0) * 1e3
+    sb.gather_to_host(dst=0, compress="sparse", out=dest)
+    _barrier(dist)
+    t0 = time.perf_counter()
+    hostvol = sb.gather_to_host(dst=0, compress="sparse", out=dest)
+    _barrier(dist)
+    res["gather_to_host_sparse_ms"] = maxed(time.perf_counter() - t0) * 1e3
+    res["gather_to_host_note"] = ("labels at 2 bits each to rank 0's GPU over the collective, one PCIe copy of 1/16 of the "
+                                  "grid's bytes, widened and interleaved into the int32 grid by the host pool "
+                                  "(sc_widen_labels2_ranks); into an array whose pages have been touched -- a fresh "
+                                  "np.empty pays first-touch page faults for 4 bytes per voxel (gather_to_host_fresh_array_ms)")
+    del hostvol, fresh, dest
+
 
 
 def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
@@ -606,23 +680,89 @@ def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        dist.barrier()
+        _barrier(dist)
         t0 = time.perf_counter()
         for _ in range(nsteps):
             full = step()
         sb.synchronize()
         torch.cuda.synchronize()
-        dist.barrier()
+        _barrier(dist)
         dt = maxed(time.perf_counter() - t0)
         del full
         return dt
 
     eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
     res = {"steps": steps}
+    dss = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=False, form="sparse")
+    res["sparse_grid_serial"] = {"ms_per_step": dss / steps * 1e3, "steps": steps, "value": n_total * V * steps / dss / 1e6,
+                                 "bytes_sent_per_rank": int(sb.sparse_rank_bytes()), "capacity_bricks": int(sb._sparse_cap),
+                                 "note": "as `value` (the brick-sparse form), the collective on the engine's own stream: "
+                                         "the next carve waits for it"}
+    # the same steps + the kernel that writes the int8 grid in global order from the sparse buffers on every GPU
+    sgrid = [None]
+
+    def step_su():
+        eng.clear()
+        eng.process_views_device(*call, nat.SC_MASK_U8)
+        sgrid[0] = sb.all_gather(compress="sparse", unpack=False, check=False)
+        return sgrid[0].unpack(widen=False, out=out8s[0])
+
+    out8s = [None]
+    first = sb.all_gather(compress="sparse", unpack=False).unpack(widen=False)
+    out8s[0] = first
+    dsu = run(step_su, steps)
+    res["sparse_grid_unpacked_int8"] = {"ms_per_step": dsu / steps * 1e3, "steps": steps, "value": n_total * V * steps / dsu / 1e6,
+                                        "note": "+ sc_unpack_sparse: the int8 grid in global order on every GPU (1 byte per voxel written)"}
+    del first
+    out8s[0] = None
+    if sb.comm is not None:
+        # the dense forms of rounds 3-5 through the same communicator (sc_all_gather_packed), for comparison
+        from plant3dvision_amd.sharded import DevMem
+
+        def dense_library(bits, overlap):
+            stride = sb.packed_rank_bytes(bits)
+            recv = [DevMem(eng, stride * world) for _ in range(2)]
+
+            def step(i):
+                eng.clear()
+                eng.process_views_device(*call, nat.SC_MASK_U8)
+                eng.all_gather_packed(sb.comm, bits, recv[i & 1].ptr, stride, overlap=overlap)
+
+            def fin():
+                eng.synchronize()
+                sb.comm.synchronize()
+
+            for i in range(2):
+                step(i)
+            fin()
+            _barrier(dist)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            fin()
+            _barrier(dist)
+            dt = maxed(time.perf_counter() - t0)
+            for r in recv:
+                r.free()
+            return {"ms_per_step": dt / steps * 1e3, "steps": steps, "value": n_total * V * steps / dt / 1e6,
+                    "bytes_sent_per_rank": int(stride)}
+
+        res["packed_grid_serial"] = dict(dense_library(2, False), note="the DENSE 2-bit form of rounds 3-5 (every voxel packed), "
+                                         "sc_all_gather_packed on the engine's stream")
+        res["packed_grid_overlapped"] = dict(dense_library(2, True), note="the dense 2-bit form, the collective beside the next "
+                                             "carve: `value` of round 5")
+        res["occupancy_1bit"] = dict(dense_library(1, True), note="only the occupancy `label == 1` travels, 1 bit per voxel")
+        if host:
+            _gather_to_host_legs(res, sb, dist, maxed)
+        return res
     dts = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, bits=2, overlap=False)
     res["packed_grid_serial"] = {"ms_per_step": dts / steps * 1e3, "steps": steps, "value": n_total * V * steps / dts / 1e6,
-                                 "note": "carve, pack to 2 bits, all-gather, one after the other: the next carve waits for "
-                                         "the collective (`value` lets them overlap)"}
+                                 "note": "the DENSE 2-bit form of rounds 3-5: carve, pack every voxel to 2 bits, all-gather, one "
+                                         "after the other"}
+    dtd = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, bits=2, overlap=True)
+    res["packed_grid_overlapped"] = {"ms_per_step": dtd / steps * 1e3, "steps": steps, "value": n_total * V * steps / dtd / 1e6,
+                                     "bytes_sent_per_rank": int(sb.packed_rank_bytes(2)),
+                                     "note": "the dense 2-bit form with the collective beside the next carve: `value` of round 5"}
     dt1 = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, bits=1, overlap=True)
     res["occupancy_1bit"] = {"ms_per_step": dt1 / steps * 1e3, "steps": steps, "value": n_total * V * steps / dt1 / 1e6,
                              "bytes_received_per_rank": int(sb.packed_rank_bytes(1) * world),
@@ -658,27 +798,11 @@ def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
     res["int8_wire"] = {"ms_per_step": dt8 / n8 * 1e3, "steps": n8, "bytes_received_per_rank": int(recv.numel())}
     del recv, out, out8
     if host:
-        dest = np.zeros(sb.shape, dtype=np.int32) if dist.get_rank() == 0 else None  # (its pages touched: see below)
-        sb.gather_to_host(dst=0, out=dest)  # once untimed: the engine's packed buffer, RCCL's first gather
-        dist.barrier()
-        t0 = time.perf_counter()
-        hostvol = sb.gather_to_host(dst=0, out=dest)
-        dist.barrier()
-        res["gather_to_host_ms"] = maxed(time.perf_counter() - t0) * 1e3
-        dist.barrier()
-        t0 = time.perf_counter()
-        fresh = sb.gather_to_host(dst=0)
-        dist.barrier()
-        res["gather_to_host_fresh_array_ms"] = maxed(time.perf_counter() - t0) * 1e3
-        res["gather_to_host_note"] = ("labels at 2 bits each to rank 0's GPU over the collective, one PCIe copy of 1/16 of the "
-                                      "grid's bytes, widened and interleaved into the int32 grid by the host pool "
-                                      "(sc_widen_labels2_ranks); into an array whose pages have been touched -- a fresh "
-                                      "np.empty pays first-touch page faults for 4 bytes per voxel (gather_to_host_fresh_array_ms)")
-        del hostvol, fresh, dest
+        _gather_to_host_legs(res, sb, dist, maxed)
     return res
 
 
-def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, steps):
+def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, steps, comm_library=False):
     """BASELINE.json's metric literally: ONE 512^3 x 72 grid (cfg 3) split over the N ranks (x-planes dealt
     round-robin), carve only and carve + assembly; barrier + synchronize on both sides, MAX over ranks."""
     gshape, origin, vs, views = scenes.make_scene((a.n,) * 3, a.views, a.scene)
@@ -696,11 +820,13 @@ def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, wor
     run_steps(eng, nat, *call, 3, 0)
     eng.synchronize()
     dt, _ = timed(eng, nat, torch, dist, call, steps, 0, world, time_kernels="span")
-    dta = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, bits=2, overlap=True)
-    dts = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, bits=2, overlap=False)
+    if comm_library:
+        sb.init_comm()
+    dta = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=True, form="sparse")
+    dts = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=False, form="sparse")
     out = {"workload": f"ONE {a.n}^3 x {V} grid split over {world} rank(s), x-planes cyclic ({len(sb.planes)} planes per rank)",
            "value": n_total * V * steps / dta / 1e6, "ms_per_step": dta / steps * 1e3, "steps": steps,
-           "value_is": "carve + pack + 2-bit all-gather per step, the collective beside the next step's carve (as the headline at N > 1)",
+           "value_is": "carve + sparse pack + all-gather per step, the collective beside the next step's carve (as the headline at N > 1)",
            "value_carve_only": n_total * V * steps / dt / 1e6, "ms_per_step_carve_only": dt / steps * 1e3,
            "value_serial_assembly": n_total * V * steps / dts / 1e6, "ms_per_step_serial_assembly": dts / steps * 1e3,
            "unit": "Mvoxel*views/s", "scaling": "strong"}
@@ -1003,15 +1129,20 @@ def main():
     if a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    global COLLECTIVE
+    global COLLECTIVE, BARRIER
     collective = COLLECTIVE = world > 1 or a.rccl_rehearsal
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if a.dist_backend == "nccl":
+        if a.dist_backend == "torch-nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         else:
+            # "nccl": the library's own RCCL communicator carries the data (sc_comm_create below); torch.distributed is
+            # the control plane only -- barriers, the MAX over ranks, the 128-byte id -- and a gloo group is enough for
+            # that.  (Measured: with torch's NCCL group alive in the process the same carve + gather steps take 0.197 ms
+            # instead of 0.177 -- its streams and watchdog share the hardware queues with the engine's and the
+            # communicator's.)
             dist.init_process_group("gloo", rank=rank, world_size=world)
     from plant3dvision_amd import _native as nat
     from plant3dvision_amd import scenes
@@ -1022,13 +1153,16 @@ def main():
         # 72 splatted silhouettes of a 1024^3 scene take the host a while: rank 0 builds them, the others load its file
         if rank == 0:
             cached_scene(a, scenes, shape)
-        dist.barrier()
+        _barrier(dist)
     gshape, origin, vs, views = cached_scene(a, scenes, shape)
     V = len(views)
     H, W = views[0][3].shape
     sb = ShardedBackprojection(gshape, origin, vs, rank=rank, world_size=world, device=local_rank)
     sb.force_collective = bool(a.rccl_rehearsal)
     eng = sb.engine
+    comm_library = collective and a.dist_backend == "nccl"  # RCCL bound by the library itself (sc_comm_*); gloo: torch
+    if comm_library:
+        BARRIER = sb.init_comm().barrier
     n_local = eng.num_voxels()
     n_total = int(np.prod(gshape))
     stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
@@ -1095,27 +1229,21 @@ def main():
         breakdown["fused_counts"] = {"live_bricks": live, "alive_after_dense_stage": s0,
                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}
     # N > 1: `value` = carve + assembly (t_device + collective), W warm-up and exactly K timed steps
+    # These legs are sequences of collectives: an exception on ONE rank must not be swallowed there (its peers would
+    # sit in a collective it never joins, and its next leg would pair with their pending one out of phase -- ADVICE
+    # r05).  A rank that fails exits non-zero and the launcher (self_launch / torchrun) ends the job.
     asm = None
     dt_asm = None
-    asm_error = None
     if collective and a.path == "fused":
-        try:
-            dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, bits=2, overlap=True)
-        except Exception as ex:  # noqa: BLE001  (the line must still come out: `value` falls back to the carve alone, and says so)
-            asm_error = repr(ex)
+        dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, overlap=True, form="sparse")
     if collective and a.assembly_steps > 0:
-        try:
-            asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
-        except Exception as ex:  # noqa: BLE001  (a secondary leg must not cost the line)
-            asm = {"error": repr(ex)}
+        asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
         if world == 1:
             asm["rehearsal"] = "process group of one rank on one GPU: the collectives move nothing over xGMI"
     strong = None
     if collective and a.strong_steps > 0 and a.path == "fused":
-        try:
-            strong = strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, a.strong_steps)
-        except Exception as ex:  # noqa: BLE001
-            strong = {"error": repr(ex)}
+        strong = strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, a.strong_steps,
+                                comm_library=comm_library)
     parity = None
     if a.parity_check == "on" and a.path == "fused" and rank == 0:
         parity = parity_check(a, nat, eng, call, gshape, origin, vs, views, planes=None if world == 1 else sb.planes,
@@ -1138,7 +1266,7 @@ def main():
     if a.gather != "none":
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            _barrier(dist)
         t0 = time.perf_counter()
         if a.gather == "allgather":
             full = sb.all_gather()
@@ -1148,7 +1276,7 @@ def main():
             full = sb.all_reduce()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            _barrier(dist)
         gather = {"kind": a.gather, "ms": (time.perf_counter() - t0) * 1e3,
                   "bytes_out_per_rank": int(full.numel() * full.element_size())}
         del full
@@ -1224,10 +1352,12 @@ def main():
             "config": {"workload": f"BASELINE cfg 3: {a.n}^3 voxels x {V} views per GPU, scene S1 "
                                    f"'{a.scene}' (SURVEY 8d), masks {W}x{H} uint8 resident in HBM",
                        "global_grid": gshape, "slab_per_gpu": list(sb.slab_shape),
-                       "parallelism": (f"x-planes cyclic over {world} rank(s); `value` = carve + pack + RCCL all-gather of the "
-                                       f"labels at 2 bits each per step (every GPU ends every step with the whole grid, "
-                                       f"packed), the collective beside the next step's carve; `value_carve_only` has no "
-                                       f"collective; `strong` splits ONE {a.n}^3 grid over the ranks") if dt_asm is not None
+                       "parallelism": (f"x-planes cyclic over {world} rank(s); `value` = carve + sparse pack + RCCL all-gather of "
+                                       f"the labels in the brick-sparse form per step (a code per 16 x 64-voxel brick + the "
+                                       f"2-bit labels of the mixed bricks: every GPU ends every step with the whole grid), "
+                                       f"the collective enqueued by the library (sc_all_gather_sparse) beside the next "
+                                       f"step's carve; `value_carve_only` has no collective; `strong` splits ONE {a.n}^3 "
+                                       f"grid over the ranks") if dt_asm is not None
                                       else "one GPU, the whole grid: no collective",
                        "path": a.path, "views_per_launch": V if a.path == "fused" else 1,
                        "arithmetic": "float32 projection (no contraction, correctly rounded divide) into int32 labels"},
@@ -1260,12 +1390,14 @@ def main():
             out["value_carve_only"] = value_carve
             out["ms_per_step_carve_only"] = dt / a.steps * 1e3
             out["value_with_assembly"] = value  # (the name of rounds 2-4; `value` IS the with-assembly rate now)
-            out["value_is"] = ("carve + assembly: K steps of clear + 72 resident masks + carve + pack to 2 bits per label + "
-                               "all-gather into alternating receive buffers, the collective of step k beside the carve of "
-                               "step k + 1, everything waited for inside the timed region; the roofline object describes the "
-                               "carve-only span")
-        if asm_error is not None:
-            out["value_is"] = "CARVE ONLY: the carve + assembly steps failed (%s)" % asm_error
+            out["value_is"] = ("carve + assembly: K steps of clear + 72 resident masks + carve + brick-sparse pack (codes + mixed "
+                               "bricks, from the batch's verdict bytes and live list) + all-gather into alternating receive "
+                               "buffers, the collective of step k beside the carve of step k + 1, step k's headers checked "
+                               "while step k + 1 runs, everything waited for inside the timed region; the roofline object "
+                               "describes the carve-only span")
+            out["assembly_transport"] = ("library RCCL (sc_comm_create / sc_all_gather_sparse: no torch in the data path)"
+                                         if sb.comm is not None else "torch.distributed (%s)" % a.dist_backend)
+            out["assembly_bytes_sent_per_rank"] = int(sb.sparse_rank_bytes())
         if asm is not None:
             out["assembly"] = asm
         if parity is not None:
@@ -1290,6 +1422,7 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.dev_free(masks_dev)
+    BARRIER = None
     sb.close()
     if collective:
         dist.barrier()

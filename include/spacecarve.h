@@ -279,7 +279,7 @@ int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t
  * A carved volume is uniform almost everywhere, and the engine already holds a 1-byte verdict per 16 x 64-voxel brick
  * of one x-plane (brick b = (plane * bricks_y + j / 16) * bricks_z + k / 64).  One rank's buffer:
  *     header   64 bytes: uint32 magic "SCSP", version 1, bits 2, nbricks, cap, nmixed, planes, ny, nz, bricks_y,
- *              bricks_z, first, stride (its planes are first, first + stride, ... of the grid), 3 spare
+ *              bricks_z, first, stride (its planes are first, first + stride, ... of the grid), nread (bricks the sender had to read: diagnostic), 2 spare
  *     codes    [nbricks] bytes: 0 / 1 / 3 = every voxel of the brick is 0 / 1 / -1 (label & 3); 2 = MIXED   (to 64 bytes)
  *     ids      [cap] uint32: the brick of payload slot s                                       (cap is a multiple of 16)
  *     payload  [cap][256] bytes: slot s = the brick's labels at 2 bits each, voxel (column jl, depth kl) of the brick
@@ -293,9 +293,10 @@ int sc_unpack_labels(int device, void *hip_stream, const void *recv_dev, int64_t
  * the rest is read.  A brick that is read and turns out uniform gets its code, not a slot.  cap = 0: the engine's
  * last capacity (first call: an eighth of the bricks).  nmixed > cap: slots were refused -- the codes are complete,
  * the payload is not; ask again with cap >= nmixed.  SC_ERR_STATE unless default_value is -1, 0 or 1.
- * sc_sparse_headers waits for `hip_stream` and returns nmixed[r], cap[r] of the `world` buffers rank_bytes apart in
- * device memory (every rank of an all-gather sees the same numbers, so all ranks take the same decision about a
- * retry without talking).  sc_unpack_sparse writes ONE [nx][ny][nz] grid in global order from them on hip_stream:
+ * sc_sparse_headers returns nmixed[r], cap[r] of the `world` buffers rank_bytes apart in device memory (every rank of
+ * an all-gather sees the same numbers, so all ranks take the same decision about a retry without talking); it waits
+ * for done_event -- the event sc_all_gather_sparse hands out, recorded behind ITS collective -- and copies on a stream
+ * of the library's own, or (done_event NULL) copies on hip_stream behind whatever that stream still has to do.  sc_unpack_sparse writes ONE [nx][ny][nz] grid in global order from them on hip_stream:
  * out_kind 4 int32 labels, 1 int8 labels, 0 the uint8 occupancy label == 1 (what proc3d.py:515 binarises to).
  * sc_widen_sparse_ranks is the same on the host (no device) into int32, on the library's host pool.
  */
@@ -303,8 +304,8 @@ int64_t sc_sparse_bricks(int64_t planes, int64_t ny, int64_t nz);
 int64_t sc_sparse_rank_bytes(int64_t nbricks, int64_t cap);
 int sc_values_sparse(sc_engine *e, int64_t cap, void **ptr, int64_t *bytes);
 int sc_get_values_sparse(sc_engine *e, int64_t cap, void *out, int64_t out_bytes);
-int sc_sparse_headers(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, uint32_t *nmixed,
-                      uint32_t *cap);
+int sc_sparse_headers(int device, void *hip_stream, void *done_event, const void *recv_dev, int64_t rank_bytes, int world,
+                      uint32_t *nmixed, uint32_t *cap);
 int sc_unpack_sparse(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, int64_t nx, int64_t ny,
                      int64_t nz, void *out_dev, int out_kind);
 int sc_widen_sparse_ranks(const void *packed, int64_t rank_bytes, int world, int64_t nx, int64_t ny, int64_t nz, int32_t *out);
@@ -331,9 +332,17 @@ int sc_comm_size(const sc_comm *c);
 int sc_comm_rank(const sc_comm *c);
 int sc_comm_stream(sc_comm *c, void **hip_stream);
 int sc_comm_synchronize(sc_comm *c);
+int sc_comm_barrier(sc_comm *c); /* a 16-byte all-gather, waited for: every rank has called it when it returns */
 int sc_comm_all_gather(sc_comm *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *hip_stream /* NULL: its own */);
 int sc_engine_stream(sc_engine *e, void **hip_stream);
-int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, int64_t rank_stride, int overlap);
+int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, int64_t rank_stride, int overlap,
+                         void **done_event /* may be NULL; the engine's, valid until its next sc_all_gather_sparse but one */,
+                         const void **headers_host /* may be NULL; likewise */);
+/* The headers of THAT gather without a copy at the time of asking: sc_all_gather_sparse has put a copy of the ranks'
+ * headers to page-locked host memory on the collective's stream, in front of done_event; this waits for the event
+ * (host code: a poll) and reads them.  nmixed[r], cap[r] as sc_sparse_headers. */
+int sc_sparse_wait_headers(void *done_event, const void *headers_host, int64_t rank_bytes, int world, uint32_t *nmixed,
+                           uint32_t *cap);
 int sc_all_gather_packed(sc_engine *e, sc_comm *c, int bits, void *recv_dev, int64_t rank_stride, int overlap);
 
 /* number of voxels this engine owns */

@@ -86,7 +86,7 @@ _SIGNATURES = {
     "sc_sparse_rank_bytes": ("q", ["q", "q"]),
     "sc_values_sparse": ("i", ["p", "q", "p", "p"]),
     "sc_get_values_sparse": ("i", ["p", "q", "p", "q"]),
-    "sc_sparse_headers": ("i", ["i", "p", "p", "q", "i", "p", "p"]),
+    "sc_sparse_headers": ("i", ["i", "p", "p", "p", "q", "i", "p", "p"]),
     "sc_unpack_sparse": ("i", ["i", "p", "p", "q", "i", "q", "q", "q", "p", "i"]),
     "sc_widen_sparse_ranks": ("i", ["p", "q", "i", "q", "q", "q", "p"]),
     "sc_comm_unique_id": ("i", ["p", "q"]),
@@ -96,9 +96,11 @@ _SIGNATURES = {
     "sc_comm_rank": ("i", ["p"]),
     "sc_comm_stream": ("i", ["p", "p"]),
     "sc_comm_synchronize": ("i", ["p"]),
+    "sc_comm_barrier": ("i", ["p"]),
     "sc_comm_all_gather": ("i", ["p", "p", "p", "q", "p"]),
     "sc_engine_stream": ("i", ["p", "p"]),
-    "sc_all_gather_sparse": ("i", ["p", "p", "q", "p", "q", "i"]),
+    "sc_all_gather_sparse": ("i", ["p", "p", "q", "p", "q", "i", "p", "p"]),
+    "sc_sparse_wait_headers": ("i", ["p", "p", "q", "i", "p", "p"]),
     "sc_all_gather_packed": ("i", ["p", "p", "i", "p", "q", "i"]),
     "sc_kernel_stats": ("i", ["p", "i", "p", "p"]),
     "sc_reset_kernel_stats": ("i", ["p"]),
@@ -451,12 +453,22 @@ def sparse_rank_bytes(nbricks, cap):
     return int(n)
 
 
-def sparse_headers(device, stream_ptr, recv_ptr, rank_bytes, world):
-    """(nmixed[world], cap[world]) of gathered sparse buffers in device memory; waits for ``stream_ptr``."""
+def sparse_headers(device, stream_ptr, recv_ptr, rank_bytes, world, done_event=0):
+    """(nmixed[world], cap[world]) of gathered sparse buffers in device memory; waits for ``done_event`` (what
+    ``Engine.all_gather_sparse`` returned) or, without one, for ``stream_ptr``."""
     nm = np.zeros(int(world), dtype=np.uint32)
     cp = np.zeros(int(world), dtype=np.uint32)
-    check(backend().call("sc_sparse_headers", int(device), int(stream_ptr or 0), int(recv_ptr), int(rank_bytes), int(world),
-                         addr(nm), addr(cp)), "sc_sparse_headers")
+    check(backend().call("sc_sparse_headers", int(device), int(stream_ptr or 0), int(done_event or 0), int(recv_ptr), int(rank_bytes),
+                         int(world), addr(nm), addr(cp)), "sc_sparse_headers")
+    return nm, cp
+
+
+def sparse_wait_headers(done_event, headers_host, rank_bytes, world):
+    """(nmixed[world], cap[world]) of the gather ``Engine.all_gather_sparse`` returned (event, host headers) for."""
+    nm = np.zeros(int(world), dtype=np.uint32)
+    cp = np.zeros(int(world), dtype=np.uint32)
+    check(backend().call("sc_sparse_wait_headers", int(done_event), int(headers_host), int(rank_bytes), int(world), addr(nm), addr(cp)),
+          "sc_sparse_wait_headers")
     return nm, cp
 
 
@@ -515,6 +527,10 @@ class Comm:
 
     def synchronize(self):
         check(self._b.call("sc_comm_synchronize", self._h), "sc_comm_synchronize")
+
+    def barrier(self):
+        """Every rank has called this when it returns (a 16-byte all-gather, waited for on the host)."""
+        check(self._b.call("sc_comm_barrier", self._h), "sc_comm_barrier")
 
     def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream_ptr=0):
         check(self._b.call("sc_comm_all_gather", self._h, int(send_ptr), int(recv_ptr), int(bytes_per_rank), int(stream_ptr or 0)),
@@ -825,7 +841,11 @@ class Engine:
         return int(out[0])
 
     def all_gather_sparse(self, comm, cap, recv_ptr, rank_stride, overlap=False):
-        self._call("sc_all_gather_sparse", comm.handle, int(cap), int(recv_ptr), int(rank_stride), 1 if overlap else 0)
+        """Pack + all-gather through the library's communicator; returns the event recorded behind the collective."""
+        ev = np.zeros(2, dtype=np.uintp)
+        self._call("sc_all_gather_sparse", comm.handle, int(cap), int(recv_ptr), int(rank_stride), 1 if overlap else 0, addr(ev),
+                   addr(ev) + 8)
+        return int(ev[0]), int(ev[1])
 
     def all_gather_packed(self, comm, bits, recv_ptr, rank_stride, overlap=False):
         self._call("sc_all_gather_packed", comm.handle, int(bits), int(recv_ptr), int(rank_stride), 1 if overlap else 0)

@@ -118,19 +118,19 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
         // two ends of its late list: candidates a late view rejected) name the others
         SparseScan sc{e->flags, nbricks, 2, code_full, code_untouched, nullptr};
         SparseLists sl{};
-        sl.list[0] = e->live;
-        sl.count[0] = &e->ctl->nlive[e->last_parity];
-        sl.step[0] = 1;
+        sl.list0 = e->live;
+        sl.count0 = &e->ctl->nlive[e->last_parity];
+        sl.step0 = 1;
         if (e->sparse_late && e->late != nullptr) {
-            sl.list[1] = e->late;
-            sl.count[1] = &e->ctl->nlate;
-            sl.step[1] = 1;
-            sl.list[2] = e->late + (nbricks - 1u);
-            sl.count[2] = &e->ctl->nlate_units;
-            sl.step[2] = -1;
+            sl.list1 = e->late;
+            sl.count1 = &e->ctl->nlate;
+            sl.step1 = 1;
+            sl.list2 = e->late + (nbricks - 1u);
+            sl.count2 = &e->ctl->nlate_units;
+            sl.step2 = -1;
         }
-        // a wavefront per listed brick: 2048 blocks take 8192 bricks in one turn (a plant's 7 577)
-        const uint32_t npack = std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (nbricks + 3u) / 4u));
+        // 16 listed bricks per wavefront and turn: 256 blocks take 16 384 bricks in one turn (a plant's 7 577)
+        const uint32_t npack = std::min<uint32_t>(256u, std::max<uint32_t>(16u, (nbricks + 63u) / 64u));
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(nscan + npack), dim3(kBlock), 0, e->stream, st, g, bys, bzs, sc, nscan,
                            sl, wire, hdr, cnt, cnt_next);
     } else {
@@ -143,11 +143,11 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(nscan), dim3(kBlock), 0, e->stream, st, g, bys, bzs, sc, nscan, none,
                            wire, hdr, cnt, static_cast<SparseCounters *>(nullptr));
         SparseLists sl{};
-        sl.list[0] = e->sparse_work;
-        sl.count[0] = &cnt->nwork;
-        sl.step[0] = 1;
+        sl.list0 = e->sparse_work;
+        sl.count0 = &cnt->nwork;
+        sl.step0 = 1;
         SparseScan noscan{nullptr, nbricks, 0, 0u, 0u, nullptr};
-        const uint32_t npack = std::min<uint32_t>(4096u, std::max<uint32_t>(64u, (nbricks + 3u) / 4u));
+        const uint32_t npack = std::min<uint32_t>(1024u, std::max<uint32_t>(16u, (nbricks + 63u) / 64u));
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(npack), dim3(kBlock), 0, e->stream, st, g, bys, bzs, noscan, 0u, sl, wire,
                            hdr, cnt, cnt_next);
     }
@@ -182,22 +182,37 @@ int sc_get_values_sparse(sc_engine *e, int64_t cap, void *out, int64_t out_bytes
     return SC_OK;
 }
 
-int sc_sparse_headers(int device, void *hip_stream, const void *recv_dev, int64_t rank_bytes, int world, uint32_t *nmixed,
-                      uint32_t *cap) {
+int sc_sparse_headers(int device, void *hip_stream, void *done_event, const void *recv_dev, int64_t rank_bytes, int world,
+                      uint32_t *nmixed, uint32_t *cap) {
     if (!recv_dev || !nmixed || !cap) return fail(SC_ERR_INVALID, "null argument");
     if (world < 1 || world > 4096 || rank_bytes < 64) return fail(SC_ERR_INVALID, "bad world / stride");
     HIP_TRY(hipSetDevice(device));
+    // A page-locked landing place and a stream of the library's own, per device: with `done_event` (what
+    // sc_all_gather_sparse hands out) the host waits for THAT collective and copies beside whatever the collectives'
+    // stream has been given since -- the next batch's collective, which waits for the next batch's carve
+    static std::mutex mu;
+    static SparseHeader *pin[64] = {nullptr};
+    static hipStream_t copy_stream[64] = {nullptr};
+    if (device < 0 || device >= 64) return fail(SC_ERR_INVALID, "device %d", device);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pin[device]) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pin[device]), 4096 * sizeof(SparseHeader), hipHostMallocDefault));
+        HIP_TRY(hipStreamCreateWithFlags(&copy_stream[device], hipStreamNonBlocking));
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    std::vector<SparseHeader> h((size_t)world);
-    // one strided copy of the W headers, behind whatever the stream still has to do (the collective)
-    HIP_TRY(hipMemcpy2DAsync(h.data(), sizeof(SparseHeader), recv_dev, (size_t)rank_bytes, sizeof(SparseHeader), (size_t)world,
+    if (done_event) {
+        HIP_TRY(schost::wait_event(static_cast<hipEvent_t>(done_event)));
+        st = copy_stream[device];
+    }
+    // one strided copy of the W headers
+    HIP_TRY(hipMemcpy2DAsync(pin[device], sizeof(SparseHeader), recv_dev, (size_t)rank_bytes, sizeof(SparseHeader), (size_t)world,
                              hipMemcpyDeviceToHost, st));
     HIP_TRY(schost::wait_stream(st));
     for (int r = 0; r < world; ++r) {
-        int rc = sparse_check_header(h[(size_t)r], rank_bytes, r);
+        int rc = sparse_check_header(pin[device][r], rank_bytes, r);
         if (rc) return rc;
-        nmixed[r] = h[(size_t)r].nmixed;
-        cap[r] = h[(size_t)r].cap;
+        nmixed[r] = pin[device][r].nmixed;
+        cap[r] = pin[device][r].cap;
     }
     return SC_OK;
 }

@@ -71,6 +71,7 @@ struct sc_comm {
     int nranks = 0, rank = 0, device = 0;
     hipStream_t stream = nullptr;  // collectives that run beside the engine's stream
     hipEvent_t ev_ready = nullptr; // the engine's pack has been enqueued: the collective waits for it
+    char *scratch = nullptr;       // (nranks + 1) x 16 bytes: sc_comm_barrier's all-gather
 };
 
 extern "C" {
@@ -105,7 +106,11 @@ int sc_comm_create(sc_comm **out, const void *id, int nranks, int rank, int devi
     }
     hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+    if (he == hipSuccess) he = (hipMalloc)(reinterpret_cast<void **>(&c->scratch), (size_t)(nranks + 1) * 16);
+    if (he == hipSuccess) he = hipMemset(c->scratch, 0, (size_t)(nranks + 1) * 16);
     if (he != hipSuccess) {
+        if (c->scratch) (void)hipFree(c->scratch);
+        if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         (void)rccl().comm_destroy(c->comm);
         delete c;
@@ -121,6 +126,7 @@ void sc_comm_destroy(sc_comm *c) {
     if (c->stream) (void)schost::wait_stream(c->stream);
     if (c->comm) (void)rccl().comm_destroy(c->comm);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->scratch) (void)hipFree(c->scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -141,6 +147,16 @@ int sc_comm_synchronize(sc_comm *c) {
     return SC_OK;
 }
 
+// Every rank has reached this call when it returns anywhere: a 16-byte all-gather on the communicator's stream, waited
+// for on the host (what a bench brackets its timed steps with; torch.distributed is not needed for it).
+int sc_comm_barrier(sc_comm *c) {
+    if (!c) return fail(SC_ERR_INVALID, "null communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    RCCL_TRY(rccl().all_gather(c->scratch, c->scratch + 16, 16, /* ncclInt8 */ 0, c->comm, c->stream));
+    HIP_TRY(schost::wait_stream(c->stream));
+    return SC_OK;
+}
+
 int sc_comm_all_gather(sc_comm *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *hip_stream) {
     if (!c || !send_dev || !recv_dev || bytes_per_rank < 0) return fail(SC_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -157,22 +173,30 @@ int sc_engine_stream(sc_engine *e, void **hip_stream) {
 
 // pack on the engine's stream, gather on `st` (the engine's own, or the communicator's behind an event); the send buffer
 // is busy until the collective has read it: an event the engine's next pack into that buffer waits for
+constexpr int kMaxHeaderRanks = 256;
+
 static int gather_behind_pack(sc_engine *e, sc_comm *c, const void *send, void *recv_dev, int64_t bytes, int overlap,
-                              hipEvent_t *busy) {
+                              hipEvent_t *busy, SparseHeader *hdr_pin = nullptr) {
     if (overlap) {
         HIP_TRY(hipEventRecord(c->ev_ready, e->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
     }
     hipStream_t st = overlap ? c->stream : e->stream;
     RCCL_TRY(rccl().all_gather(send, recv_dev, (size_t)bytes, /* ncclInt8 */ 0, c->comm, st));
-    if (overlap) {
-        if (!*busy) HIP_TRY(hipEventCreateWithFlags(busy, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(*busy, c->stream));
-    }
+    // the ranks' headers to page-locked host memory, behind the collective on its stream (sparse form)
+    if (hdr_pin != nullptr && c->nranks <= kMaxHeaderRanks)
+        HIP_TRY(hipMemcpy2DAsync(hdr_pin, sizeof(SparseHeader), recv_dev, (size_t)bytes, sizeof(SparseHeader), (size_t)c->nranks,
+                                 hipMemcpyDeviceToHost, st));
+    // an event behind the collective (and that copy), whichever stream it is on: what a reader of the receive buffer
+    // waits for without queueing behind the NEXT batch's collective, and -- overlap -- what the engine's next pack into
+    // this send buffer waits for
+    if (!*busy) HIP_TRY(hipEventCreateWithFlags(busy, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(*busy, st));
     return SC_OK;
 }
 
-int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, int64_t rank_stride, int overlap) {
+int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, int64_t rank_stride, int overlap,
+                         void **done_event, const void **headers_host) {
     if (!e || !c || !recv_dev) return fail(SC_ERR_INVALID, "null argument");
     if (c->device != e->device) return fail(SC_ERR_INVALID, "communicator on device %d, engine on %d", c->device, e->device);
     if (cap <= 0) return fail(SC_ERR_INVALID, "every rank names the same capacity (bricks)");
@@ -192,9 +216,28 @@ int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, 
     if (rc) return rc;
     if (rank_stride < bytes)
         return fail(SC_ERR_INVALID, "rank stride of %lld bytes for a buffer of %lld", (long long)rank_stride, (long long)bytes);
-    rc = gather_behind_pack(e, c, ptr, recv_dev, rank_stride, overlap, &e->sparse_busy[q]);
+    if (!e->sparse_hdr_pin[q])
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->sparse_hdr_pin[q]), kMaxHeaderRanks * sizeof(SparseHeader), hipHostMallocDefault));
+    rc = gather_behind_pack(e, c, ptr, recv_dev, rank_stride, overlap, &e->sparse_busy[q], e->sparse_hdr_pin[q]);
     if (rc) return rc;
     e->sparse_busy_armed[q] = overlap != 0;
+    if (done_event) *done_event = e->sparse_busy[q];
+    if (headers_host) *headers_host = c->nranks <= kMaxHeaderRanks ? e->sparse_hdr_pin[q] : nullptr;
+    return SC_OK;
+}
+
+int sc_sparse_wait_headers(void *done_event, const void *headers_host, int64_t rank_bytes, int world, uint32_t *nmixed,
+                           uint32_t *cap) {
+    if (!done_event || !headers_host || !nmixed || !cap) return fail(SC_ERR_INVALID, "null argument");
+    if (world < 1 || world > kMaxHeaderRanks) return fail(SC_ERR_INVALID, "bad world");
+    HIP_TRY(schost::wait_event(static_cast<hipEvent_t>(done_event)));
+    const SparseHeader *h = static_cast<const SparseHeader *>(headers_host);
+    for (int r = 0; r < world; ++r) {
+        int rc = sparse_check_header(h[r], rank_bytes, r);
+        if (rc) return rc;
+        nmixed[r] = h[r].nmixed;
+        cap[r] = h[r].cap;
+    }
     return SC_OK;
 }
 

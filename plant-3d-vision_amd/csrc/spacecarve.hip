@@ -214,6 +214,9 @@ struct sc_engine {
     hipEvent_t sparse_busy[2] = {nullptr, nullptr}, packed_busy = nullptr;
     bool sparse_busy_armed[2] = {false, false}, packed_busy_armed = false;
     size_t packed_cap = 0;                 // bytes of packed_labels
+    // sc_all_gather_sparse: the ranks' headers of a gather land here (page-locked), copied behind the collective on its
+    // stream: a reader waits for the gather's event and reads host memory (sc_sparse_wait_headers)
+    SparseHeader *sparse_hdr_pin[2] = {nullptr, nullptr};
     size_t wire_stage_words = 0;
     int64_t unit_cull = 1;     // the dense stage asks the views packed ahead about every live brick's units (0: not;
                                // 2: even when the tiles settled less than half of the bricks)
@@ -1735,6 +1738,8 @@ void sc_destroy(sc_engine *e) {
     for (int q = 0; q < 2; ++q)
         if (e->sparse_busy[q]) (void)hipEventDestroy(e->sparse_busy[q]);
     if (e->packed_busy) (void)hipEventDestroy(e->packed_busy);
+    for (int q = 0; q < 2; ++q)
+        if (e->sparse_hdr_pin[q]) (void)hipHostFree(e->sparse_hdr_pin[q]);
     if (e->sparse_cnt) (void)hipFree(e->sparse_cnt);
     if (e->sparse_work) (void)hipFree(e->sparse_work);
     if (e->wire_stage) (void)hipHostFree(e->wire_stage);

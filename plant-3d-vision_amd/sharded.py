@@ -103,6 +103,13 @@ class DevMem:
             self._engine.dev_free(self.ptr)
             self.ptr = 0
 
+    def __del__(self):
+        try:
+            if self.ptr and getattr(self._engine, "_h", 0):
+                self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
 
 class SparseGrid:
     """The assembled grid in the BRICK-SPARSE form (``include/spacecarve.h``): every rank's header, one code per
@@ -113,10 +120,16 @@ class SparseGrid:
     ``occupancy_device()`` the uint8 ``label == 1`` volume ``proc3d.vol2pcd`` reads (proc3d.py:515);
     ``to_host()`` the int32 array of cl.py:229-232 (widened by the library's host pool)."""
 
-    def __init__(self, recv, rank_bytes, world, shape, device, cap, stream=0, on_gpu=True, engine=None):
+    def __init__(self, recv, rank_bytes, world, shape, device, cap, stream=0, on_gpu=True, engine=None, done_event=0,
+                 headers_host=0):
         self.recv, self.rank_bytes, self.world = recv, int(rank_bytes), int(world)
         self.shape, self.device, self.cap = [int(s) for s in shape], int(device), int(cap)
         self.stream, self.on_gpu, self._engine = int(stream or 0), bool(on_gpu), engine
+        #: the event the library recorded behind this grid's collective: ``verify`` waits for it and not for whatever the
+        #: collectives' stream has been given since (the next batch's collective, which waits for the next batch's carve)
+        self.done_event = int(done_event or 0)
+        #: ... and the page-locked copy of the ranks' headers the library made behind that collective
+        self.headers_host = int(headers_host or 0)
         self.nmixed = None
 
     def _ptr(self):
@@ -139,7 +152,12 @@ class SparseGrid:
                 if not stream and hasattr(self.recv, "is_cuda"):
                     import torch
                     stream = torch.cuda.current_stream(self.recv.device).cuda_stream
-                nm, cp = nat.sparse_headers(self.device, stream, self._ptr(), self.rank_bytes, self.world)
+                if self.done_event and self.headers_host:
+                    nm, cp = nat.sparse_wait_headers(self.done_event, self.headers_host, self.rank_bytes, self.world)
+                else:
+                    nm, cp = nat.sparse_headers(self.device, stream, self._ptr(), self.rank_bytes, self.world,
+                                                done_event=self.done_event)
+                self.done_event = self.headers_host = 0  # (the engine uses them again two gathers later)
             else:
                 buf = self._host_bytes().reshape(self.world, self.rank_bytes)
                 hdr = np.ascontiguousarray(buf[:, :64]).view(np.uint32)
@@ -283,6 +301,7 @@ class ShardedBackprojection:
         self._sparse_cap = max(1024, self._bricks_max() // 8)
         self._sparse_recv = [None, None]
         self._sparse_turn = 0
+        self._streams = None
 
     def _bricks_max(self):
         ny, nz = self.shape[1], self.shape[2]
@@ -508,9 +527,11 @@ class ShardedBackprojection:
                     rbuf = buf
                 else:
                     rbuf = recv
-                self._engine.all_gather_sparse(self.comm, cap, rbuf.ptr, stride, overlap=overlap)
+                ev, hh = self._engine.all_gather_sparse(self.comm, cap, rbuf.ptr, stride, overlap=overlap)
+                if self._streams is None:
+                    self._streams = (self.comm.stream(), self._engine.stream())
                 grid = SparseGrid(rbuf, stride, W, self.shape, self.device, cap,
-                                  stream=self.comm.stream() if overlap else self._engine.stream(), engine=self._engine)
+                                  stream=self._streams[0 if overlap else 1], engine=self._engine, done_event=ev, headers_host=hh)
             else:
                 grid = self._all_gather_sparse_torch(cap, stride, recv, overlap)
             if not check:
@@ -522,6 +543,11 @@ class ShardedBackprojection:
                 self._sparse_cap = min(self._bricks_max(), (ex.needed + ex.needed // 8 + 15) & ~15)
                 recv = None
                 continue
+            # far fewer mixed bricks than slots: the next gathers travel lighter (every rank reads the same headers and
+            # changes its capacity alike); a later batch that needs more is gathered again, as above
+            worst = int(max(int(n) for n in grid.nmixed))
+            if 2 * worst < cap and cap > 1024:
+                self._sparse_cap = max(1024, (worst + worst // 2 + 15) & ~15)
             return grid.unpack(widen=widen, out=out) if unpack else grid
 
     def _all_gather_sparse_torch(self, cap, stride, recv, overlap):
@@ -664,6 +690,9 @@ class ShardedBackprojection:
         Carve labels of a default value of -1 / 0 / 1 take the 2-bit wire instead (``_gather_to_host_2bit``);
         ``out``: an int32 array of the grid's size to widen into on ``dst`` -- one whose pages have been touched
         takes 512^3 labels in ~4 ms, a fresh ``np.empty`` ~30 (first-touch page faults, not the transfer)."""
+        if compress is None and (self.world_size > 1 or self.force_collective) and self.dtype == np.int32 \
+                and float(self.default_value) in (-1.0, 0.0, 1.0) and hasattr(self._engine, "get_values_sparse"):
+            compress = "sparse"  # (round 6: the default wire of a sharded run's labels)
         if compress == "sparse":
             # (round 6) codes + mixed bricks only over the collective (every rank ends with every rank's buffer: they
             # are small), ONE PCIe copy on ``dst``, widened and put in global order by the host pool

@@ -142,7 +142,7 @@ def pack_sparse_np(values, first, stride, cap=0):
 
 def sparse_header_np(buf):
     h = np.ascontiguousarray(buf[:64]).view(np.uint32)
-    keys = ("magic", "version", "bits", "nbricks", "cap", "nmixed", "planes", "ny", "nz", "bricks_y", "bricks_z", "first", "stride")
+    keys = ("magic", "version", "bits", "nbricks", "cap", "nmixed", "planes", "ny", "nz", "bricks_y", "bricks_z", "first", "stride", "nread")
     return {k: int(h[i]) for i, k in enumerate(keys)}
 
 
