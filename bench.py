@@ -135,6 +135,7 @@ def parse():
                     help="N = 1: a fresh child process (started before this one touches the GPU) times import -> "
                          "sc_create -> ONE 72-view batch -> synchronize, once: cold_process_first_batch_ms")
     ap.add_argument("--cold-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cold-files-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--parity-check", default="on", choices=["on", "off"],
                     help="outside every timed region: fused digest == per-view digest, a 20 000-voxel closed-form "
                          "sample against the oracle's projection, the histogram; a mismatch exits non-zero")
@@ -949,6 +950,99 @@ def cold_child(a):
     sys.stdout.flush()
 
 
+def write_gray_png(path, img):
+    """8-bit greyscale, non-interlaced PNG with the standard library (what `io.write_image(f, im, 'png')` makes of a
+    uint8 mask of tasks/proc2d.py, as far as a reader is concerned)."""
+    import struct
+    import zlib
+    H, W = img.shape
+    raw = np.empty((H, W + 1), dtype=np.uint8)
+    raw[:, 0] = 0  # filter type 0 on every row
+    raw[:, 1:] = img
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw.tobytes(), 1)) + chunk(b"IEND", b""))
+
+
+def cold_files_child(a):
+    """The body of `bench.py --cold-files-child DIR`: a fresh process from its first line to the int32 volume in host
+    memory -- import of the drop-in module, the 72 PNG files of DIR (poses in DIR/poses.npz), Backprojection(...),
+    process_fileset (cl.py:234-305 of the reference): what a cold `Voxels.run` (tasks/cl.py:100, 162-165) costs."""
+    t0 = time.perf_counter()
+    from plant3dvision_amd.cl import Backprojection
+    from plant3dvision_amd import scenes
+    t1 = time.perf_counter()
+    meta = np.load(os.path.join(a.cold_files_child, "poses.npz"))
+    shape, origin, vs = [int(x) for x in meta["shape"]], [float(x) for x in meta["origin"]], float(meta["vs"])
+
+    class PngFile:
+        def __init__(self, fid, path, md):
+            self.id, self.path, self._md = fid, path, md
+
+        def get_metadata(self, key=None, default=None):
+            return self._md if key is None else self._md.get(key, default)
+
+        def read_raw(self):  # plantdb's File.read_raw(): the bytes io.read_image decodes
+            with open(self.path, "rb") as f:
+                return f.read()
+
+    files = [PngFile("%05d_mask" % q, os.path.join(a.cold_files_child, "%05d_mask.png" % q),
+                     {"colmap_camera": scenes.camera_dict(meta["K"][q], meta["R"][q], meta["t"][q])})
+             for q in range(len(meta["K"]))]
+    t2 = time.perf_counter()
+    bp = Backprojection(shape, origin, vs)
+    t3 = time.perf_counter()
+    vol = bp.process_fileset(files, "colmap_camera")
+    t4 = time.perf_counter()
+    hist = [int((vol == -1).sum()), int((vol == 0).sum()), int((vol == 1).sum())]
+    # the same files again through the warm engine: reads + decode + carve + read-back without any set-up
+    bp.clear()
+    t5 = time.perf_counter()
+    bp.process_fileset(files, "colmap_camera")
+    t6 = time.perf_counter()
+    bp.close()
+    out = {"import_ms": (t1 - t0) * 1e3, "file_list_ms": (t2 - t1) * 1e3, "constructor_ms": (t3 - t2) * 1e3,
+           "process_fileset_ms": (t4 - t3) * 1e3, "files_to_volume_ms": (t4 - t0) * 1e3,
+           "warm_files_to_volume_ms": (t6 - t5) * 1e3, "labels_histogram": hist}
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
+def cold_files(a, views, shape, origin, vs):
+    """`files_to_volume_ms` of a fresh process, with the engine's device half deferred (the default) and, for comparison,
+    all inside the constructor (SC_ASYNC_CREATE=0); the parent writes the PNG files first and never touches the GPU."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="sc_cold_files_")
+    try:
+        for q, (K, R, t, m) in enumerate(views):
+            write_gray_png(os.path.join(tmp, "%05d_mask.png" % q), m)
+        np.savez(os.path.join(tmp, "poses.npz"), K=np.stack([v[0] for v in views]), R=np.stack([v[1] for v in views]),
+                 t=np.stack([v[2] for v in views]), shape=np.array(shape), origin=np.array(origin, dtype=np.float64), vs=float(vs))
+        res = {}
+        for name, flag in (("deferred", "1"), ("all_in_constructor", "0")):
+            env = dict(os.environ, SC_ASYNC_CREATE=flag)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-files-child", tmp], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            if r.returncode != 0:
+                res[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+                continue
+            for ln in r.stdout.decode(errors="replace").splitlines():
+                if ln.startswith("{"):
+                    res[name] = json.loads(ln)
+        return res
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cold_process(a):
     """Runs `bench.py --cold-child` as a fresh process (this one has not touched the GPU yet) with the library's
     allocation trace on; returns its figures + the allocations of a millisecond or more."""
@@ -1093,6 +1187,9 @@ def main():
     if a.cold_child:
         cold_child(a)
         return
+    if a.cold_files_child:
+        cold_files_child(a)
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))  # the ranks are fresh child processes; this one never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
@@ -1117,8 +1214,20 @@ def main():
     if world == 1 and rank == 0 and a.path == "fused" and not a.rccl_rehearsal and not profiled and \
             (a.cold_process == "on" or (a.cold_process == "auto" and a.cold_reps > 0)):
         from plant3dvision_amd import scenes as _scenes
-        cached_scene(a, _scenes, global_shape(a.n, 1))
+        _g, _o, _v, _views = cached_scene(a, _scenes, global_shape(a.n, 1))
         cold_proc = cold_process(a)
+        cf = cold_files(a, _views, _g, _o, _v)
+        cold_proc["files_to_volume"] = cf
+        if isinstance(cf.get("deferred"), dict) and "files_to_volume_ms" in cf["deferred"]:
+            cold_proc["files_to_volume_ms"] = cf["deferred"]["files_to_volume_ms"]
+        cold_proc["files_to_volume_note"] = (
+            "a fresh process, its first line to the int32 volume in host memory: import of the drop-in module, 72 PNG files, "
+            "Backprojection(...), process_fileset (cl.py:234-305).  `deferred` (the default): the engine's device half -- "
+            "hip_runtime_init_ms + create_ms above -- runs on a thread of the library's from the constructor on "
+            "(sc_create_ex, SC_CREATE_DEFERRED) and the files are read and decoded beside it; `all_in_constructor`: "
+            "SC_ASYNC_CREATE=0, the constructor waits for all of it (rounds 1-5); warm_files_to_volume_ms: the same files "
+            "again through the engine that is up (reads + decode + carve + read-back)")
+        del _views
     # ONE JSON line on stdout: RCCL prints a version banner to stdout when its communicator comes up, so
     # everything but that line (libraries included, file descriptor 1) goes to stderr from here on
     sys.stdout.flush()

@@ -123,6 +123,24 @@ int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_
                      const float origin[3], float voxel_size, int mode, float default_value,
                      int device);
 
+/*
+ * The three above in one call, with flags: the engine owns `planes` x-planes first, first + stride, ... of the grid
+ * (sc_create: 0, 1, nx; sc_create_slab: i0, 1, i1 - i0; sc_create_cyclic: first, stride, ceil((nx - first) / stride)).
+ * SC_CREATE_DEFERRED (round 6): the arguments are judged now, the DEVICE half of the set-up -- runtime initialisation,
+ * the process's first stream, the state's allocation: 130-240 ms in a fresh process, where cl.py:29-30 pays its context
+ * and queue at import -- runs on a thread of the library's; the call returns at once, every later call that needs the
+ * device joins that thread first and reports ITS failure (no device, not a gfx950, out of memory) as its own, and
+ * sc_process_png_views decodes its files beside it: a cold `Voxels.run` (tasks/cl.py:100, 162-165) hides the decode
+ * and whatever else the host does between the two calls behind the set-up.
+ */
+/* What cl.py:29-30 does at import (the context and the queue), without blocking the importer: a thread of the library's
+ * initialises the runtime on `device` and creates its first stream; the first engine there takes that stream.  Returns
+ * at once; a failure is the first engine's to report. */
+int sc_prewarm(int device);
+#define SC_CREATE_DEFERRED 1
+int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride, int64_t planes,
+                 const float origin[3], float voxel_size, int mode, float default_value, int device, int flags);
+
 void sc_destroy(sc_engine *e);
 
 /* Backprojection.clear (cl.py:307-311): reset state to default_value, drop pending views. */

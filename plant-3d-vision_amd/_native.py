@@ -28,6 +28,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "spacecarve.h")
 SC_OK = 0
 SC_ERR_INVALID, SC_ERR_DEVICE, SC_ERR_NOMEM, SC_ERR_STATE = -1, -2, -3, -4
 SC_MODE_CARVE, SC_MODE_AVERAGE = 0, 1
+SC_CREATE_DEFERRED = 1
 SC_MASK_U8, SC_MASK_I32, SC_MASK_F32, SC_MASK_U8_INV, SC_MASK_BOOL_INV = 0, 1, 2, 3, 4
 SC_MASK_U8_LUT = 5
 SC_OPT_VIEWS_PER_LAUNCH, SC_OPT_VIEW_ORDER, SC_OPT_TIME_KERNELS, SC_OPT_MAX_PENDING = 1, 2, 3, 4
@@ -54,6 +55,8 @@ _SIGNATURES = {
     "sc_create": ("i", ["p", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_create_slab": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_create_cyclic": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
+    "sc_prewarm": ("i", ["i"]),
+    "sc_create_ex": ("i", ["p", "q", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i", "i"]),
     "sc_destroy": ("v", ["p"]),
     "sc_clear": ("i", ["p"]),
     "sc_set_option": ("i", ["p", "i", "q"]),
@@ -636,6 +639,20 @@ def png_decode_gray8(raw):
     return out
 
 
+def prewarm(device=None):
+    """``sc_prewarm``: bring the HIP runtime up and make the device's first stream on a thread of the library's (what the
+    reference's module-global context and queue cost at import, cl.py:29-30, without blocking the importer).  Nothing
+    happens without a ROCm device node, with ``SC_PREWARM=0``, or when the library is not built."""
+    if os.environ.get("SC_PREWARM", "1") == "0" or not os.path.exists("/dev/kfd") or not os.path.exists(LIB_PATH):
+        return False
+    if device is None:
+        device = int(os.environ.get("SC_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0)
+    try:
+        return backend().call("sc_prewarm", int(device)) == SC_OK
+    except Exception:  # noqa: BLE001  (an optimisation only)
+        return False
+
+
 def device_count():
     out = np.zeros(1, dtype=np.int32)
     check(backend().call("sc_device_count", addr(out)), "sc_device_count")
@@ -646,9 +663,11 @@ class Engine:
     """Owning handle of one ``sc_engine`` (whole grid or an X-slab of it)."""
 
     def __init__(self, shape, origin, voxel_size, mode, default_value=0.0, device=0, slab=None,
-                 cyclic=None):
+                 cyclic=None, deferred=False):
         """slab=(i0, i1): the engine owns x-planes [i0, i1); cyclic=(first, stride): planes
-        first, first+stride, ... ; neither: the whole grid."""
+        first, first+stride, ... ; neither: the whole grid.  deferred: ``SC_CREATE_DEFERRED`` -- the arguments are
+        judged now, the device half of the set-up runs on a thread of the library's and the first call that needs
+        the device joins it (and raises what it failed with)."""
         self._b = backend()
         self._h = 0
         nx, ny, nz = (int(s) for s in shape)
@@ -657,7 +676,12 @@ class Engine:
         self.planes = None
         if slab is not None and cyclic is not None:
             raise ValueError("slab and cyclic are exclusive")
-        if cyclic is not None:
+        if deferred and cyclic is None:
+            i0, i1 = (0, nx) if slab is None else (int(slab[0]), int(slab[1]))
+            rc = self._b.call("sc_create_ex", addr(out), nx, ny, nz, i0, 1, i1 - i0, addr(origin32),
+                              float(np.float32(voxel_size)), int(mode), float(default_value), int(device), SC_CREATE_DEFERRED)
+            self.slab = (i0, i1)
+        elif cyclic is not None:
             first, stride = int(cyclic[0]), int(cyclic[1])
             rc = self._b.call("sc_create_cyclic", addr(out), nx, ny, nz, first, stride, addr(origin32),
                               float(np.float32(voxel_size)), int(mode), float(default_value),

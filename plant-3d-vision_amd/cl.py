@@ -176,6 +176,12 @@ def _assign_and_return(dst, src):
     return src
 
 
+# The reference creates its OpenCL context and queue when the module is imported (cl.py:29-30).  Here the runtime comes
+# up on a thread of the library's from this import on (nat.prewarm), beside whatever the importer does before it builds
+# its first Backprojection; nothing blocks, and nothing happens on a box without a ROCm device (SC_PREWARM=0: never).
+nat.prewarm()
+
+
 class Backprojection(object):
     """Back-projection onto a voxel volume (drop-in for ``plant3dvision.cl.Backprojection``).
 
@@ -245,8 +251,16 @@ class Backprojection(object):
             self._engine = nat.EngineGroup(self.shape, self.origin, self.voxel_size, self._mode, self.device,
                                            default_value=float(self.default_value))
         else:
+            # The device half of the engine's set-up runs beside what the caller does next (SC_CREATE_DEFERRED): the
+            # reference pays its context and queue at import (cl.py:29-30), a fresh process here pays 130-240 ms of
+            # runtime set-up -- behind which the file loop's reads and decodes now hide (process_label).  "No device at
+            # all" is still this constructor's error (the device node is looked at, not the runtime); a device that
+            # is there and unusable (not a gfx950, out of memory) is the first call's.  SC_ASYNC_CREATE=0: all here.
+            deferred = os.environ.get("SC_ASYNC_CREATE", "1") != "0"
+            if deferred and not os.path.exists("/dev/kfd"):
+                raise nat.SpaceCarveError("no ROCm device: /dev/kfd is missing (this engine has no CPU path)")
             self._engine = nat.Engine(self.shape, self.origin, self.voxel_size, self._mode,
-                                      default_value=float(self.default_value), device=self.device)
+                                      default_value=float(self.default_value), device=self.device, deferred=deferred)
         self._lut = None
         self._values_d = None
         if self.views_per_launch:

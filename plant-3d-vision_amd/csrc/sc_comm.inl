@@ -167,6 +167,8 @@ int sc_comm_all_gather(sc_comm *c, const void *send_dev, void *recv_dev, int64_t
 
 int sc_engine_stream(sc_engine *e, void **hip_stream) {
     if (!e || !hip_stream) return fail(SC_ERR_INVALID, "null argument");
+    int rcw = wait_setup(e);
+    if (rcw) return rcw;
     *hip_stream = e->stream;
     return SC_OK;
 }

@@ -42,6 +42,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,13 @@ struct sc_engine {
     bool fresh = true;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // sc_create_ex with SC_CREATE_DEFERRED: the device half of the set-up (runtime initialisation, the process's first
+    // stream, the state's allocation: 130-240 ms in a fresh process) runs on a thread of its own; every entry point that
+    // needs the device joins it first (use_device), sc_process_png_views decodes its files beside it
+    std::thread setup_thread;
+    bool setup_pending = false;
+    int setup_rc = SC_OK;
+    std::string setup_err;
 
     // deferred views
     std::vector<ViewDesc> pending;
@@ -299,7 +307,19 @@ struct sc_engine {
 
 namespace {
 
+// the deferred half of the set-up has finished (sc_create_ex); its failure is every later call's failure
+int wait_setup(sc_engine *e) {
+    if (e->setup_pending) {
+        if (e->setup_thread.joinable()) e->setup_thread.join();
+        e->setup_pending = false;
+    }
+    if (e->setup_rc != SC_OK) return fail(e->setup_rc, "%s", e->setup_err.c_str());
+    return SC_OK;
+}
+
 int use_device(sc_engine *e) {
+    int rc = wait_setup(e);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     return SC_OK;
 }
@@ -1578,9 +1598,15 @@ std::mutex g_stream_mu;
 std::vector<std::pair<int, hipStream_t>> g_stream_pool;  // (device, idle stream)
 constexpr size_t kStreamPoolMax = 16;
 
+// sc_prewarm: a thread that is bringing the runtime up and making the device's first stream; whoever wants a stream of
+// that device waits for it (one creation, not two side by side) and finds the stream on the list
+std::condition_variable g_prewarm_cv;
+int g_prewarm_running[64] = {0};
+
 hipError_t take_stream(int device, hipStream_t *out) {
     {
-        std::lock_guard<std::mutex> lk(g_stream_mu);
+        std::unique_lock<std::mutex> lk(g_stream_mu);
+        if (device >= 0 && device < 64) g_prewarm_cv.wait(lk, [&] { return g_prewarm_running[device] == 0; });
         for (size_t i = 0; i < g_stream_pool.size(); ++i)
             if (g_stream_pool[i].first == device) {
                 *out = g_stream_pool[i].second;
@@ -1602,21 +1628,9 @@ void give_stream_back(int device, hipStream_t s) {
     (void)hipStreamDestroy(s);
 }
 
-// The engine owns the x-planes  i0, i0 + istride, ...  (`planes` of them) of the global grid.
-int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t istride,
-           int64_t planes, const float *origin, float vs, int mode, float default_value, int device) {
-    if (!out) return fail(SC_ERR_INVALID, "null out pointer");
-    *out = nullptr;
-    if (!origin) return fail(SC_ERR_INVALID, "null origin");
-    if (nx <= 0 || ny <= 0 || nz <= 0) return fail(SC_ERR_INVALID, "shape must be positive");
-    // int -> float of an index must be exact (SURVEY 8c item 4)
-    if (nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24))
-        return fail(SC_ERR_INVALID, "axis longer than 2^24 voxels");
-    if (i0 < 0 || istride < 1 || planes < 1 || i0 + (planes - 1) * istride >= nx)
-        return fail(SC_ERR_INVALID, "bad slab / plane set (first %lld, stride %lld, planes %lld of %lld)",
-                    (long long)i0, (long long)istride, (long long)planes, (long long)nx);
-    if (mode != SC_MODE_CARVE && mode != SC_MODE_AVERAGE)
-        return fail(SC_ERR_INVALID, "unknown mode %d", mode);
+// The device half of an engine's set-up: the device is there and is a gfx950, a stream, the state.
+int device_setup(sc_engine *e) {
+    const int device = e->device;
     // `device` is a HIP ordinal; only that device has to be a gfx950
     int ndev = 0;
     hipError_t hq = hipGetDeviceCount(&ndev);
@@ -1631,6 +1645,30 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
             return fail(SC_ERR_DEVICE, "device %d is %s; this engine is built for gfx950 only", device,
                         prop.gcnArchName);
     }
+    hipError_t he = sctrace::timed("hipSetDevice", __LINE__, 0, [&] { return hipSetDevice(device); });
+    if (he == hipSuccess) he = take_stream(device, &e->own_stream);
+    if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->npitch * 4);
+    if (he != hipSuccess)
+        return fail(he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE, "engine setup failed: %s", hipGetErrorString(he));
+    e->stream = e->own_stream;
+    return SC_OK;
+}
+
+// The engine owns the x-planes  i0, i0 + istride, ...  (`planes` of them) of the global grid.
+int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int64_t istride,
+           int64_t planes, const float *origin, float vs, int mode, float default_value, int device, bool deferred = false) {
+    if (!out) return fail(SC_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!origin) return fail(SC_ERR_INVALID, "null origin");
+    if (nx <= 0 || ny <= 0 || nz <= 0) return fail(SC_ERR_INVALID, "shape must be positive");
+    // int -> float of an index must be exact (SURVEY 8c item 4)
+    if (nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24))
+        return fail(SC_ERR_INVALID, "axis longer than 2^24 voxels");
+    if (i0 < 0 || istride < 1 || planes < 1 || i0 + (planes - 1) * istride >= nx)
+        return fail(SC_ERR_INVALID, "bad slab / plane set (first %lld, stride %lld, planes %lld of %lld)",
+                    (long long)i0, (long long)istride, (long long)planes, (long long)nx);
+    if (mode != SC_MODE_CARVE && mode != SC_MODE_AVERAGE)
+        return fail(SC_ERR_INVALID, "unknown mode %d", mode);
     sc_engine *e = new (std::nothrow) sc_engine();
     if (!e) return fail(SC_ERR_NOMEM, "host allocation failed");
     e->device = device;
@@ -1642,17 +1680,32 @@ int create(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t i0, int6
     memcpy(e->origin, origin, sizeof e->origin);
     e->vs = vs;
     e->default_value = default_value;
-    hipError_t he = sctrace::timed("hipSetDevice", __LINE__, 0, [&] { return hipSetDevice(device); });
-    if (he == hipSuccess) he = take_stream(device, &e->own_stream);
-    if (he == hipSuccess) he = hipMalloc(&e->state, (size_t)e->npitch * 4);
-    if (he != hipSuccess) {
-        int code = he == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_DEVICE;
-        fail(code, "engine setup failed: %s", hipGetErrorString(he));
-        sc_destroy(e);
-        return code;
-    }
-    e->stream = e->own_stream;
     e->fresh = true;
+    if (deferred) {
+        // the device half on a thread of its own: the caller goes on (reads its files, decodes them) and the first
+        // call that needs the device joins -- and takes the failure, if there is one
+        e->setup_pending = true;
+        try {
+            e->setup_thread = std::thread([e]() {
+                e->setup_rc = device_setup(e);
+                if (e->setup_rc != SC_OK) e->setup_err = g_err;  // (the thread's own message)
+            });
+        } catch (...) {
+            e->setup_pending = false;
+            int rc = device_setup(e);
+            if (rc) {
+                sc_destroy(e);
+                return rc;
+            }
+        }
+        *out = e;
+        return SC_OK;
+    }
+    int rc = device_setup(e);
+    if (rc) {
+        sc_destroy(e);
+        return rc;
+    }
     *out = e;
     return SC_OK;
 }
@@ -1706,8 +1759,54 @@ int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_
     return create(out, nx, ny, nz, first, stride, planes, origin, voxel_size, mode, default_value, device);
 }
 
+// What cl.py:29-30 does at import -- the context and the queue -- without blocking the importer: a thread of the library's
+// initialises the runtime on `device` and creates the device's first non-blocking stream (84-147 ms in a fresh process),
+// which the first engine on that device then takes from the idle-stream list.  Returns at once; errors are the first
+// engine's to report (it runs the same calls).
+int sc_prewarm(int device) {
+    if (device < 0 || device >= 64) return fail(SC_ERR_INVALID, "device %d", device);
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (g_prewarm_running[device]) return SC_OK;
+        for (auto &p : g_stream_pool)
+            if (p.first == device) return SC_OK;  // a stream is waiting already
+        g_prewarm_running[device] = 1;
+    }
+    try {
+        std::thread([device]() {
+            hipStream_t s = nullptr;
+            int n = 0;
+            bool ok = hipGetDeviceCount(&n) == hipSuccess && device < n && hipSetDevice(device) == hipSuccess &&
+                      hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+            std::lock_guard<std::mutex> lk(g_stream_mu);
+            if (ok) g_stream_pool.emplace_back(device, s);
+            g_prewarm_running[device] = 0;
+            g_prewarm_cv.notify_all();
+        }).detach();
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        g_prewarm_running[device] = 0;
+        g_prewarm_cv.notify_all();
+    }
+    return SC_OK;
+}
+
+int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride, int64_t planes,
+                 const float origin[3], float voxel_size, int mode, float default_value, int device, int flags) {
+    if (flags & ~SC_CREATE_DEFERRED) return fail(SC_ERR_INVALID, "unknown creation flags %d", flags);
+    return create(out, nx, ny, nz, first, stride, planes, origin, voxel_size, mode, default_value, device,
+                  (flags & SC_CREATE_DEFERRED) != 0);
+}
+
 void sc_destroy(sc_engine *e) {
     if (!e) return;
+    if (e->setup_pending && e->setup_thread.joinable()) e->setup_thread.join();
+    e->setup_pending = false;
+    if (e->setup_rc != SC_OK) {  // the device half never came up: nothing but host memory to give back
+        if (e->own_stream) give_stream_back(e->device, e->own_stream);
+        delete e;
+        return;
+    }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)schost::wait_stream(e->stream);
     for (int k = 0; k < kNumKernels; ++k)
@@ -1779,6 +1878,10 @@ int sc_clear(sc_engine *e) {
 }
 
 int sc_set_option(sc_engine *e, int key, int64_t value) {
+    if (e) {
+        int rcw = wait_setup(e);  // (some keys create events or move buffers)
+        if (rcw) return rcw;
+    }
     if (!e) return fail(SC_ERR_INVALID, "null engine");
     switch (key) {
         case SC_OPT_VIEWS_PER_LAUNCH:
@@ -2109,15 +2212,28 @@ int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, co
         offs[(size_t)q] = total;
         total += ((size_t)Hs[(size_t)q] * (size_t)((Ws[(size_t)q] + kTile - 1) / kTile) * 4 + 255) & ~(size_t)255;
     }
-    int rc = use_device(e);
-    if (rc) return rc;
-    rc = materialize_deferred(e);
-    if (rc) return rc;
+    // An engine whose device half is still coming up (sc_create_ex, SC_CREATE_DEFERRED): the files are decoded into
+    // plain host memory beside it and copied to the page-locked arena once the device is there -- 14 MB, 2 ms, against
+    // the 15 ms of decoding that would otherwise wait for 130-240 ms of runtime set-up
+    const bool beside_setup = e->setup_pending;
+    std::vector<char> heap;
+    int rc = SC_OK;
     char *base = nullptr;
-    rc = hostbits_reserve(e, total, &base);  // one reservation: the arena does not move while the threads write
-    if (rc) return rc;
-    auto &arena = e->hb[e->hb_cur];
-    const uint64_t base_off = (uint64_t)(base - arena.pin);
+    if (beside_setup) {
+        try {
+            heap.resize(total);
+        } catch (...) {
+            return fail(SC_ERR_NOMEM, "out of host memory while decoding the masks");
+        }
+        base = heap.data();
+    } else {
+        rc = use_device(e);
+        if (rc) return rc;
+        rc = materialize_deferred(e);
+        if (rc) return rc;
+        rc = hostbits_reserve(e, total, &base);  // one reservation: the arena does not move while the threads write
+        if (rc) return rc;
+    }
     // decode + pack, a file per thread at a time.  Threads of this call's own (16 by default: inflate is the floor
     // of the files -> volume time, ~1.3 ms per mask and thread, and the pool's 8 are sized for the per-mask hand-overs)
     int nth = threads > 0 ? threads : 16;
@@ -2160,13 +2276,25 @@ int sc_process_png_views(sc_engine *e, int V, const float *K, const float *R, co
         for (auto &th : pool) th.join();
     }
     if (nomem.load()) {
-        arena.used -= total;
+        if (!beside_setup) e->hb[e->hb_cur].used -= total;
         return fail(SC_ERR_NOMEM, "out of host memory while decoding the masks");
     }
     if (bad.load() >= 0) {
-        arena.used -= total;  // nothing of this call stays
+        if (!beside_setup) e->hb[e->hb_cur].used -= total;  // nothing of this call stays
         return fail(SC_ERR_INVALID, "file %d could not be decoded", bad.load());
     }
+    if (beside_setup) {
+        rc = use_device(e);  // joins the set-up
+        if (rc) return rc;
+        rc = materialize_deferred(e);
+        if (rc) return rc;
+        char *pinned = nullptr;
+        rc = hostbits_reserve(e, total, &pinned);
+        if (rc) return rc;
+        memcpy(pinned, heap.data(), total);
+        base = pinned;
+    }
+    const uint64_t base_off = (uint64_t)(base - e->hb[e->hb_cur].pin);
     for (int q = 0; q < V; ++q) {
         rc = hostbits_push_view(e, K + 4 * q, R + 9 * q, t + 3 * q, base_off + offs[(size_t)q], Hs[(size_t)q], Ws[(size_t)q]);
         if (rc) return rc;
