@@ -61,30 +61,42 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # kernel's own instruction mix (the SQ_INSTS_VALU_* counters of a run on random grey masks, every (brick, view) pair
 # projected) at those costs; instructions no class counter names are priced as the cheapest class, so the ceiling is
 # a LOWER bound of the time the mix needs and `frac` = ceiling / measured a lower bound of the issue utilisation.
-VALU_COST_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.64, "SQ_INSTS_VALU_MUL_F32": 2.52, "SQ_INSTS_VALU_FMA_F32": 4.09,
-                    "SQ_INSTS_VALU_TRANS_F32": 8.34, "SQ_INSTS_VALU_CVT": 4.67, "SQ_INSTS_VALU_INT32": 2.70,
-                    "SQ_INSTS_VALU_INT64": 4.40, "other": 2.64}
-VALU_PROBE = "profiles/r05_valu_probe.txt"
+# Round 6: what a vector instruction costs, from tools/probes/valu_probe2.hip -- s_memtime around the
+# loop AND the wall clock, no assumed frequency (profiles/r06_valu_probe2.txt).  In shader cycles a v_fma_f32 issues every
+# 1.7-2.0 cycles per SIMD with four or more waves (the guide's SIMD-32 rate, MI355X_MICROARCH.md "Per-instruction cycle
+# constants") -- but with every SIMD of the chip issuing vector instructions the clock is 1.3-1.55 GHz, not 2.4, so in
+# TIME a wave-instruction costs what round 5's table said in "cycles at 2.4 GHz".  The costs below are nanoseconds per
+# wavefront instruction and SIMD at 8 waves per SIMD (wall time / instructions: nothing assumed).
+VALU_COST_NS = {"SQ_INSTS_VALU_ADD_F32": 1.098, "SQ_INSTS_VALU_MUL_F32": 1.134, "SQ_INSTS_VALU_FMA_F32": 1.317,
+                "SQ_INSTS_VALU_TRANS_F32": 3.687, "SQ_INSTS_VALU_CVT": 1.956, "SQ_INSTS_VALU_INT32": 1.32,
+                "SQ_INSTS_VALU_INT64": 1.83, "other": 1.06}
+# ... and what the SAME classes cost when they are one stream -- a projection's 32 instructions for four voxels side by
+# side, as the kernels issue them: 1.591 ns per instruction, 25 % above the sum of its classes (the classes are not
+# independent: clock and issue ports are shared)
+VALU_MIX_STREAM_NS = 1.591
+VALU_PROBE = "profiles/r06_valu_probe2.txt"
 AVG_COUNTERS = {"u8": "profiles/r05_avg_u8_grey_counters.json", "f32": "profiles/r05_avg_f32_grey_counters.json"}
 AVG_COUNTERS_NVV = 512 ** 3 * 72  # the voxel.views of the run the counters were taken on
-SIMDS, PROBE_CLOCK_HZ = 1024, 2.4e9
+SIMDS = 1024
 
 
 def valu_ceiling(form, nvv):
-    """(ceiling_ms, lane_ops_per_voxel_view, cycles_per_wave_voxel_view, mix) of the averaging kernel for `nvv`
-    voxel.views, from the committed counters of its `form` ("u8" / "f32") priced at VALU_COST_CYCLES; None without them."""
+    """(ceiling_ms, lane_ops_per_voxel_view, ns_per_wave_voxel_view, mix, mix_stream_ms) of the averaging kernel for `nvv`
+    voxel.views, from the committed counters of its `form` ("u8" / "f32") priced at VALU_COST_NS (a lower bound of the time
+    the mix needs: every class at the rate it reaches alone) and at VALU_MIX_STREAM_NS (the rate a stream of that mix
+    reaches); None without the counters."""
     try:
         d = json.load(open(os.path.join(ROOT, AVG_COUNTERS[form])))
         k = [v for n, v in d["kernels"].items() if n.startswith("average_brick_kernel")][0]
     except Exception:
         return None
-    total = k["SQ_INSTS_VALU"]
-    named = {c: k.get(c, 0.0) for c in VALU_COST_CYCLES if c != "other"}
+    total = float(k["SQ_INSTS_VALU"])
+    named = {c: k.get(c, 0.0) for c in VALU_COST_NS if c != "other"}
     mix = dict(named, other=max(0.0, total - sum(named.values())))
-    cycles = sum(mix[c] * VALU_COST_CYCLES[c] for c in mix)  # per dispatch of AVG_COUNTERS_NVV voxel.views
+    ns = sum(mix[c] * VALU_COST_NS[c] for c in mix)  # per dispatch of AVG_COUNTERS_NVV voxel.views, summed over SIMDs
     scale = nvv / AVG_COUNTERS_NVV
-    return (cycles * scale / SIMDS / PROBE_CLOCK_HZ * 1e3, total * 64.0 / AVG_COUNTERS_NVV,
-            cycles / (AVG_COUNTERS_NVV / 64.0), {c: v * 64.0 / AVG_COUNTERS_NVV for c, v in mix.items()})
+    return (ns * scale / SIMDS * 1e-6, total * 64.0 / AVG_COUNTERS_NVV, ns / (AVG_COUNTERS_NVV / 64.0),
+            {c: v * 64.0 / AVG_COUNTERS_NVV for c, v in mix.items()}, total * VALU_MIX_STREAM_NS * scale / SIMDS * 1e-6)
 
 
 # Weak scaling: N GPUs carve a near-cubic grid of ~N x 512^3 voxels (N = 8: 1024^3, BASELINE cfg 4),
@@ -544,20 +556,25 @@ def average_forms(a, nat, torch, shape, origin, vs, views, device, steps):
                "timing": "best of 3 runs of that many steps"}
         ceil = valu_ceiling("u8" if name.startswith("u8") else "f32", float(n) * V)
         if ceil is not None:
-            ceiling_ms, lane_ops, cyc, mix = ceil
+            ceiling_ms, lane_ops, ns_vv, mix, stream_ms = ceil
             roof = {"bound": "valu-issue", "ceiling_ms": ceiling_ms, "frac": ceiling_ms / ms,
-                    "lane_ops_per_voxel_view": lane_ops, "simd_cycles_per_wavefront_voxel_view": cyc,
-                    "mix_lane_ops_per_voxel_view": mix, "cost_cycles": VALU_COST_CYCLES,
+                    "mix_stream_ms": stream_ms, "frac_of_mix_stream": stream_ms / ms,
+                    "lane_ops_per_voxel_view": lane_ops, "ns_per_wavefront_voxel_view": ns_vv,
+                    "mix_lane_ops_per_voxel_view": mix, "cost_ns": VALU_COST_NS, "mix_stream_ns_per_instruction": VALU_MIX_STREAM_NS,
                     "model": "the kernel's vector instructions (SQ_INSTS_VALU_* of %s: random grey masks, every (brick, view) "
-                             "pair projected) priced at the cycles per wavefront instruction and SIMD that %s measures for "
-                             "each class (instructions no class counter names priced as the cheapest class), over %d SIMDs at "
-                             "the probe's 2.4 GHz: a lower bound of the time this mix needs"
-                             % (AVG_COUNTERS["u8" if name.startswith("u8") else "f32"], VALU_PROBE, SIMDS)}
+                             "pair projected) over %d SIMDs.  ceiling_ms: each class priced at the nanoseconds per wavefront "
+                             "instruction and SIMD it costs as a stream of its own at 8 waves per SIMD (%s: wall time, no "
+                             "assumed clock; instructions no class counter names at the cheapest class) -- a lower bound of "
+                             "the time the mix needs.  mix_stream_ms: the whole count at the rate a stream of a projection's "
+                             "own mix reaches there (1.591 ns per instruction, 25 %% above the sum of its classes: the "
+                             "classes share the clock -- 1.3-1.55 GHz with every SIMD issuing, not 2.4 -- and the issue ports)"
+                             % (AVG_COUNTERS["u8" if name.startswith("u8") else "f32"], SIMDS, VALU_PROBE)}
             if name in ("u8_binary", "f32"):
                 # flat footprints (all 0 / all 255 under a whole brick) add table[0] / table[255] without
                 # projecting: the model above counts work the kernel did not do
                 roof["equivalent_frac"] = roof.pop("frac")
                 roof["frac"] = None
+                roof.pop("frac_of_mix_stream", None)
                 roof["note"] = ("brick form skips the projection of (brick, view) pairs with a flat footprint: "
                                 "an equivalent rate, not issue utilisation")
             ent["roofline"] = roof
