@@ -83,13 +83,13 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
         if (e->sparse_buf[q]) (void)hipFree(e->sparse_buf[q]);
         e->sparse_buf[q] = nullptr;
         e->sparse_bytes[q] = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sparse_buf[q]), need));
+        HIP_TRY(sc_dev_malloc(reinterpret_cast<void **>(&e->sparse_buf[q]), need));
         e->sparse_bytes[q] = need;
         // what the pack kernel does not write (the padding of the codes, slots nobody took) travels too: never garbage
         HIP_TRY(hipMemsetAsync(e->sparse_buf[q], 0, need, e->stream));
     }
     if (!e->sparse_cnt) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sparse_cnt), 2 * sizeof(SparseCounters)));
+        HIP_TRY(sc_dev_malloc(reinterpret_cast<void **>(&e->sparse_cnt), 2 * sizeof(SparseCounters)));
         HIP_TRY(hipMemsetAsync(e->sparse_cnt, 0, 2 * sizeof(SparseCounters), e->stream));
     }
     char *wire = e->sparse_buf[q];
@@ -136,7 +136,7 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
     } else {
         // the labels' history is not one fused batch: bricks an earlier launch found empty are all -1 until the next
         // clear (the dead bytes), every other brick is read
-        if (!e->sparse_work) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sparse_work), (size_t)nbricks * 4));
+        if (!e->sparse_work) HIP_TRY(sc_dev_malloc(reinterpret_cast<void **>(&e->sparse_work), (size_t)nbricks * 4));
         const bool dead = e->dead != nullptr && e->dead_clean;
         SparseScan sc{dead ? e->dead : nullptr, nbricks, dead ? 1 : 0, code_full, code_untouched, e->sparse_work};
         SparseLists none{};
@@ -196,7 +196,7 @@ int sc_sparse_headers(int device, void *hip_stream, void *done_event, const void
     if (device < 0 || device >= 64) return fail(SC_ERR_INVALID, "device %d", device);
     std::lock_guard<std::mutex> lock(mu);
     if (!pin[device]) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pin[device]), 4096 * sizeof(SparseHeader), hipHostMallocDefault));
+        HIP_TRY(sc_pin_malloc(reinterpret_cast<void **>(&pin[device]), 4096 * sizeof(SparseHeader), hipHostMallocDefault));
         HIP_TRY(hipStreamCreateWithFlags(&copy_stream[device], hipStreamNonBlocking));
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);

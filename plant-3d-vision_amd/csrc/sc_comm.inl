@@ -106,7 +106,7 @@ int sc_comm_create(sc_comm **out, const void *id, int nranks, int rank, int devi
     }
     hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
-    if (he == hipSuccess) he = (hipMalloc)(reinterpret_cast<void **>(&c->scratch), (size_t)(nranks + 1) * 16);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&c->scratch), (size_t)(nranks + 1) * 16);
     if (he == hipSuccess) he = hipMemset(c->scratch, 0, (size_t)(nranks + 1) * 16);
     if (he != hipSuccess) {
         if (c->scratch) (void)hipFree(c->scratch);
@@ -219,7 +219,7 @@ int sc_all_gather_sparse(sc_engine *e, sc_comm *c, int64_t cap, void *recv_dev, 
     if (rank_stride < bytes)
         return fail(SC_ERR_INVALID, "rank stride of %lld bytes for a buffer of %lld", (long long)rank_stride, (long long)bytes);
     if (!e->sparse_hdr_pin[q])
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->sparse_hdr_pin[q]), kMaxHeaderRanks * sizeof(SparseHeader), hipHostMallocDefault));
+        HIP_TRY(sc_pin_malloc(reinterpret_cast<void **>(&e->sparse_hdr_pin[q]), kMaxHeaderRanks * sizeof(SparseHeader), hipHostMallocDefault));
     rc = gather_behind_pack(e, c, ptr, recv_dev, rank_stride, overlap, &e->sparse_busy[q], e->sparse_hdr_pin[q]);
     if (rc) return rc;
     e->sparse_busy_armed[q] = overlap != 0;

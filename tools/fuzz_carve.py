@@ -16,17 +16,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plant3dvision_amd import _native as nat, scenes
 from oracle import oracle_c
 
-KNOBS = {
+KNOBS = {  # (round 6: the sixteen settled tuning keys are retired -- accepted, no effect -- and left the draw)
     "SC_OPT_FLAG_VIEWS": [0, 1, 3, 8, 11], "SC_OPT_DENSE_VIEWS": [1, 2, 3], "SC_OPT_STAGE1_VIEWS": [1, 4, 8, 64],
-    "SC_OPT_STAGE2_VIEWS": [0, 2], "SC_OPT_VIEW_GROUP": [1, 5, 16], "SC_OPT_LIST_BLOCKS": [8, 64, 2048],
-    "SC_OPT_DEFER_STORES": [0, 8, 1024], "SC_OPT_DEFER_SHARE": [0, 5, 16], "SC_OPT_FULL_BRICKS": [0, 1],
-    "SC_OPT_BRICK": [0, 1, 1, 1], "SC_OPT_COMPACT": [0, 1, 1, 1], "SC_OPT_VIEW_ORDER": [0, 1],
-    "SC_OPT_PACK_ROWS": [0, 1, 2, 3, 3, 3, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5],
-    "SC_OPT_PACK_RIDE": [0, 1], "SC_OPT_BRICK_WALKERS": [8, 1024], "SC_OPT_FILL_BLOCKS": [0, 1, 512],
-    "SC_OPT_FINAL_VOXELS": [1, 2, 4], "SC_OPT_STAGE1_VOXELS": [1, 2, 4], "SC_OPT_VIEW_BRICK": [0, 1], "SC_OPT_STAGE1_STORE_SHARE": [0, 4, 16], "SC_OPT_STAGE1_LIST_BLOCKS": [8, 1280],
-    "SC_OPT_BULK_MIN": [0, 1, 64, 128, 256], "SC_OPT_BULK_FLOOR": [0, 1, 16, 2048, 1 << 30], "SC_OPT_ITEM_BIAS": [0, 8, 12, 64],
-    "SC_OPT_UNIT_BLOCKS": [1, 64, 512], "SC_OPT_UNIT_CULL": [0, 1, 2, 2],
-    "SC_OPT_HOST_PACK": [0, 1, 1], "SC_OPT_BULK_LIVE": [0, 0, 2, 16], "SC_OPT_SAFE_KERNELS": [0, 1, 1], "SC_OPT_DENSE_EXTRA": [0, 1, 1], "SC_OPT_SPEC_SHARE": [0, 3, 9, 16], "SC_OPT_SPEC_BLOCKS": [1, 128], "SC_OPT_LATE_ROAD": [0, 1, 1], "SC_OPT_LIST_CAP": [0, 0, 0, 2, 16, 300],
+    "SC_OPT_FULL_BRICKS": [0, 1], "SC_OPT_BRICK": [0, 1, 1, 1], "SC_OPT_COMPACT": [0, 1, 1, 1], "SC_OPT_VIEW_ORDER": [0, 1],
+    "SC_OPT_PACK_ROWS": [0, 1, 2, 3, 3, 3, 4, 8], "SC_OPT_VIEWS_PER_LAUNCH": [0, 0, 0, 1, 5], "SC_OPT_PACK_RIDE": [0, 1],
+    "SC_OPT_VIEW_BRICK": [0, 1], "SC_OPT_BULK_MIN": [0, 1, 64, 128, 256], "SC_OPT_BULK_FLOOR": [0, 1, 16, 2048, 1 << 30],
+    "SC_OPT_UNIT_CULL": [0, 1, 2, 2], "SC_OPT_HOST_PACK": [0, 1, 1], "SC_OPT_BULK_LIVE": [0, 0, 2, 16],
+    "SC_OPT_SAFE_KERNELS": [0, 1, 1], "SC_OPT_LATE_ROAD": [0, 1, 1], "SC_OPT_LIST_CAP": [0, 0, 0, 2, 16, 300],
 }
 
 def main():
