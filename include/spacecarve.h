@@ -180,6 +180,11 @@ int sc_order_before(sc_engine *e, void *consumer_stream);
  * the library's host threads during the call and cross PCIe as bits, one copy per flush (sc_hostpack_bits is that
  * bit form by itself; SC_OPT_HOST_PACK 0: the bytes travel and are packed on the device).
  * Picture sizes: 1 <= H <= 2^24 - 32, 1 <= W <= 2^24, H W <= 2^34; else SC_ERR_INVALID ("bad mask shape").
+ * Averaging masks are re-laid in strips of 128-byte tiles on the device, whose addressing is narrower:
+ * uint8 masks with a table (SC_MASK_U8_LUT: tiles of 16 x 8 pixels) need ceil(H / 8) * 128 < 2^24 (H < 1 048 576) and
+ * ceil(W / 16) * ceil(H / 8) * 128 < 2^31 bytes per view; float32 masks (SC_MASK_F32: tiles of 8 x 4 pixels) need
+ * ceil(H / 4) * 32 < 2^24 (H < 2 097 152) and ceil(W / 8) * ceil(H / 4) * 128 < 2^33 bytes per view; beyond that
+ * SC_ERR_INVALID.  sc_process_png_views takes files of at most 2^24 x 2^24 pixels and H W <= 2^31.
  */
 int sc_process_view(sc_engine *e, const float K[4], const float R[9], const float t[3],
                     const void *mask, int H, int W, int mask_dtype, int64_t row_stride_bytes);

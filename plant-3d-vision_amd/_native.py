@@ -991,8 +991,17 @@ class Engine:
                     b = min(flat.size, a + step)
                     s = state["next"] % slots
                     state["next"] += 1
-                    for f in state["busy"][s]:
-                        f.result()  # the slot's previous piece has left the ring
+                    # the slot's previous piece has left the ring -- or failed: either way the slot is free afterwards
+                    # (a `fn` that raised once must not poison the ring for every later read-back)
+                    prev, state["busy"][s] = state["busy"][s], []
+                    err = None
+                    for f in prev:
+                        try:
+                            f.result()
+                        except BaseException as ex:  # noqa: BLE001
+                            err = err or ex
+                    if err is not None:
+                        raise err
                     land = ring[s][: b - a]
                     self.dev_download(land, src + a * item)
                     state["busy"][s] = [pool.submit(fn, land[c - a:min(b, c + sub) - a], flat[c:min(b, c + sub)])
@@ -1002,6 +1011,17 @@ class Engine:
                 return futs
             for f in futs:
                 f.result()
+        except BaseException:
+            # nothing of this call may stay in flight into the caller's `out`, and no failed piece may stay on a slot
+            with state["lock"]:
+                for slot in state["busy"]:
+                    for f in slot:
+                        try:
+                            f.result()
+                        except BaseException:  # noqa: BLE001
+                            pass
+                    slot.clear()
+            raise
         finally:
             if own:
                 pool.shutdown(wait=True)
@@ -1039,6 +1059,17 @@ class Engine:
                 return futs
             for f in futs:
                 f.result()
+        except BaseException:
+            # nothing of this call may stay in flight into the caller's `out`, and no failed piece may stay on a slot
+            with state["lock"]:
+                for slot in state["busy"]:
+                    for f in slot:
+                        try:
+                            f.result()
+                        except BaseException:  # noqa: BLE001
+                            pass
+                    slot.clear()
+            raise
         finally:
             if own:
                 pool.shutdown(wait=True)

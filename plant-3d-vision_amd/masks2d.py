@@ -277,13 +277,21 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
             nlab = len(masks)
             dests = [None] * nlab
             ready = [threading.Event() for _ in range(nlab)]
+            touch_error = []
 
             def touch_in_turn():
                 # the labels' host arrays, pages touched in the order the copies need them (all at once they fight
                 # over the same page-fault path: the first label's pages are what the first copy waits for)
-                for i in range(nlab):
-                    dests[i] = nat.TouchedEmpty(vol_shape, vol_dtype, threads=nat.host_workers()).result()
-                    ready[i].set()
+                # (an allocation that fails here must reach the waiting thread, not leave it waiting)
+                try:
+                    for i in range(nlab):
+                        dests[i] = nat.TouchedEmpty(vol_shape, vol_dtype, threads=nat.host_workers()).result()
+                        ready[i].set()
+                except BaseException as ex:  # noqa: BLE001
+                    touch_error.append(ex)
+                finally:
+                    for ev in ready:
+                        ev.set()
 
             toucher = threading.Thread(target=touch_in_turn, daemon=True)
             toucher.start()
@@ -303,6 +311,8 @@ def voxels_from_masks(masks, cameras, shape, origin, voxel_size, type="averaging
                 futs = []
                 for i, (label, eng) in enumerate(zip(masks, engines)):
                     ready[i].wait()
+                    if touch_error:
+                        raise touch_error[0]
                     tm.append((f"pages{i}", time.perf_counter()))
                     if pipelined:
                         # (the ring is shared by the labels: a slot is written again only when its piece has left it)
