@@ -820,7 +820,7 @@ def assembly(a, nat, torch, dist, sb, eng, call, steps, n_total, V, host=True):
     return res
 
 
-def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, steps, comm_library=False):
+def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, steps, comm_library=False, all_ok=None):
     """BASELINE.json's metric literally: ONE 512^3 x 72 grid (cfg 3) split over the N ranks (x-planes dealt
     round-robin), carve only and carve + assembly; barrier + synchronize on both sides, MAX over ranks."""
     gshape, origin, vs, views = scenes.make_scene((a.n,) * 3, a.views, a.scene)
@@ -839,7 +839,15 @@ def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, wor
     eng.synchronize()
     dt, _ = timed(eng, nat, torch, dist, call, steps, 0, world, time_kernels="span")
     if comm_library:
-        sb.init_comm()
+        try:
+            sb.init_comm()
+            made = True
+        except Exception:  # noqa: BLE001
+            made = False
+        if not all_ok(made):  # every rank skips the leg together
+            eng.dev_free(masks_dev)
+            sb.close()
+            return {"error": "a rank could not create a second communicator: the strong leg was skipped on every rank"}
     dta = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=True, form="sparse")
     dts = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=False, form="sparse")
     out = {"workload": f"ONE {a.n}^3 x {V} grid split over {world} rank(s), x-planes cyclic ({len(sb.planes)} planes per rank)",
@@ -1287,8 +1295,40 @@ def main():
     sb.force_collective = bool(a.rccl_rehearsal)
     eng = sb.engine
     comm_library = collective and a.dist_backend == "nccl"  # RCCL bound by the library itself (sc_comm_*); gloo: torch
+    comm_error = None
+    all_ok = None
     if comm_library:
-        BARRIER = sb.init_comm().barrier
+        # The library's communicator has never met eight GPUs: if librccl cannot be opened or ncclCommInitRank fails on
+        # ANY rank, EVERY rank falls back together (a MIN over the control plane after each step) to the collectives of
+        # torch.distributed's gloo group, staged through the hosts -- slower, still correct, and the line says which
+        # transport carried the data (`assembly_transport`).
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        try:
+            nat.Comm.unique_id()  # (opens librccl on every rank; rank 0 makes the id that counts inside init_comm)
+            opened = True
+        except Exception as ex:  # noqa: BLE001
+            opened, comm_error = False, repr(ex)
+        if all_ok(opened):
+            try:
+                sb.init_comm()
+                made = True
+            except Exception as ex:  # noqa: BLE001
+                made, comm_error = False, repr(ex)
+            if all_ok(made):
+                BARRIER = sb.comm.barrier
+            else:
+                if sb.comm is not None:
+                    sb.comm.close()
+                    sb.comm = None
+                comm_library = False
+                comm_error = comm_error or "another rank could not create the communicator"
+        else:
+            comm_library = False
+            comm_error = comm_error or "another rank could not open librccl"
     n_local = eng.num_voxels()
     n_total = int(np.prod(gshape))
     stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
@@ -1369,7 +1409,7 @@ def main():
     strong = None
     if collective and a.strong_steps > 0 and a.path == "fused":
         strong = strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, world, local_rank, a.strong_steps,
-                                comm_library=comm_library)
+                                comm_library=comm_library, all_ok=all_ok if comm_library else None)
     parity = None
     if a.parity_check == "on" and a.path == "fused" and rank == 0:
         parity = parity_check(a, nat, eng, call, gshape, origin, vs, views, planes=None if world == 1 else sb.planes,
@@ -1522,7 +1562,9 @@ def main():
                                "while step k + 1 runs, everything waited for inside the timed region; the roofline object "
                                "describes the carve-only span")
             out["assembly_transport"] = ("library RCCL (sc_comm_create / sc_all_gather_sparse: no torch in the data path)"
-                                         if sb.comm is not None else "torch.distributed (%s)" % a.dist_backend)
+                                         if sb.comm is not None else "torch.distributed (%s%s)" % (
+                                             "gloo, staged through the hosts" if a.dist_backend != "torch-nccl" else "nccl",
+                                             "; the library's communicator failed: " + comm_error if comm_error else ""))
             out["assembly_bytes_sent_per_rank"] = int(sb.sparse_rank_bytes())
         if asm is not None:
             out["assembly"] = asm

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The measurement set kept under profiles/ for a round, in one go on the GPU box (gpurun, <= 20 min):
-#   bash tools/final_profiles.sh r05
+#   bash tools/final_profiles.sh r06
 # then, back in the build container:  python tools/pmc_traffic.py r05s && python tools/pmc_traffic.py r05
 # (that order: the fused entry of profiles/pmc_traffic.json must come from the fused run) and copy the files
 # listed in profiles/README.md out of gpurun_out/<tag>/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"

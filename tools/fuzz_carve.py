@@ -15,6 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plant3dvision_amd import _native as nat, scenes
 from oracle import oracle_c
+from tests.helpers import unpack_sparse_np
 
 KNOBS = {  # (round 6: the sixteen settled tuning keys are retired -- accepted, no effect -- and left the draw)
     "SC_OPT_FLAG_VIEWS": [0, 1, 3, 8, 11], "SC_OPT_DENSE_VIEWS": [1, 2, 3], "SC_OPT_STAGE1_VIEWS": [1, 4, 8, 64],
@@ -79,11 +80,22 @@ def main():
                         for Kq, Rq, tq, m in views:
                             e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
                     gots.append(e.get_values().copy())
+                    # (round 6) the brick-sparse transport form of the same labels, packed from this batch's verdict bytes
+                    # and lists (or from the dead bytes / from nothing, by the labels' history): it must decode to them
+                    if dv in (-1, 0, 1):
+                        buf = e.get_values_sparse(nat.sparse_bricks(*sh))
+                        dec = unpack_sparse_np(buf, buf.size, 1, sh)
+                        if not np.array_equal(dec, gots[-1]):
+                            sparse_bad.append((rnd, int((dec != gots[-1]).sum())))
                 counts = e.fused_counts_ex()
                 e.dev_free(ptr); e.close()
                 return gots, counts
 
+            sparse_bad = []
             gots, counts = carve_twice(opts)
+            if sparse_bad:
+                ok = False
+                print(f"SPARSE MISMATCH case {c}: shape {sh} {kind} views {nviews} dv {dv} opts {opts} device {device_masks}: {sparse_bad}")
             for rnd, got in enumerate(gots):
                 if not np.array_equal(got, want):
                     ok = False
