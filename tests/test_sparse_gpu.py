@@ -212,3 +212,36 @@ def test_sparse_form_at_the_benchmarked_size(gpu_device):
     assert buf.size < (5 << 20) and np.array_equal(nat.widen_sparse_ranks(buf, buf.size, 1, shape), want)
     eng.dev_free(ptr)
     eng.close()
+
+
+def test_sparse_form_of_a_rank_of_cfg4(gpu_device):
+    """BASELINE cfg 4: rank 3 of 8 of the 1024^3 x 72 grid (128 planes, plane-cyclic).  Its sparse buffer against its
+    labels without building anything of the grid's size on the host: the code of every brick from the labels'
+    per-brick minimum and maximum, the payload of the mixed bricks word by word."""
+    shape, origin, vs, views = scene(1024, 72, "plant")
+    eng = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, cyclic=(3, 8))
+    K, R, t = _poses(views)
+    stack = np.ascontiguousarray(np.stack([m for _, _, _, m in views]))
+    ptr = eng.dev_alloc(stack.nbytes)
+    eng.dev_upload(ptr, stack)
+    eng.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+    lab = eng.get_values()                      # [128][1024][1024] int32
+    buf = eng.get_values_sparse()
+    h = sparse_header_np(buf)
+    assert (h["planes"], h["first"], h["stride"], h["bricks_y"], h["bricks_z"]) == (128, 3, 8, 64, 16)
+    assert h["nbricks"] == 131072 and h["nmixed"] <= h["cap"]
+    bricks = lab.reshape(128, 64, 16, 16, 64).transpose(0, 1, 3, 2, 4).reshape(131072, 1024)  # (plane, by, bz) x (jl, kl)
+    lo, hi = bricks.min(axis=1), bricks.max(axis=1)
+    want_code = np.where(lo != hi, 2, np.where(lo == -1, 3, lo)).astype(np.uint8)
+    codes = buf[64:64 + 131072]
+    assert np.array_equal(codes, want_code)
+    assert h["nmixed"] == int((want_code == 2).sum()) and h["nread"] >= h["nmixed"]
+    o_ids = 64 + 131072
+    o_pay = o_ids + ((h["cap"] * 4 + 63) & ~63)
+    ids = buf[o_ids:o_ids + 4 * h["nmixed"]].view(np.uint32)
+    assert np.array_equal(np.sort(ids), np.nonzero(want_code == 2)[0])
+    words = buf[o_pay:o_pay + 256 * h["nmixed"]].view(np.uint32).reshape(-1, 64).astype(np.int64)
+    two = ((words[:, :, None] >> (np.arange(16, dtype=np.int64) * 2)[None, None, :]) & 3).reshape(-1, 1024)
+    assert np.array_equal(np.where(two == 3, -1, two), bricks[ids])
+    eng.dev_free(ptr)
+    eng.close()
