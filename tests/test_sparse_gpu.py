@@ -245,3 +245,20 @@ def test_sparse_form_of_a_rank_of_cfg4(gpu_device):
     assert np.array_equal(np.where(two == 3, -1, two), bricks[ids])
     eng.dev_free(ptr)
     eng.close()
+
+
+def test_sparse_form_without_brick_verdicts_and_on_other_engines(gpu_device):
+    """A column too long for the brick form (nz > 4096: no verdict bytes, no live list -- every brick is read), and an
+    averaging engine (no labels to pack: SC_ERR_STATE)."""
+    shape, origin, vs, views = scenes.make_scene((2, 20, 4200), 7, "plant")
+    want = oracle_c.carve(list(shape), origin, vs, views, nthreads=4)
+    eng = nat.Engine(list(shape), origin, vs, nat.SC_MODE_CARVE)
+    for K, R, t, m in views:
+        eng.process_view(K, R, t, m, nat.SC_MASK_U8)
+    h, lab = _sparse_equals_labels(eng, shape, cap=nat.sparse_bricks(*shape))
+    assert np.array_equal(lab, want) and h["bricks_z"] == 66 and h["nread"] == h["nbricks"]
+    eng.close()
+    avg = nat.Engine([8, 16, 64], [0.0, 0.0, 0.0], 1.0, nat.SC_MODE_AVERAGE)
+    with pytest.raises(nat.SpaceCarveError):
+        avg.values_sparse()
+    avg.close()
