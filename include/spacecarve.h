@@ -137,6 +137,7 @@ int sc_create_cyclic(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_
  * initialises the runtime on `device` and creates its first stream; the first engine there takes that stream.  Returns
  * at once; a failure is the first engine's to report. */
 int sc_prewarm(int device);
+void sc_prewarm_wait(void); /* returns when no such thread is running any more: call it before the process exits */
 #define SC_CREATE_DEFERRED 1
 int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride, int64_t planes,
                  const float origin[3], float voxel_size, int mode, float default_value, int device, int flags);

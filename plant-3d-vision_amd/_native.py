@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sc_create_slab": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_create_cyclic": ("i", ["p", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i"]),
     "sc_prewarm": ("i", ["i"]),
+    "sc_prewarm_wait": ("v", []),
     "sc_create_ex": ("i", ["p", "q", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i", "i"]),
     "sc_destroy": ("v", ["p"]),
     "sc_clear": ("i", ["p"]),
@@ -639,6 +640,9 @@ def png_decode_gray8(raw):
     return out
 
 
+_prewarm_registered = False
+
+
 def prewarm(device=None):
     """``sc_prewarm``: bring the HIP runtime up and make the device's first stream on a thread of the library's (what the
     reference's module-global context and queue cost at import, cl.py:29-30, without blocking the importer).  Nothing
@@ -648,7 +652,15 @@ def prewarm(device=None):
     if device is None:
         device = int(os.environ.get("SC_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0)
     try:
-        return backend().call("sc_prewarm", int(device)) == SC_OK
+        b = backend()
+        ok = b.call("sc_prewarm", int(device)) == SC_OK
+        global _prewarm_registered
+        if ok and not _prewarm_registered:
+            # the interpreter must not go down (exit handlers, the runtime's among them) while that thread is inside hipInit
+            import atexit
+            atexit.register(b.call, "sc_prewarm_wait")
+            _prewarm_registered = True
+        return ok
     except Exception:  # noqa: BLE001  (an optimisation only)
         return False
 

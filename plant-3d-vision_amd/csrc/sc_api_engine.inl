@@ -77,6 +77,18 @@ int sc_prewarm(int device) {
     return SC_OK;
 }
 
+// A process must not run its exit handlers -- the runtime's among them -- while a prewarm thread is still inside hipInit:
+// whoever started one waits for it here before the interpreter goes down (plant-3d-vision_amd/_native.py registers this
+// with atexit); returns at once when none is running.
+void sc_prewarm_wait(void) {
+    std::unique_lock<std::mutex> lk(g_stream_mu);
+    g_prewarm_cv.wait(lk, [] {
+        for (int d = 0; d < 64; ++d)
+            if (g_prewarm_running[d]) return false;
+        return true;
+    });
+}
+
 int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride, int64_t planes,
                  const float origin[3], float voxel_size, int mode, float default_value, int device, int flags) {
     if (flags & ~SC_CREATE_DEFERRED) return fail(SC_ERR_INVALID, "unknown creation flags %d", flags);

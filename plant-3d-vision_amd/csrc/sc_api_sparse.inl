@@ -129,8 +129,8 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
             sl.count2 = &e->ctl->nlate_units;
             sl.step2 = -1;
         }
-        // 16 listed bricks per wavefront and turn: 256 blocks take 16 384 bricks in one turn (a plant's 7 577)
-        const uint32_t npack = std::min<uint32_t>(256u, std::max<uint32_t>(16u, (nbricks + 63u) / 64u));
+        // 8 listed bricks per wavefront and turn, 32 per block: 512 blocks take 16 384 bricks in one turn (a plant's 7 577)
+        const uint32_t npack = std::min<uint32_t>(512u, std::max<uint32_t>(16u, (nbricks + 31u) / 32u));
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(nscan + npack), dim3(kBlock), 0, e->stream, st, g, bys, bzs, sc, nscan,
                            sl, wire, hdr, cnt, cnt_next);
     } else {
@@ -147,7 +147,7 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
         sl.count0 = &cnt->nwork;
         sl.step0 = 1;
         SparseScan noscan{nullptr, nbricks, 0, 0u, 0u, nullptr};
-        const uint32_t npack = std::min<uint32_t>(1024u, std::max<uint32_t>(16u, (nbricks + 63u) / 64u));
+        const uint32_t npack = std::min<uint32_t>(2048u, std::max<uint32_t>(16u, (nbricks + 31u) / 32u));
         hipLaunchKernelGGL(sparse_pack_kernel, dim3(npack), dim3(kBlock), 0, e->stream, st, g, bys, bzs, noscan, 0u, sl, wire,
                            hdr, cnt, cnt_next);
     }
@@ -194,16 +194,15 @@ int sc_sparse_headers(int device, void *hip_stream, void *done_event, const void
     static SparseHeader *pin[64] = {nullptr};
     static hipStream_t copy_stream[64] = {nullptr};
     if (device < 0 || device >= 64) return fail(SC_ERR_INVALID, "device %d", device);
+    // (the wait for the collective comes first and outside the lock: another thread's headers need not queue behind it)
+    if (done_event) HIP_TRY(schost::wait_event(static_cast<hipEvent_t>(done_event)));
     std::lock_guard<std::mutex> lock(mu);
     if (!pin[device]) {
         HIP_TRY(sc_pin_malloc(reinterpret_cast<void **>(&pin[device]), 4096 * sizeof(SparseHeader), hipHostMallocDefault));
         HIP_TRY(hipStreamCreateWithFlags(&copy_stream[device], hipStreamNonBlocking));
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (done_event) {
-        HIP_TRY(schost::wait_event(static_cast<hipEvent_t>(done_event)));
-        st = copy_stream[device];
-    }
+    if (done_event) st = copy_stream[device];
     // one strided copy of the W headers
     HIP_TRY(hipMemcpy2DAsync(pin[device], sizeof(SparseHeader), recv_dev, (size_t)rank_bytes, sizeof(SparseHeader), (size_t)world,
                              hipMemcpyDeviceToHost, st));

@@ -76,14 +76,14 @@ struct SparseLists {  // the bricks whose labels are read: entry i of list q at 
 };
 
 // Blocks [0, nscan): one lane per brick, the code of every brick a verdict byte settles (and, with sc.work, the list of
-// the others).  Blocks [nscan, gridDim): a block takes 64 consecutive list entries per turn, a WAVEFRONT 16 of them --
-// lane l reads the 16 labels (lane & 3) * 16 .. + 15 of column lane >> 2 of a brick, four 16-byte loads, eight bricks
+// the others).  Blocks [nscan, gridDim): a block takes 32 consecutive list entries per turn, a WAVEFRONT 8 of them --
+// lane l reads the 16 labels (lane & 3) * 16 .. + 15 of column lane >> 2 of a brick, four 16-byte loads, the eight bricks
 // in one flight, and holds word l of each brick's 64 in a register -- three ballots per brick say whether it is
 // uniform; the block's mixed bricks of the turn take their slots with ONE atomic (returning atomics on one line
 // serialise at ~11 ns: one per brick was 84 us of them on a plant) and leave with a coalesced 256-byte store each;
-// lanes 0..15 write the wavefront's 16 codes.  The block that finishes last (a counter, nobody waits) writes the
+// lanes 0..7 write the wavefront's 8 codes.  The block that finishes last (a counter, nobody waits) writes the
 // header.
-constexpr uint32_t kSparseTurn = 16;  // bricks per wavefront and turn
+constexpr uint32_t kSparseTurn = 8;  // bricks per wavefront and turn: ONE flight of loads (16 in two flights measured 3.5 us slower per batch)
 
 __global__ __launch_bounds__(kBlock) void sparse_pack_kernel(const int32_t *__restrict__ labels, GridDesc g, uint32_t bricks_y,
                                                             uint32_t bricks_z, SparseScan sc, uint32_t nscan, SparseLists sl,
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void sparse_pack_kernel(const int32_t *__re
     const uint32_t total = n0 + n1 + n2;
     const uint32_t per_plane = bricks_y * bricks_z;
     const uint32_t jl = lane >> 2, kq = (lane & 3u) * 16u;
-    constexpr uint32_t kBlockTurn = kSparseTurn * (kBlock / 64);  // 64 entries per block and turn
+    constexpr uint32_t kBlockTurn = kSparseTurn * (kBlock / 64);  // 32 entries per block and turn
     for (uint32_t tb = (blockIdx.x - nscan) * kBlockTurn; tb < total; tb += npack * kBlockTurn) {  // block-uniform
         // lane i < 16 holds entry tb + 16 wave + i: its brick (0xffffffff: none), its first column and voxel, and the
         // element offset of that corner in the state -- the divisions once per lane, not once per brick and wavefront
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void sparse_pack_kernel(const int32_t *__re
                 payload[(uint64_t)slot * 64u + lane] = w[i];
             }
         }
-        if (mine != 0xffffffffu) codes[mine] = (uint8_t)((codes2 >> (2u * lane)) & 3u);  // lanes 0..15
+        if (mine != 0xffffffffu) codes[mine] = (uint8_t)((codes2 >> (2u * lane)) & 3u);  // lanes 0..7
     }
     // No fence here: a block's slot reservations are RETURNING atomics (their values were used above), so they have been
     // performed at the device's coherence point before this barrier, and the counter below is incremented behind it --
