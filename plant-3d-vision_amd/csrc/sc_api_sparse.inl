@@ -68,7 +68,6 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
     uint64_t nb64;
     rc = sparse_geometry(e->planes, e->ny, e->nz, &bys, &bzs, &nb64);
     if (rc) return rc;
-    if ((uint64_t)e->npitch >= 0x80000000ull * 2ull) return fail(SC_ERR_INVALID, "grid too large for the sparse form");
     const uint32_t nbricks = (uint32_t)nb64;
     if (cap == 0) cap = e->sparse_cap > 0 ? e->sparse_cap : (int64_t)std::max<uint64_t>(1024, nb64 / 8);
     const uint32_t capb = sparse_round_cap((uint64_t)cap, nb64);
@@ -85,7 +84,8 @@ int values_sparse(sc_engine *e, int64_t cap, int64_t min_bytes, void **ptr, int6
         e->sparse_bytes[q] = 0;
         HIP_TRY(sc_dev_malloc(reinterpret_cast<void **>(&e->sparse_buf[q]), need));
         e->sparse_bytes[q] = need;
-        // what the pack kernel does not write (the padding of the codes, slots nobody took) travels too: never garbage
+        // what the pack kernel does not write (the padding of the codes, slots nobody took) travels too: zeroes the first
+        // time (later: whatever an earlier call with another capacity left there; a reader goes by the header)
         HIP_TRY(hipMemsetAsync(e->sparse_buf[q], 0, need, e->stream));
     }
     if (!e->sparse_cnt) {
