@@ -1024,6 +1024,7 @@ def cold_files_child(a):
     vol = bp.process_fileset(files, "colmap_camera")
     t4 = time.perf_counter()
     hist = [int((vol == -1).sum()), int((vol == 0).sum()), int((vol == 1).sum())]
+    setup_ms, waited_ms = bp._engine.setup_times()
     # the same files again through the warm engine: reads + decode + carve + read-back without any set-up
     bp.clear()
     t5 = time.perf_counter()
@@ -1032,7 +1033,9 @@ def cold_files_child(a):
     bp.close()
     out = {"import_ms": (t1 - t0) * 1e3, "file_list_ms": (t2 - t1) * 1e3, "constructor_ms": (t3 - t2) * 1e3,
            "process_fileset_ms": (t4 - t3) * 1e3, "files_to_volume_ms": (t4 - t0) * 1e3,
-           "warm_files_to_volume_ms": (t6 - t5) * 1e3, "labels_histogram": hist}
+           "warm_files_to_volume_ms": (t6 - t5) * 1e3, "labels_histogram": hist,
+           "device_setup_ms": setup_ms, "waited_for_setup_ms": waited_ms,
+           "process_fileset_minus_wait_ms": (t4 - t3) * 1e3 - waited_ms}
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
 
@@ -1251,7 +1254,10 @@ def main():
             "hip_runtime_init_ms + create_ms above -- runs on a thread of the library's from the constructor on "
             "(sc_create_ex, SC_CREATE_DEFERRED) and the files are read and decoded beside it; `all_in_constructor`: "
             "SC_ASYNC_CREATE=0, the constructor waits for all of it (rounds 1-5); warm_files_to_volume_ms: the same files "
-            "again through the engine that is up (reads + decode + carve + read-back)")
+            "again through the engine that is up (reads + decode + carve + read-back); device_setup_ms: what the engine's "
+            "device half took (runtime initialisation, the first stream, the state); waited_for_setup_ms: how long "
+            "process_fileset -- its files read and decoded by then -- waited for it; process_fileset_minus_wait_ms: what of "
+            "process_fileset was NOT hidden behind the set-up (the copy of the bits, the carve, the read-back)")
         del _views
     # ONE JSON line on stdout: RCCL prints a version banner to stdout when its communicator comes up, so
     # everything but that line (libraries included, file descriptor 1) goes to stderr from here on

@@ -142,6 +142,10 @@ void sc_prewarm_wait(void); /* returns when no such thread is running any more: 
 int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t first, int64_t stride, int64_t planes,
                  const float origin[3], float voxel_size, int mode, float default_value, int device, int flags);
 
+/* Diagnostic of a (deferred) engine's set-up: out[0] = milliseconds its device half took, out[1] = milliseconds the first
+ * call that needed the device waited for it. */
+int sc_setup_times(sc_engine *e, double out[2]);
+
 void sc_destroy(sc_engine *e);
 
 /* Backprojection.clear (cl.py:307-311): reset state to default_value, drop pending views. */

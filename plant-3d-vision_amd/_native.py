@@ -58,6 +58,7 @@ _SIGNATURES = {
     "sc_prewarm": ("i", ["i"]),
     "sc_prewarm_wait": ("v", []),
     "sc_create_ex": ("i", ["p", "q", "q", "q", "q", "q", "q", "p", "f", "i", "f", "i", "i"]),
+    "sc_setup_times": ("i", ["p", "p"]),
     "sc_destroy": ("v", ["p"]),
     "sc_clear": ("i", ["p"]),
     "sc_set_option": ("i", ["p", "i", "q"]),
@@ -855,6 +856,12 @@ class Engine:
         out = np.empty((self.num_voxels() + per - 1) // per, dtype=np.uint32)
         self._call("sc_get_values_packed", int(bits), addr(out))
         return out
+
+    def setup_times(self):
+        """(ms the device half of the set-up took, ms the first call that needed the device waited for it)."""
+        out = np.zeros(2, dtype=np.float64)
+        self._call("sc_setup_times", addr(out))
+        return float(out[0]), float(out[1])
 
     def values_sparse(self, cap=0):
         """(device pointer, bytes) of the labels in the brick-sparse form (``sc_values_sparse``); work may still run."""

@@ -96,6 +96,18 @@ int sc_create_ex(sc_engine **out, int64_t nx, int64_t ny, int64_t nz, int64_t fi
                   (flags & SC_CREATE_DEFERRED) != 0);
 }
 
+// Diagnostic: out[0] = milliseconds the device half of the engine's set-up took (on its own thread when the engine was
+// created deferred), out[1] = milliseconds the first call that needed the device waited for that thread (0: it had
+// finished, or the engine was not deferred).  Waits for the set-up.
+int sc_setup_times(sc_engine *e, double out[2]) {
+    if (!e || !out) return fail(SC_ERR_INVALID, "null argument");
+    int rc = wait_setup(e);
+    if (rc) return rc;
+    out[0] = e->setup_ms;
+    out[1] = e->setup_waited_ms;
+    return SC_OK;
+}
+
 void sc_destroy(sc_engine *e) {
     if (!e) return;
     if (e->setup_pending && e->setup_thread.joinable()) e->setup_thread.join();

@@ -24,6 +24,8 @@ struct sc_engine {
     bool setup_pending = false;
     int setup_rc = SC_OK;
     std::string setup_err;
+    double setup_ms = 0.0;         // what the device half took (on its thread, or inside sc_create*)
+    double setup_waited_ms = 0.0;  // how long the first call that needed the device waited for it (deferred engines)
 
     // deferred views
     std::vector<ViewDesc> pending;
@@ -170,7 +172,9 @@ namespace {
 // the deferred half of the set-up has finished (sc_create_ex); its failure is every later call's failure
 int wait_setup(sc_engine *e) {
     if (e->setup_pending) {
+        const auto t0 = std::chrono::steady_clock::now();
         if (e->setup_thread.joinable()) e->setup_thread.join();
+        e->setup_waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         e->setup_pending = false;
     }
     if (e->setup_rc != SC_OK) return fail(e->setup_rc, "%s", e->setup_err.c_str());

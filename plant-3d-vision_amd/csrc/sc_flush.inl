@@ -561,7 +561,14 @@ void give_stream_back(int device, hipStream_t s) {
 }
 
 // The device half of an engine's set-up: the device is there and is a gfx950, a stream, the state.
+int device_setup_body(sc_engine *e);
 int device_setup(sc_engine *e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = device_setup_body(e);
+    e->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+int device_setup_body(sc_engine *e) {
     const int device = e->device;
     // `device` is a HIP ordinal; only that device has to be a gfx950
     int ndev = 0;
