@@ -59,3 +59,20 @@ def test_bench_line_at_one_gpu_carries_parity_and_cold_process(gpu_device):
     assert out["cold_process_first_batch_ms"] == cp["first_batch_ms"] > 0
     assert abs(cp["first_batch_ms"] - (cp["create_ms"] + cp["enqueue_ms"] + cp["wait_ms"])) < 1e-6
     assert cp["allocations"] >= 3  # the label volume, the survivor lists, the control block at least
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_carries_the_assembly_over_the_library_communicator(gpu_device):
+    """`bench.py --rccl-rehearsal`: the N > 1 code path with an RCCL group of ONE on the one-GPU box -- the library's own
+    communicator (sc_comm_create), the brick-sparse form, the collective beside the next carve, the headers checked one
+    step late; gloo is the control plane only."""
+    out = _run(["--rccl-rehearsal", "--steps", "4", "--warmup", "2", "--assembly-steps", "3", "--strong-steps", "2"] + SMALL)
+    assert out["n_gpus"] == 1 and "library RCCL" in out["assembly_transport"]
+    assert out["value"] == out["value_with_assembly"] and out["value_carve_only"] >= out["value"] > 0
+    assert 0 < out["assembly_bytes_sent_per_rank"] < 128 ** 3 // 4  # less than the dense 2-bit form of the grid
+    asm = out["assembly"]
+    for leg in ("sparse_grid_serial", "sparse_grid_unpacked_int8", "packed_grid_serial", "packed_grid_overlapped", "occupancy_1bit"):
+        assert asm[leg]["value"] > 0, leg
+    assert asm["gather_to_host_sparse_ms"] > 0 and "error" not in out["strong"]
+    pc = out["parity_check"]
+    assert pc["ok"] is True and pc["oracle_whole_grid"] is True and pc["fused_equals_committed_oracle_digest"] is True
