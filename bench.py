@@ -1314,8 +1314,7 @@ def main():
             return int(flag.item()) == 1
 
         try:
-            nat.Comm.unique_id()  # (opens librccl on every rank; rank 0 makes the id that counts inside init_comm)
-            opened = True
+            opened = nat.Comm.available()  # (librccl opens on every rank; rank 0 makes the id inside init_comm)
         except Exception as ex:  # noqa: BLE001
             opened, comm_error = False, repr(ex)
         if all_ok(opened):

@@ -353,6 +353,7 @@ int sc_widen_sparse_ranks(const void *packed, int64_t rank_bytes, int world, int
  * (sc_comm_synchronize, sc_sparse_headers on the stream the collective ran on).
  */
 typedef struct sc_comm sc_comm;
+int sc_comm_available(void); /* SC_OK when librccl could be opened (nothing else is done) */
 int sc_comm_unique_id(void *id, int64_t id_bytes /* >= 128 */);
 int sc_comm_create(sc_comm **out, const void *id, int nranks, int rank, int device);
 void sc_comm_destroy(sc_comm *c);

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "sc_sparse_headers": ("i", ["i", "p", "p", "p", "q", "i", "p", "p"]),
     "sc_unpack_sparse": ("i", ["i", "p", "p", "q", "i", "q", "q", "q", "p", "i"]),
     "sc_widen_sparse_ranks": ("i", ["p", "q", "i", "q", "q", "q", "p"]),
+    "sc_comm_available": ("i", []),
     "sc_comm_unique_id": ("i", ["p", "q"]),
     "sc_comm_create": ("i", ["p", "p", "i", "i", "i"]),
     "sc_comm_destroy": ("v", ["p"]),
@@ -504,6 +505,12 @@ class Comm:
     on every rank (collective)."""
 
     ID_BYTES = 128
+
+    @staticmethod
+    def available():
+        """librccl can be opened (nothing else is done; raises with the loader's message otherwise)."""
+        check(backend().call("sc_comm_available"), "sc_comm_available")
+        return True
 
     @staticmethod
     def unique_id():

@@ -76,6 +76,8 @@ struct sc_comm {
 
 extern "C" {
 
+int sc_comm_available(void) { return rccl_ready(); }  // SC_OK when librccl could be opened (no device call)
+
 int sc_comm_unique_id(void *id, int64_t id_bytes) {
     if (!id || id_bytes < (int64_t)sizeof(NcclId)) return fail(SC_ERR_INVALID, "the id buffer holds %d bytes", (int)sizeof(NcclId));
     int rc = rccl_ready();
