@@ -106,6 +106,7 @@ GRIDS_512 = {1: (512, 512, 512), 2: (640, 640, 640), 4: (808, 800, 832), 8: (102
 
 
 COLLECTIVE = False
+COMM_STUCK = False  # a thread of this process never came back from sc_comm_create (the ranks fell back together)
 BARRIER = None  # the library communicator's barrier once it exists (sc_comm_barrier), else torch.distributed's
 
 
@@ -161,6 +162,9 @@ def parse():
                          "torch's NCCL process group for everything (rounds 2-5); gloo + --share-device rehearses the N>1 "
                          "path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use device 0 (rehearsal)")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="seconds sc_comm_create (ncclCommInitRank) may take on a rank before ALL ranks fall back to the "
+                         "staged gloo collectives")
     ap.add_argument("--rccl-rehearsal", action="store_true",
                     help="one rank, but with an RCCL process group of one: barriers, the timing all-reduce and the "
                          "assembly collectives run as they do at N > 1 (reported under 'assembly')")
@@ -1269,7 +1273,7 @@ def main():
     if a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    global COLLECTIVE, BARRIER
+    global COLLECTIVE, BARRIER, COMM_STUCK
     collective = COLLECTIVE = world > 1 or a.rccl_rehearsal
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1318,17 +1322,38 @@ def main():
         except Exception as ex:  # noqa: BLE001
             opened, comm_error = False, repr(ex)
         if all_ok(opened):
-            try:
-                sb.init_comm()
-                made = True
-            except Exception as ex:  # noqa: BLE001
-                made, comm_error = False, repr(ex)
+            # ncclCommInitRank blocks inside the library: it runs on a thread of its own so that a bootstrap that never
+            # completes (a rank that cannot reach its peers) becomes a fallback of ALL ranks after --comm-timeout seconds,
+            # not a job that hangs until the launcher's limit.  A thread stuck in there is left behind (daemon) and the
+            # process leaves through os._exit at the end.
+            import threading
+            box = {}
+
+            def make():
+                try:
+                    sb.init_comm()
+                    box["made"] = True
+                except Exception as ex:  # noqa: BLE001
+                    box["error"] = repr(ex)
+                if box.get("abandoned"):  # came back after the ranks had fallen back: nobody may find it
+                    box["late"], sb.comm = sb.comm, None
+
+            th = threading.Thread(target=make, daemon=True, name="sc-comm-init")
+            th.start()
+            th.join(a.comm_timeout)
+            if th.is_alive():
+                box["abandoned"] = True
+                made, comm_error, COMM_STUCK = False, f"sc_comm_create did not return within {a.comm_timeout:.0f} s", True
+            else:
+                made, comm_error = bool(box.get("made")), box.get("error")
             if all_ok(made):
                 BARRIER = sb.comm.barrier
             else:
-                if sb.comm is not None:
+                if not all_ok(not COMM_STUCK):
+                    COMM_STUCK = True  # some rank is still inside: a destroy on the others would wait for it
+                if sb.comm is not None and not COMM_STUCK:
                     sb.comm.close()
-                    sb.comm = None
+                sb.comm = None
                 comm_library = False
                 comm_error = comm_error or "another rank could not create the communicator"
         else:
@@ -1602,7 +1627,13 @@ def main():
         dist.destroy_process_group()
     if parity is not None and not parity["ok"]:
         sys.stderr.write("bench.py: PARITY CHECK FAILED: %s\n" % json.dumps(parity))
+        sys.stderr.flush()
+        if COMM_STUCK:
+            os._exit(3)
         sys.exit(3)
+    if COMM_STUCK:  # the stuck thread holds library locks an ordinary interpreter shutdown would wait for
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

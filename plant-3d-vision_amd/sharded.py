@@ -326,8 +326,15 @@ class ShardedBackprojection:
             except ImportError:
                 dist = None
             if dist is not None:
-                box = [nat.Comm.unique_id() if self.rank == 0 else None]
+                box = [None]
+                if self.rank == 0:
+                    try:
+                        box = [nat.Comm.unique_id()]
+                    except Exception as ex:  # noqa: BLE001 -- the others are waiting in the broadcast: tell them
+                        box = [ex]
                 dist.broadcast_object_list(box, src=0)
+                if isinstance(box[0], Exception):
+                    raise RuntimeError(f"rank 0 could not make the RCCL id: {box[0]!r}")
                 unique_id = box[0]
             else:
                 unique_id = exchange_unique_id(self.rank, self.world_size)
@@ -468,8 +475,11 @@ class ShardedBackprojection:
                 send = torch.zeros(rank_bytes, dtype=torch.uint8, device=local.device)
                 send[: min(local.numel(), rank_bytes)] = local[:rank_bytes]
             if dist.get_backend() == "gloo" and recv.is_cuda:  # rehearsal on one box: through the host
-                hrecv = torch.empty(recv.shape, dtype=recv.dtype)
-                dist.all_gather_into_tensor(hrecv, send.cpu())
+                if W == 1:  # (gloo takes 50 ms to gather a group of one: a poll that waits for nobody)
+                    hrecv = send.cpu()
+                else:
+                    hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+                    dist.all_gather_into_tensor(hrecv, send.cpu())
                 recv.copy_(hrecv)
             else:
                 dist.all_gather_into_tensor(recv, send)
@@ -577,8 +587,11 @@ class ShardedBackprojection:
                 recv = torch.empty(stride * W, dtype=torch.uint8, device=local.device)
             recv = recv[: stride * W]
             if dist.get_backend() == "gloo" and recv.is_cuda:  # rehearsal on one box: through the host
-                hrecv = torch.empty(recv.shape, dtype=recv.dtype)
-                dist.all_gather_into_tensor(hrecv, send.cpu())
+                if W == 1:  # (gloo takes 50 ms to gather a group of one: a poll that waits for nobody)
+                    hrecv = send.cpu()
+                else:
+                    hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+                    dist.all_gather_into_tensor(hrecv, send.cpu())
                 recv.copy_(hrecv)
             else:
                 dist.all_gather_into_tensor(recv, send)

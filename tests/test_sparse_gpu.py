@@ -307,3 +307,50 @@ def test_a_carve_rank_assembles_without_torch_and_the_id_travels_over_tcp(gpu_de
     assert all(p.returncode == 0 for p in procs), [o[1].decode(errors="replace")[-800:] for o in outs]
     ids = [o[0].decode().strip().splitlines()[-1] for o in outs]
     assert len(ids[0]) == 256 and ids[0] == ids[1] and set(ids[0]) != {"0"}
+
+
+@pytest.mark.parametrize("world,partition", [(2, "cyclic"), (3, "cyclic"), (8, "cyclic"), (3, "slab"), (8, "slab")])
+def test_several_ranks_buffers_unpack_into_one_grid_on_the_device(gpu_device, world, partition):
+    """What an N > 1 assembly does behind its collective, with the transport taken out: every rank of a `world`-rank
+    partition (engines side by side on the one GPU; nx is no multiple of world, so the ranks differ by a plane) packs
+    its planes, the buffers land rank-major `rank_bytes` apart as an all-gather leaves them, and sc_sparse_headers /
+    sc_unpack_sparse / sc_widen_sparse_ranks turn them into ONE grid in global order == the oracle's."""
+    shape, origin, vs, views = scene((21, 40, 130), 9, "plant")
+    want = oracle_c.carve(shape, origin, vs, views, nthreads=4)
+    ranks = [ShardedBackprojection(shape, origin, vs, rank=r, world_size=world, device=0, partition=partition)
+             for r in range(world)]
+    cap = 64
+    stride = ranks[0].sparse_rank_bytes(cap)
+    assert all(sb.sparse_rank_bytes(cap) == stride for sb in ranks)  # the rank with the most planes sets it for all
+    wire = np.zeros(stride * world, dtype=np.uint8)
+    mixed, caps = [], []
+    for r, sb in enumerate(ranks):
+        for K, R, t, m in views:
+            sb.process_view(K, R, t, m)
+        buf = sb.engine.get_values_sparse(cap)
+        assert buf.size <= stride
+        wire[r * stride:r * stride + buf.size] = buf
+        h = sparse_header_np(buf)
+        assert h["planes"] == len(sb.planes) and h["first"] == sb.planes[0]
+        assert h["stride"] == (world if partition == "cyclic" else 1)
+        mixed.append(h["nmixed"])
+        caps.append((min(cap, h["nbricks"]) + 15) & ~15)  # a rank never carries more slots than it has bricks
+    eng = ranks[0].engine
+    recv = eng.dev_alloc(wire.nbytes)
+    eng.dev_upload(recv, wire)
+    nm, cp = nat.sparse_headers(0, eng.stream(), recv, stride, world)
+    assert list(nm) == mixed and list(cp) == caps
+    n = int(np.prod(shape))
+    for kind, dt, ref in ((4, np.int32, want), (1, np.int8, want.astype(np.int8)), (0, np.uint8, (want == 1).astype(np.uint8))):
+        out = eng.dev_alloc(n * np.dtype(dt).itemsize)
+        nat.unpack_sparse(0, eng.stream(), recv, stride, world, shape, out, kind)
+        eng.synchronize()
+        got = np.empty(n, dtype=dt)
+        eng.dev_download(got, out)
+        assert np.array_equal(got.reshape(shape), ref), (kind, world, partition)
+        eng.dev_free(out)
+    assert np.array_equal(nat.widen_sparse_ranks(wire, stride, world, shape), want)
+    assert np.array_equal(unpack_sparse_np(wire, stride, world, shape), want)
+    eng.dev_free(recv)
+    for sb in ranks:
+        sb.close()
