@@ -26,6 +26,63 @@ KNOBS = {  # (round 6: the sixteen settled tuning keys are retired -- accepted, 
     "SC_OPT_SAFE_KERNELS": [0, 1, 1], "SC_OPT_LATE_ROAD": [0, 1, 1], "SC_OPT_LIST_CAP": [0, 0, 0, 2, 16, 300],
 }
 
+ranked = 0
+
+
+def ranks_assembly(sh, origin, vs, views, dv, opts, device_masks, world, part, cap, want, stack, K, R, t):
+    """The labels of `world` rank engines through the brick-sparse wire into one grid; returns what differs (or None)."""
+    from plant3dvision_amd.sharded import rank_planes, slab_bounds
+    from tests.helpers import sparse_header_np
+    planes = [rank_planes(sh[0], world, r, part) for r in range(world)]
+    nbmax = nat.sparse_bricks(max(len(p) for p in planes), sh[1], sh[2])
+    engines = []
+    for r in range(world):
+        kw = {"cyclic": (r, world)} if part == "cyclic" else {"slab": slab_bounds(sh[0], world, r)}
+        e = nat.Engine(sh, origin, vs, nat.SC_MODE_CARVE, default_value=dv, **kw)
+        for k, v in opts.items():
+            e.set_option(getattr(nat, k), v)
+        if device_masks:
+            ptr = e.dev_alloc(stack.nbytes); e.dev_upload(ptr, stack)
+            e.process_views_device(K, R, t, ptr, *stack.shape, nat.SC_MASK_U8)
+            e.synchronize(); e.dev_free(ptr)
+        else:
+            for Kq, Rq, tq, m in views:
+                e.process_view(Kq, Rq, tq, m, nat.SC_MASK_U8)
+        engines.append(e)
+    out = {}
+    for attempt in range(2):
+        stride = nat.sparse_rank_bytes(nbmax, cap)
+        wire = np.zeros(stride * world, dtype=np.uint8)
+        over = False
+        for r, e in enumerate(engines):
+            buf = e.get_values_sparse(cap)
+            h = sparse_header_np(buf)
+            over |= h["nmixed"] > h["cap"]
+            if buf.size > stride:
+                out["stride"] = (r, int(buf.size), int(stride))
+            wire[r * stride:r * stride + min(buf.size, stride)] = buf[:stride]
+        if not over:
+            break
+        cap = nbmax  # a rank ran out of slots: every rank again with room for every brick (what ShardedBackprojection does)
+    e0 = engines[0]
+    recv = e0.dev_alloc(wire.nbytes); e0.dev_upload(recv, wire)
+    n = int(np.prod(sh))
+    dst = e0.dev_alloc(n * 4)
+    nat.unpack_sparse(0, e0.stream(), recv, stride, world, sh, dst, 4)
+    e0.synchronize()
+    got = np.empty(n, dtype=np.int32)
+    e0.dev_download(got, dst)
+    e0.dev_free(dst); e0.dev_free(recv)
+    if not np.array_equal(got.reshape(sh), want):
+        out["device_unpack"] = int((got.reshape(sh) != want).sum())
+    host = nat.widen_sparse_ranks(wire, stride, world, sh)
+    if not np.array_equal(host, want):
+        out["host_widen"] = int((host != want).sum())
+    for e in engines:
+        e.close()
+    return out or None
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
@@ -33,6 +90,7 @@ def main():
     only = {int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x.strip()}
     bad = 0
     certified_views = uncertified_views = averaged = 0
+    global ranked
     for c in range(cases):
         shape = (int(rng.integers(2, 24)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
         kind = str(rng.choice(["plant", "noise", "solid", "empty", "dense"]))
@@ -60,6 +118,11 @@ def main():
         opts = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.5}
         run_it = not only or c in only
         device_masks = rng.random() < 0.5
+        # (round 6) the same carve as the ranks of an N > 1 run hold it: W engines on plane sets of the grid, their sparse
+        # buffers laid rank-major as an all-gather leaves them, unpacked on the device and on the host into ONE grid
+        ranks_w = int(rng.integers(2, 9)) if rng.random() < 0.3 else 0
+        ranks_part = str(rng.choice(["cyclic", "slab"]))
+        ranks_cap = int(rng.choice([16, 64, 4096, 1 << 20]))
         ok = True
         if run_it:
             print(f"case {c}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts}", flush=True)
@@ -101,6 +164,13 @@ def main():
                     ok = False
                     print(f"MISMATCH case {c} round {rnd}: shape {sh} {kind} views {nviews} dv {dv} kw {kw} opts {opts} "
                           f"device {device_masks}: {int((got != want).sum())} voxels differ")
+            if ranks_w and dv in (-1, 0, 1) and sh[0] >= ranks_w:
+                nbad = ranks_assembly(sh, origin, vs, views, dv, opts, device_masks, ranks_w, ranks_part, ranks_cap, want, stack, K, R, t)
+                ranked += 1
+                if nbad:
+                    ok = False
+                    print(f"RANKS MISMATCH case {c}: shape {sh} {kind} views {nviews} dv {dv} opts {opts} device {device_masks} "
+                          f"world {ranks_w} {ranks_part} cap {ranks_cap}: {nbad}")
             if only and not ok:  # where, what, and which knobs it takes
                 got = gots[0]
                 badv = np.argwhere(got != want)
@@ -154,11 +224,13 @@ def main():
             ea.close()
             averaged += 1
         bad += 0 if ok else 1
+    print(f"{ranked} cases also as the ranks of an N > 1 run through the sparse wire")
     print(f"{cases} cases ({averaged} with the average kernel too), {bad} with mismatches; {certified_views} certified views, {uncertified_views} not")
     if len(sys.argv) > 3:
         import json
         json.dump({"tool": "tools/fuzz_carve.py", "cases": cases, "seed": int(sys.argv[2]), "cases_with_mismatches": bad,
                    "cases_with_the_average_kernel_too": averaged,
+                   "cases_also_as_ranks_through_the_sparse_wire": ranked,
                    "views_on_the_certified_projection_path": certified_views, "views_on_the_general_path": uncertified_views,
                    "knobs": sorted(KNOBS), "scenes": ["plant", "noise", "solid", "empty", "dense"],
                    "checked": "HIP carve (host masks or device batch, fresh volume and a second batch on the stored one) "
