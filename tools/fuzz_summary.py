@@ -10,6 +10,9 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", ROUND, "fuzz_*.log"))
     mism = len(re.findall(r"MISMATCH", txt))
     m = re.search(r"(\d+) cases \((\d+) with the average kernel too\), (\d+) with mismatches; (\d+) certified views, (\d+) not", txt)
     ent = {"log": os.path.basename(f), "cases_started": cases, "mismatch_lines": mism, "gpu_fault": "Memory access fault" in txt}
+    mr = re.search(r"(\d+) cases also as the ranks of an N > 1 run", txt)
+    if mr:
+        ent["cases_also_as_ranks_through_the_sparse_wire"] = int(mr.group(1))
     if m:
         ent.update(cases_completed=int(m.group(1)), with_average=int(m.group(2)), cases_with_mismatches=int(m.group(3)),
                    certified_views=int(m.group(4)), uncertified_views=int(m.group(5)))
