@@ -76,3 +76,15 @@ def test_bench_rehearsal_carries_the_assembly_over_the_library_communicator(gpu_
     assert asm["gather_to_host_sparse_ms"] > 0 and "error" not in out["strong"]
     pc = out["parity_check"]
     assert pc["ok"] is True and pc["oracle_whole_grid"] is True and pc["fused_equals_committed_oracle_digest"] is True
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_together_when_the_communicator_never_comes_up(gpu_device):
+    """`--comm-timeout 0`: sc_comm_create (on its own thread) is not back in time, so the ranks agree on the staged
+    gloo collectives, the line says so, the labels are the oracle's and the process ends with code 0 although a thread
+    of it may still be inside the library."""
+    out = _run(["--rccl-rehearsal", "--comm-timeout", "0", "--steps", "3", "--warmup", "1", "--assembly-steps", "2",
+                "--strong-steps", "2"] + SMALL)
+    assert "gloo" in out["assembly_transport"] and "did not return within 0 s" in out["assembly_transport"]
+    assert out["value"] == out["value_with_assembly"] and out["value_carve_only"] >= out["value"] > 0
+    assert out["parity_check"]["ok"] is True
