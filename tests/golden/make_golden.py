@@ -122,7 +122,7 @@ def main():
 
 def big_digests(nthreads=None):
     """BASELINE cfg 3 (512^3 x 72: the benchmarked scene and the bench's other three) and cfg 4 (1024^3 x 72, the
-    planes of ranks 0, 3 and 7 of 8, both partitions): SHA-256 + histogram of the ORACLE's int32 labels over the
+    planes of every rank of 8, both partitions: rank_digests): SHA-256 + histogram of the ORACLE's int32 labels over the
     whole grid / the rank's planes.  `python tests/golden/make_golden.py big` (about ten minutes on 8 cores; the
     sizes at which tests and bench.py's parity_check compare the HIP path with these)."""
     from plant3dvision_amd.sharded import rank_planes
@@ -135,20 +135,54 @@ def big_digests(nthreads=None):
         digests[f"{kind}_512_72"] = {"sha256_int32": sha256(lab), "hist_m1_0_p1": histogram3(lab)}
         print(kind, 512, 72, digests[f"{kind}_512_72"], flush=True)
         del lab
+    json.dump(digests, open(path, "w"), indent=1, sort_keys=True)
+    rank_digests(nthreads)
+
+
+def rank_digests(nthreads=None, only_missing=False):
+    """BASELINE cfg 4: EVERY rank of 8 of the 1024^3 x 72 grid, both partitions (16 x 128 planes), and the histogram of
+    the whole grid as the sum of a partition's ranks (the two partitions must agree: a checksum of checksums).
+    `python tests/golden/make_golden.py ranks` computes only the keys that are not there yet."""
+    from plant3dvision_amd.sharded import rank_planes
+    nthreads = nthreads or min(32, os.cpu_count() or 8)
+    path = os.path.join(OUT, "synthetic_digests.json")
+    digests = json.load(open(path))
     shape, origin, vs, views = scenes.make_scene(1024, 72, "plant")
     for partition in ("cyclic", "slab"):
-        for rank in (0, 3, 7):
+        for rank in range(8):
+            key = f"plant_1024_72_{partition}_rank{rank}of8"
+            if only_missing and key in digests:
+                continue
             pl = rank_planes(shape[0], 8, rank, partition)
             lab = oracle_c.carve_planes(shape, origin, vs, views, pl.start, pl.step, len(pl), nthreads=nthreads)
-            key = f"plant_1024_72_{partition}_rank{rank}of8"
             digests[key] = {"sha256_int32": sha256(lab), "hist_m1_0_p1": histogram3(lab)}
             print(key, digests[key], flush=True)
             del lab
+    # the weak-scaling grids of bench.py at 2 and 4 GPUs (bench.py GRIDS_512): what rank 0 compares its digest with
+    for world, gshape in ((2, (640, 640, 640)), (4, (808, 800, 832))):
+        key = f"plant_{gshape[0]}_72_cyclic_rank0of{world}"
+        if only_missing and key in digests:
+            continue
+        sh, og, vz, vw = scenes.make_scene(gshape, 72, "plant")
+        pl = rank_planes(sh[0], world, 0, "cyclic")
+        lab = oracle_c.carve_planes(sh, og, vz, vw, pl.start, pl.step, len(pl), nthreads=nthreads)
+        digests[key] = {"sha256_int32": sha256(lab), "hist_m1_0_p1": histogram3(lab), "global_grid": list(gshape)}
+        print(key, digests[key], flush=True)
+        del lab
+    sums = {}
+    for partition in ("cyclic", "slab"):
+        hs = [digests[f"plant_1024_72_{partition}_rank{r}of8"]["hist_m1_0_p1"] for r in range(8)]
+        sums[partition] = [int(sum(h[q] for h in hs)) for q in range(3)]
+    assert sums["cyclic"] == sums["slab"] and sum(sums["cyclic"]) == 1024 ** 3, sums
+    digests["plant_1024_72_whole_grid"] = {"hist_m1_0_p1": sums["cyclic"]}
+    print("plant_1024_72_whole_grid", sums["cyclic"], flush=True)
     json.dump(digests, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         big_digests()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ranks":
+        rank_digests(only_missing=True)
     else:
         main()

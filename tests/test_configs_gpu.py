@@ -137,6 +137,30 @@ def test_cfg4_1024_cubed_ranks_of_8(gpu_device, partition):
     assert alive > 0  # the object is in there (cyclic: in every rank; slab: in rank 3)
 
 
+@pytest.mark.parametrize("partition", ["cyclic", "slab"])
+def test_cfg4_every_rank_of_8_equals_the_oracles_digest(gpu_device, partition):
+    """BASELINE cfg 4, the WHOLE 1024^3 x 72 grid: the fused labels of each of the 8 ranks against the oracle's committed
+    SHA-256 and histogram over the same planes (tests/golden/make_golden.py ranks; ranks 0, 3 and 7 are compared
+    element by element above), and the ranks' histograms add up to the whole grid's."""
+    shape, origin, vs, views = scene(1024, 72, "plant")
+    K, R, t = _poses(views)
+    total = [0, 0, 0]
+    for rank in range(8):
+        planes = rank_planes(shape[0], 8, rank, partition)
+        kw = {"cyclic": (rank, 8)} if partition == "cyclic" else {"slab": (planes.start, planes.stop)}
+        eng = nat.Engine(shape, origin, vs, nat.SC_MODE_CARVE, **kw)
+        ptr, dims = _device_masks(eng, views)
+        fused = _run(eng, K, R, t, ptr, dims, 0)
+        gold = GOLD[f"plant_1024_72_{partition}_rank{rank}of8"]
+        h = histogram3(fused)
+        assert h == gold["hist_m1_0_p1"], (partition, rank, h)
+        assert sha256(fused) == gold["sha256_int32"], (partition, rank)
+        total = [a + b for a, b in zip(total, h)]
+        eng.dev_free(ptr)
+        eng.close()
+    assert total == GOLD["plant_1024_72_whole_grid"]["hist_m1_0_p1"] and sum(total) == 1024 ** 3
+
+
 # -- the bench's other scenes at cfg 3's size ---------------------------------------------------------
 @pytest.mark.parametrize("kind", ["dense", "solid", "noise"])
 def test_cfg3_other_scenes_whole_grid_vs_oracle(gpu_device, kind):

@@ -266,3 +266,19 @@ def test_oracle_over_a_ranks_planes_equals_the_whole_grid_oracle(first, stride, 
     assert np.array_equal(got, full[first:first + (count - 1) * stride + 1:stride])
     with pytest.raises(RuntimeError):
         oracle_c.carve_planes(shape, origin, vs, views, first, stride, count + 40)
+
+
+def test_committed_rank_digests_of_cfg4_cover_the_whole_grid():
+    """tests/golden/synthetic_digests.json holds the oracle's digest of EVERY rank of 8 of the 1024^3 x 72 grid in both
+    partitions; the ranks' histograms add up to the same whole grid either way (a checksum of checksums: no plane is
+    missing or counted twice), and the empty end slabs are the all -1 volume."""
+    dig = json.load(open(os.path.join(GOLDEN, "synthetic_digests.json")))
+    whole = dig["plant_1024_72_whole_grid"]["hist_m1_0_p1"]
+    assert sum(whole) == 1024 ** 3 and whole[1] == 0 and whole[2] > 0
+    for partition in ("cyclic", "slab"):
+        hs = [dig[f"plant_1024_72_{partition}_rank{r}of8"]["hist_m1_0_p1"] for r in range(8)]
+        assert all(sum(h) == 128 * 1024 * 1024 for h in hs)
+        assert [sum(h[q] for h in hs) for q in range(3)] == whole
+    shas = {dig[f"plant_1024_72_slab_rank{r}of8"]["sha256_int32"] for r in (0, 1, 6, 7)}
+    assert len(shas) == 1  # four slabs the object does not reach
+    assert len({dig[f"plant_1024_72_cyclic_rank{r}of8"]["sha256_int32"] for r in range(8)}) == 8
