@@ -551,8 +551,10 @@ struct UnitJob {
 struct SecondWord {
     unsigned long long empty, full, need;
 };
+// (first: the lane's own view's descriptor, view `lane` of the batch -- the same for every unit a wavefront asks about,
+// so the caller loads it once; the special kernel has the registers: 94 of the 128 that four wavefronts per SIMD allow)
 __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc &g, ListCtl *ctl, uint32_t unit,
-                                              uint32_t sub, uint32_t lane, const SecondWord &second) {
+                                              uint32_t sub, uint32_t lane, const SecondWord &second, const ViewDesc &first) {
     const uint32_t lb = unit >> 2, w = unit & 3u;
     const uint32_t per_plane = uj.bricks_y * uj.bricks_z;
     const uint32_t il = lb / per_plane;
@@ -573,10 +575,8 @@ __device__ __forceinline__ void unit_verdicts(const UnitJob &uj, const GridDesc 
     {
         const int vi = (int)lane;  // the first 64 views, one per lane
         uint32_t v = 8u;  // no such view, or one the dense stage has applied
-        if (vi < uj.nall && vi >= uj.ndense) {
-            const ViewDesc d = uj.views[vi];  // one descriptor per lane
-            v = d.cmask != nullptr ? rect_verdict_cells(d, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
-        }
+        if (vi < uj.nall && vi >= uj.ndense)
+            v = first.cmask != nullptr ? rect_verdict_cells(first, g, x, j0, j0 + kBrickY - 1, kb, kb + 15) : 0u;
         empty |= __ballot(v == 1u) != 0;
         seen |= __ballot(v == 2u) != 0;
         need[0] = __ballot(v == 0u);
@@ -745,6 +745,9 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
             const uint32_t rounds = (total + nworkers * gmax - 1u) / (nworkers * gmax);
             const uint32_t G = min(gmax, max(1u, (total + nworkers * rounds - 1u) / (nworkers * rounds)));
             const uint32_t nbricks_all = sj.lb.nbricks;
+            ViewDesc first;  // one descriptor per lane, once per wavefront (it was loaded per unit until round 6: a memory
+            first.cmask = nullptr;  // round trip in front of every unit's verdict chain)
+            if ((int)lane < sj.uj.nall && (int)lane >= sj.uj.ndense) first = sj.uj.views[lane];
             for (uint32_t i0 = (blockIdx.x * kFlagWaves + wave) * G; i0 < total; i0 += nworkers * G) {
                 const uint32_t slot = per1 ? lane / per1 : 0u;
                 const uint32_t i = i0 + min(slot, G - 1u);
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(64 * kFlagWaves) void carve_special_kernel(int32_t 
                     const uint32_t sub = __builtin_amdgcn_readlane(lo, src);
                     const SecondWord second{(e1 >> src) & word & (per1 ? ~0ull : 0ull), (f1 >> src) & word & (per1 ? ~0ull : 0ull),
                                             (n1 >> src) & word & (per1 ? ~0ull : 0ull)};
-                    unit_verdicts(sj.uj, g, ctl, unit, sub, lane, second);
+                    unit_verdicts(sj.uj, g, ctl, unit, sub, lane, second, first);
                 }
             }
         }
