@@ -162,6 +162,10 @@ def parse():
                          "torch's NCCL process group for everything (rounds 2-5); gloo + --share-device rehearses the N>1 "
                          "path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use device 0 (rehearsal)")
+    ap.add_argument("--pipelined-steps", type=int, default=40,
+                    help="N = 1: steps of the two-engines-in-turn throughput leg (0 = skip)")
+    ap.add_argument("--twin-engine", type=int, default=1,
+                    help="N > 1 (and --rccl-rehearsal): 1 = two engines take the steps of the assembled headline in turn, 0 = one engine")
     ap.add_argument("--comm-timeout", type=float, default=120.0,
                     help="seconds sc_comm_create (ncclCommInitRank) may take on a rank before ALL ranks fall back to the "
                          "staged gloo collectives")
@@ -594,7 +598,7 @@ def _maxed(torch, dist, dt):
     return float(tt.item())
 
 
-def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, overlap=True, form="dense"):
+def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, overlap=True, form="dense", twin=None):
     """`steps` steps of carve + assembly, barrier + synchronize on both sides, MAX over ranks (seconds).  A step:
     clear, the batch of resident masks, pack the labels, all-gather (RCCL over xGMI) -- every rank ends every step
     holding the whole grid in its packed form (what proc3d.vol2pcd reads).
@@ -605,21 +609,30 @@ def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, over
     k + 1 runs, and a step that did not fit fails the leg (the capacity is settled before the timed steps).
     form "dense": `bits` per label for every voxel (rounds 3-5).
     overlap: the collective of step k runs beside the carve of step k + 1 (receive buffers alternate); the last
-    collective is waited for inside the timed region."""
+    collective is waited for inside the timed region.
+    twin (form "sparse"): a second engine on the same planes (ShardedBackprojection.twin) -- the two take the steps in
+    turn, so that the PACK of step k (on its engine's stream) is beside the carve of step k + 1 as well: the double
+    buffering of a pipeline of scans (every step is still clear + all the views + pack + collective, all waited for
+    inside the timed region)."""
     dev = torch.device("cuda", eng.device)
     eng.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
     if form == "sparse":
-        def batch():
-            eng.clear()
-            eng.process_views_device(*call, nat.SC_MASK_U8)
+        sbs = (sb,) if twin is None else (sb, twin)
 
-        batch()
-        sb.all_gather(compress="sparse", unpack=False)  # settles the capacity (every rank alike), synchronously
+        def batch(q):
+            q.engine.clear()
+            q.engine.process_views_device(*call, nat.SC_MASK_U8)
+
+        for q in sbs:
+            q.engine.set_option(nat.SC_OPT_VIEWS_PER_LAUNCH, 0)
+            batch(q)
+            q.all_gather(compress="sparse", unpack=False)  # settles the capacity (every rank alike), synchronously
         prev = [None]
 
         def step(i):
-            batch()
-            g = sb.all_gather(compress="sparse", unpack=False, overlap=overlap, check=False)
+            q = sbs[i % len(sbs)]
+            batch(q)
+            g = q.all_gather(compress="sparse", unpack=False, overlap=overlap, check=False)
             if prev[0] is not None:
                 prev[0].verify()  # the previous step's headers, while this one runs
             prev[0] = g
@@ -629,7 +642,8 @@ def assembled_steps(nat, torch, dist, sb, eng, call, steps, warmup, bits=2, over
             if prev[0] is not None:
                 prev[0].verify()
                 prev[0] = None
-            sb.synchronize()
+            for q in sbs:
+                q.synchronize()
             if sb.comm is not None:
                 sb.comm.synchronize()
     else:
@@ -1424,14 +1438,59 @@ def main():
         live, s0, s1n, ovf = eng.fused_counts()
         breakdown["fused_counts"] = {"live_bricks": live, "alive_after_dense_stage": s0,
                                      "alive_after_first_list_stage": s1n, "list_overflow": ovf}
+    # Throughput with two scans in flight (N = 1): a second engine of the same grid, the two taking the steps in turn on
+    # their own streams and label volumes -- a queue of scans, as a service would run them.  Reported BESIDE `value`
+    # (which stays one engine, one batch at a time: the quantity every round has measured).
+    pipelined = None
+    if world == 1 and not a.rccl_rehearsal and a.path == "fused" and a.pipelined_steps > 0:
+        import hashlib
+        eng2 = nat.Engine(gshape, origin, vs, nat.SC_MODE_CARVE, device=local_rank)
+        pair = (eng, eng2)
+        for q in pair:
+            run_steps(q, nat, *call, 2, 0)
+            q.synchronize()
+        psteps = int(a.pipelined_steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(psteps):
+            q = pair[i & 1]
+            q.clear()
+            q.process_views_device(*call, nat.SC_MASK_U8)
+            q.flush()
+        for q in pair:
+            q.synchronize()
+        dtq = time.perf_counter() - t0
+        same = hashlib.sha256(eng2.get_values().tobytes()).hexdigest() == hashlib.sha256(eng.get_values().tobytes()).hexdigest()
+        eng2.close()
+        pipelined = {"engines": 2, "steps": psteps, "ms_per_step": dtq / psteps * 1e3, "value": n_total * V * psteps / dtq / 1e6,
+                     "unit": "Mvoxel*views/s", "frac_of_hbm_roofline": (4.0 * n_local + float(V) * W * H) / (dtq / psteps) / 8e12,
+                     "labels_equal": bool(same),
+                     "note": "the same steps (clear + 72 resident masks + fused carve) dealt in turn to TWO engines of the same grid "
+                             "(two label volumes, two streams), host clock around all of them, everything waited for inside: the "
+                             "kernels of one batch run in the other's kernel boundaries and tails.  Throughput of a queue of "
+                             "scans; a single scan's latency is `ms_per_step`.  `value` and `roofline` above are one engine"}
     # N > 1: `value` = carve + assembly (t_device + collective), W warm-up and exactly K timed steps
     # These legs are sequences of collectives: an exception on ONE rank must not be swallowed there (its peers would
     # sit in a collective it never joins, and its next leg would pair with their pending one out of phase -- ADVICE
     # r05).  A rank that fails exits non-zero and the launcher (self_launch / torchrun) ends the job.
     asm = None
     dt_asm = None
+    twin = None
+    twin_check = None
+    dt_asm_one = None
     if collective and a.path == "fused":
-        dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, overlap=True, form="sparse")
+        # two engines take the steps in turn (ShardedBackprojection.twin: the double buffering of a pipeline of scans):
+        # the pack of step k, on its engine's stream, is beside the carve of step k + 1 like the collective
+        if a.twin_engine:
+            twin = sb.twin()
+        dt_asm = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, overlap=True, form="sparse", twin=twin)
+        if twin is not None:
+            # (outside the timed regions) the twin's labels are the first engine's, which parity_check compares with the oracle
+            import hashlib
+            twin_check = hashlib.sha256(twin.get_local().tobytes()).hexdigest() == hashlib.sha256(sb.get_local().tobytes()).hexdigest()
+            dt_asm_one = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, overlap=True, form="sparse")
+            twin.close()
+            twin = None
     if collective and a.assembly_steps > 0:
         asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
         if world == 1:
@@ -1444,6 +1503,9 @@ def main():
     if a.parity_check == "on" and a.path == "fused" and rank == 0:
         parity = parity_check(a, nat, eng, call, gshape, origin, vs, views, planes=None if world == 1 else sb.planes,
                               rank=rank, world=world)
+        if twin_check is not None:  # the second engine of the assembled headline carved the same labels
+            parity["twin_engine_labels_equal"] = bool(twin_check)
+            parity["ok"] = bool(parity["ok"] and twin_check)
     e2e = None
     if world == 1 and not a.rccl_rehearsal and a.e2e_reps > 0 and a.path == "fused":
         e2e = e2e_host(a, gshape, origin, vs, views, local_rank, a.e2e_reps)
@@ -1582,6 +1644,8 @@ def main():
                           "roofline": roof(other, statso, traffic_for(other)), "kernels": statso}
         if per_view is not None:
             out["per_view"] = per_view
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if dt_asm is not None:
             out["value_carve_only"] = value_carve
             out["ms_per_step_carve_only"] = dt / a.steps * 1e3
@@ -1590,7 +1654,14 @@ def main():
                                "bricks, from the batch's verdict bytes and live list) + all-gather into alternating receive "
                                "buffers, the collective of step k beside the carve of step k + 1, step k's headers checked "
                                "while step k + 1 runs, everything waited for inside the timed region; the roofline object "
-                               "describes the carve-only span")
+                               "describes the carve-only span"
+                               + ("; TWO engines on the rank's planes take the steps in turn (double buffering: the pack of "
+                                  "step k is beside the carve of step k + 1 too) -- `ms_per_step_one_engine` is the same loop "
+                                  "on one engine" if dt_asm_one is not None else ""))
+            if dt_asm_one is not None:
+                out["ms_per_step_one_engine"] = dt_asm_one / a.steps * 1e3
+                out["value_one_engine"] = n_total * V * a.steps / dt_asm_one / 1e6
+                out["twin_engine_labels_equal"] = bool(twin_check)
             out["assembly_transport"] = ("library RCCL (sc_comm_create / sc_all_gather_sparse: no torch in the data path)"
                                          if sb.comm is not None else "torch.distributed (%s%s)" % (
                                              "gloo, staged through the hosts" if a.dist_backend != "torch-nccl" else "nccl",

@@ -302,6 +302,23 @@ class ShardedBackprojection:
         self._sparse_recv = [None, None]
         self._sparse_turn = 0
         self._streams = None
+        self._comm_shared = False
+        self._ctor = dict(type=type, default_value=default_value, engine_factory=engine_factory,
+                          views_per_launch=views_per_launch, partition=partition, log=log, unpack_fn=unpack_fn)
+
+    def twin(self):
+        """A second engine on the SAME planes of the same rank and device, sharing this one's communicator: two
+        engines taking turns are the double buffering of a pipeline of scans -- while the labels of scan k are packed
+        and gathered (``all_gather(..., overlap=True)``), the twin carves scan k + 1 on its own stream and label volume,
+        and nobody's carve waits for a pack.  Every rank must alternate alike (the collectives pair up in call order).
+        Close the twin before (or with) its parent; the communicator stays the parent's."""
+        other = ShardedBackprojection(self.shape, self.origin, self.voxel_size, rank=self.rank, world_size=self.world_size,
+                                      device=self.device, **self._ctor)
+        other.force_collective = self.force_collective
+        other.comm = self.comm
+        other._comm_shared = True
+        other._sparse_cap = self._sparse_cap
+        return other
 
     def _bricks_max(self):
         ny, nz = self.shape[1], self.shape[2]
@@ -792,7 +809,7 @@ class ShardedBackprojection:
     def close(self):
         if self._engine is not None:
             self._settle()
-            if self.comm is not None:
+            if self.comm is not None and getattr(self.comm, "_h", 0):  # (a twin outliving its parent: the communicator is gone)
                 self.comm.synchronize()
             self._engine.synchronize()
             for buf in self._sparse_recv:
@@ -800,7 +817,8 @@ class ShardedBackprojection:
                     buf.free()
             self._sparse_recv = [None, None]
             if self.comm is not None:
-                self.comm.close()
+                if not self._comm_shared:
+                    self.comm.close()
                 self.comm = None
             self._engine.close()
             self._engine = None

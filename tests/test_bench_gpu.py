@@ -54,6 +54,8 @@ def test_bench_line_at_one_gpu_carries_parity_and_cold_process(gpu_device):
     assert pc["ok"] is True and pc["fused_equals_per_view"] and pc["oracle_whole_grid"] is True
     assert pc["oracle_digest_key"] == "plant_128_12" and pc["fused_equals_committed_oracle_digest"] is True
     assert sum(pc["labels_histogram"]) == 128 ** 3
+    pl = out["pipelined"]  # two scans in flight: reported beside `value`, never as it
+    assert pl["engines"] == 2 and pl["labels_equal"] is True and pl["value"] > 0
     cp = out["cold_process"]
     assert "error" not in cp, cp
     assert out["cold_process_first_batch_ms"] == cp["first_batch_ms"] > 0
@@ -76,6 +78,9 @@ def test_bench_rehearsal_carries_the_assembly_over_the_library_communicator(gpu_
     assert asm["gather_to_host_sparse_ms"] > 0 and "error" not in out["strong"]
     pc = out["parity_check"]
     assert pc["ok"] is True and pc["oracle_whole_grid"] is True and pc["fused_equals_committed_oracle_digest"] is True
+    # the assembled headline deals its steps to two engines in turn; the same loop on one engine stands beside it
+    assert out["twin_engine_labels_equal"] is True and pc["twin_engine_labels_equal"] is True
+    assert out["ms_per_step_one_engine"] > 0 and out["value_one_engine"] > 0 and "TWO engines" in out["value_is"]
 
 
 @pytest.mark.gpu

@@ -98,6 +98,16 @@ def _worker(rank, world, port, shape, mode, q, partition="cyclic"):
             sb._sparse_cap = 16
             res["ags_small_cap"] = sb.all_gather(compress="sparse").numpy()
             res["cap_after"] = sb._sparse_cap
+            # a twin engine on the same planes (the double buffering of a pipeline of scans): the two take gathers in
+            # turn, on every rank alike, and each assembles the whole grid
+            tw = sb.twin()
+            assert tw.planes == sb.planes and tw.comm is sb.comm and tw._sparse_cap == sb._sparse_cap
+            for K, R, t, m in views:
+                tw.process_view(K, R, t, m)
+            first = sb.all_gather(compress="sparse").numpy().copy()
+            res["ags_twin"] = tw.all_gather(compress="sparse").numpy().copy()
+            assert np.array_equal(first, sb.all_gather(compress="sparse").numpy())
+            tw.close()
         q.put(res)
     finally:
         dist.barrier()
@@ -139,6 +149,7 @@ def test_gloo_sharded_equals_single(world, shape, mode, partition):
             assert np.array_equal(res["ag1"], (want == 1).astype(np.int8))
             assert np.array_equal(res["ags"], want) and res["agsn"].dtype == np.int8 and np.array_equal(res["agsn"], want)
             assert np.array_equal(res["ags_small_cap"], want) and res["cap_after"] >= 16
+            assert np.array_equal(res["ags_twin"], want)
             if res["rank"] == 0:
                 assert res["hosts"].dtype == np.int32 and np.array_equal(res["hosts"], want)
             else:

@@ -195,6 +195,34 @@ def test_library_rccl_group_of_one_sparse_and_dense_with_overlap(gpu_device):
     sb.close()
 
 
+def test_twin_engines_take_the_scans_in_turn_over_one_communicator(gpu_device):
+    """ShardedBackprojection.twin(): a second engine on the rank's planes sharing the library's communicator -- scan k's
+    pack and collective beside scan k + 1's carve on the other engine (what bench.py's `value` at N > 1 runs).  Different
+    scans alternate here, so a grid that came from the wrong engine or buffer would show."""
+    shape, origin, vs, views = scene((32, 64, 192), 10, "plant")
+    wants = [oracle_c.carve(shape, origin, vs, views[:n], nthreads=4) for n in (10, 3, 6, 1, 8)]
+    sb = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, device=0)
+    sb.force_collective = True
+    comm = sb.init_comm(nat.Comm.unique_id())
+    tw = sb.twin()
+    assert tw.comm is comm and tw.force_collective and tw.engine is not sb.engine
+    pair = (sb, tw)
+    grids = []
+    for i, n in enumerate((10, 3, 6, 1, 8)):
+        q = pair[i & 1]
+        q.clear()
+        for K, R, t, m in views[:n]:
+            q.process_view(K, R, t, m)
+        grids.append(q.all_gather(compress="sparse", unpack=False, overlap=True, check=False))
+        if i >= 1:
+            assert np.array_equal(grids[i - 1].verify().to_host(), wants[i - 1]), i - 1  # while scan i runs
+    assert np.array_equal(grids[-1].verify().to_host(), wants[-1])
+    assert np.array_equal(tw.get_local(), wants[3]) and np.array_equal(sb.get_local(), wants[4])
+    tw.close()
+    assert np.array_equal(sb.all_gather(compress="sparse", unpack=False).to_host(), wants[4])  # the parent's communicator lives on
+    sb.close()
+
+
 def test_sparse_form_at_the_benchmarked_size(gpu_device):
     """512^3 x 72, the plant: the sparse buffer of the fused batch decodes to the oracle's labels; its size."""
     shape, origin, vs, views = scene(512, 72, "plant")

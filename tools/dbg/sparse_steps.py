@@ -54,6 +54,33 @@ from plant3dvision_amd.sharded import DevMem
 rb = [DevMem(eng, stride), DevMem(eng, stride)]
 if "G" in VAR: run("G raw eng.all_gather_sparse overlap", lambda i: (batch(), eng.all_gather_sparse(comm, cap, rb[i & 1].ptr, stride, overlap=True)), fin)
 if "H" in VAR: run("H raw comm.all_gather only (4 MB)", lambda i: comm.all_gather(rb[0].ptr, rb[1].ptr, stride), fin)
+if "T" in VAR:
+    # two engines take turns (double buffering at the engine's grain): engine B carves step k + 1 while engine A's labels
+    # of step k are packed and gathered -- the pack is on A's stream, nobody's next carve waits for it
+    sb2 = ShardedBackprojection(shape, origin, vs, rank=0, world_size=1, device=0)
+    sb2.force_collective = True
+    sb2.comm = comm
+    sbs = (sb, sb2)
+    def batch_on(e):
+        e.clear(); e.process_views_device(K, R, t, ptr, V, H, W, nat.SC_MASK_U8)
+    for q in sbs:
+        batch_on(q.engine); q.all_gather(compress="sparse", unpack=False)
+    stT = {}
+    def stepT(i, ver=True):
+        q = sbs[i & 1]
+        batch_on(q.engine)
+        g = q.all_gather(compress="sparse", unpack=False, overlap=True, check=False)
+        if ver and stT.get("p") is not None: stT["p"].verify()
+        stT["p"] = g
+    def finT():
+        for q in sbs: q.engine.synchronize()
+        comm.synchronize()
+    run("T two engines in turn, overlap, verify prev", stepT, finT)
+    run("T' the same without verify", lambda i: stepT(i, False), finT)
+    def stepA2(i):
+        q = sbs[i & 1]; batch_on(q.engine); q.engine.flush()
+    run("A2 carve only, two engines in turn", stepA2, finT)
+    sb2.comm = None
 if "P" in VAR:
     import cProfile, pstats
     st = {}
