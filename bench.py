@@ -866,11 +866,15 @@ def strong_scaling(a, nat, torch, dist, scenes, ShardedBackprojection, rank, wor
             eng.dev_free(masks_dev)
             sb.close()
             return {"error": "a rank could not create a second communicator: the strong leg was skipped on every rank"}
-    dta = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=True, form="sparse")
+    twin = sb.twin() if (a.twin_engine and sb.comm is not None) else None  # two engines in turn, as the headline at N > 1
+    dta = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=True, form="sparse", twin=twin)
     dts = assembled_steps(nat, torch, dist, sb, eng, call, steps, 2, overlap=False, form="sparse")
+    if twin is not None:
+        twin.close()
     out = {"workload": f"ONE {a.n}^3 x {V} grid split over {world} rank(s), x-planes cyclic ({len(sb.planes)} planes per rank)",
            "value": n_total * V * steps / dta / 1e6, "ms_per_step": dta / steps * 1e3, "steps": steps,
-           "value_is": "carve + sparse pack + all-gather per step, the collective beside the next step's carve (as the headline at N > 1)",
+           "value_is": "carve + sparse pack + all-gather per step, the collective beside the next step's carve"
+                       + (", two engines taking the steps in turn" if a.twin_engine and sb.comm is not None else "") + " (as the headline at N > 1)",
            "value_carve_only": n_total * V * steps / dt / 1e6, "ms_per_step_carve_only": dt / steps * 1e3,
            "value_serial_assembly": n_total * V * steps / dts / 1e6, "ms_per_step_serial_assembly": dts / steps * 1e3,
            "unit": "Mvoxel*views/s", "scaling": "strong"}
@@ -1491,8 +1495,9 @@ def main():
             import hashlib
             twin_check = hashlib.sha256(twin.get_local().tobytes()).hexdigest() == hashlib.sha256(sb.get_local().tobytes()).hexdigest()
             dt_asm_one = assembled_steps(nat, torch, dist, sb, eng, call, a.steps, a.warmup, overlap=True, form="sparse")
-            twin.close()
-            twin = None
+            # (the twin is closed at the very end: behind an engine's destruction -- its hipFree / hipHostFree calls -- the
+            # small device-to-host copy of the headers on the ENGINE's stream, the serial legs below, took 0.12 ms per step
+            # where it takes none before: tools/dbg/sparse_steps.py VARIANTS=ACT, 0.183 -> 0.299 ms)
     if collective and a.assembly_steps > 0:
         asm = assembly(a, nat, torch, dist, sb, eng, call, a.assembly_steps, n_total, V)
         if world == 1:
@@ -1694,6 +1699,8 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.dev_free(masks_dev)
     BARRIER = None
+    if twin is not None:
+        twin.close()
     sb.close()
     if collective:
         dist.barrier()

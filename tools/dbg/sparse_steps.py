@@ -80,7 +80,29 @@ if "T" in VAR:
     def stepA2(i):
         q = sbs[i & 1]; batch_on(q.engine); q.engine.flush()
     run("A2 carve only, two engines in turn", stepA2, finT)
+    if "C" in VAR: run("C again, twin alive", lambda i: stepC(i), fin)
     sb2.comm = None
+    sb2.close()
+    if "C" in VAR: run("C again, after the twin is closed", lambda i: stepC(i), fin)
+    if "F" in VAR: run("F again, after the twin is closed", lambda i: stepC(i, False, True), fin)
+    if "Q" in VAR:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for i in range(100): stepC(i)
+        pr.disable(); fin()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(8)
+        import ctypes
+        t0 = time.perf_counter()
+        for i in range(100):
+            batch(); eng.flush()
+        t1 = time.perf_counter(); fin()
+        print("carve only enqueue after twin", (t1 - t0) / 100 * 1e3)
+        for name in ("values_sparse",):
+            t0 = time.perf_counter()
+            for i in range(100):
+                batch(); eng.values_sparse(sb._sparse_cap)
+            t1 = time.perf_counter(); fin()
+            print("carve + values_sparse enqueue", (t1 - t0) / 100 * 1e3, "total", (time.perf_counter() - t0) / 100 * 1e3)
 if "P" in VAR:
     import cProfile, pstats
     st = {}
